@@ -1,0 +1,116 @@
+/*
+ * pilot_ot.h -- C ABI of libpilot_ot.so, the MI355X (gfx950) pairwise-Wasserstein engine.
+ *
+ * Drop-in boundary.  The reference (CostaLab/PILOT, pilotpy 2.0.6) has no FFI layer: the hot
+ * path sits behind two Python call signatures,
+ *     wasserstein_d(Clu_rep, cost, regularized, reg)   pilotpy/tools/Trajectory.py:479-523
+ *     cost_matrix(annot, data, metric)                 pilotpy/tools/Trajectory.py:441-475
+ * whose inner arithmetic is one POT call per ordered sample pair
+ *     ot.sinkhorn2(a, b, M, reg, method="sinkhorn_stabilized")     Trajectory.py:515
+ *     ot.emd2(a, b, M)                                             Trajectory.py:511
+ * and one scipy call  pdist(centroids, metric) + squareform        Trajectory.py:468-469.
+ * The entry points below are what a ctypes binding for that path binds (INTEGRATION.md shows
+ * the binding).  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns PILOT_OT_OK (0) or a negative PILOT_OT_E* code; the message of the
+ *     last failure on the calling thread is pilot_ot_last_error().  No exceptions cross the ABI.
+ *   - "host" entry points take caller-owned host buffers, copy in/out internally and retain no
+ *     pointer after returning.  "_dev" entry points take device pointers (hipMalloc'ed by the
+ *     caller or by pilot_ot_dev_alloc) and enqueue on the given hipStream_t without synchronising.
+ *   - there is NO CPU implementation behind this ABI: without a gfx950 device every compute entry
+ *     point fails with PILOT_OT_EHIP.
+ *   - matrices are row-major; P is N x K (one proportion vector per sample, rows sum to 1,
+ *     Trajectory.py:428-430); M is K x K, already divided by its max (Trajectory.py:101).
+ *   - rows of the pair grid are selected as row_begin, row_begin+row_step, ... < row_end; every
+ *     selected row is paired with ALL N columns (diagonal included, no symmetry shortcut,
+ *     Trajectory.py:508-515).  Outputs hold n_rows x N values, n_rows = ceil((row_end-row_begin)/row_step).
+ */
+#ifndef PILOT_OT_H
+#define PILOT_OT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PILOT_OT_VERSION 100 /* 0.1.0 */
+
+/* return codes */
+#define PILOT_OT_OK 0
+#define PILOT_OT_EINVAL (-1)  /* bad argument                                              */
+#define PILOT_OT_EHIP (-2)    /* HIP runtime error / no gfx950 device                      */
+#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support (K > 128, ...)      */
+
+/* precision of the Sinkhorn pair-grid kernel */
+#define PILOT_OT_PREC_AUTO 0 /* f32 when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
+#define PILOT_OT_PREC_F32 1
+#define PILOT_OT_PREC_F64 2
+
+/* per-pair flag bits (flags output) */
+#define PILOT_OT_FLAG_CONVERGED 1      /* stopped on err <= stop_thr                              */
+#define PILOT_OT_FLAG_NAN 2            /* a scaling became NaN (POT: "Numerical errors"); emd = NaN */
+#define PILOT_OT_FLAG_ABSORB_LAST 4    /* POT tau-absorption fell on the final update (plan /K^2)   */
+#define PILOT_OT_FLAG_ABSORBED 8       /* at least one POT tau-absorption happened                  */
+#define PILOT_OT_FLAG_F64 16           /* pair was solved by the f64 kernel                         */
+
+/* ground metrics of pilot_ot_cost_matrix (scipy.spatial.distance.pdist names, Trajectory.py:468) */
+#define PILOT_OT_METRIC_COSINE 0
+#define PILOT_OT_METRIC_EUCLIDEAN 1
+#define PILOT_OT_METRIC_SQEUCLIDEAN 2
+#define PILOT_OT_METRIC_CITYBLOCK 3
+#define PILOT_OT_METRIC_CHEBYSHEV 4
+#define PILOT_OT_METRIC_CORRELATION 5
+
+/* ---- library / device --------------------------------------------------------------------- */
+int pilot_ot_version(void);
+const char *pilot_ot_last_error(void);
+int pilot_ot_device_count(int *count);            /* number of visible HIP devices (0 is not an error) */
+int pilot_ot_set_device(int device);              /* device used by the calling thread's later calls   */
+int pilot_ot_device_name(char *buf, int buflen);  /* gcnArchName of the current device                 */
+
+/* thin device-memory helpers so a host language without a HIP binding can keep data resident */
+int pilot_ot_dev_alloc(void **dptr, unsigned long long bytes);
+int pilot_ot_dev_free(void *dptr);
+int pilot_ot_memcpy_h2d(void *dst, const void *src, unsigned long long bytes);
+int pilot_ot_memcpy_d2h(void *dst, const void *src, unsigned long long bytes);
+int pilot_ot_stream_sync(void *stream);
+
+/* ---- cost matrix: replaces scipy pdist+squareform at Trajectory.py:468-469 ------------------ */
+/* centroids: K x D row-major (per-cell-type medians, Trajectory.py:465-466).  cost: K x K,
+ * symmetric, zero diagonal, NOT normalised (the reference stores the raw matrix, :98-99). */
+int pilot_ot_cost_matrix(const double *centroids, int K, int D, int metric, double *cost);
+int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric, double *d_cost,
+                             void *stream);
+
+/* ---- Sinkhorn pair grid: replaces the loop at Trajectory.py:512-515 ------------------------- */
+/* Each pair follows POT 0.9.x sinkhorn_stabilized control flow (v-update then u-update; marginal
+ * error ||Gamma^T 1 - b||_2 evaluated when ii % check_period == 0; stop on err <= stop_thr or
+ * after num_iter_max updates) and returns <Gamma, M> like ot.sinkhorn2.  POT defaults:
+ * num_iter_max=1000, stop_thr=1e-9, tau=1e3, check_period=20.  In f32 the stop threshold is
+ * floored at f32_floor_ulps * FLT_EPSILON * ||b||_2 (pass 0 for the default of 8).
+ * cost_is_symmetric: 1 if M == M^T exactly (always true for pdist output), 0 otherwise.
+ * emd / iters / err / flags: n_rows x N; iters, err, flags may be NULL. */
+int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg,
+                           int num_iter_max, double stop_thr, double tau, int check_period,
+                           int precision, double f32_floor_ulps, int cost_is_symmetric,
+                           int row_begin, int row_end, int row_step,
+                           double *emd, int *iters, double *err, int *flags);
+
+/* Device-resident form.  A plan owns the device workspace for one (N, K) shape so the call itself
+ * allocates nothing (HIP-graph capturable). */
+typedef struct pilot_ot_plan pilot_ot_plan;
+int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan);
+int pilot_ot_plan_destroy(pilot_ot_plan *plan);
+int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *plan, const double *d_P, const double *d_M, double reg,
+                               int num_iter_max, double stop_thr, double tau, int check_period,
+                               int precision, double f32_floor_ulps, int cost_is_symmetric,
+                               int row_begin, int row_end, int row_step,
+                               double *d_emd, int *d_iters, double *d_err, int *d_flags,
+                               void *stream);
+/* precision actually selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (1 or 2) */
+int pilot_ot_auto_precision(double max_cost_over_reg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PILOT_OT_H */

@@ -1,0 +1,330 @@
+/*
+ * oracle/pilot_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C fp64 restatement of the arithmetic behind the reference hot path
+ *   pilotpy/tools/Trajectory.py:479-523 (wasserstein_d), whose inner calls are
+ *   ot.sinkhorn2(a, b, M, reg, method="sinkhorn_stabilized")   Trajectory.py:515
+ *   ot.emd2(a, b, M)                                           Trajectory.py:511
+ * The arithmetic itself lives in the third-party package POT
+ * (pot>=0.9.1,<0.10.0, /root/reference/setup.py:19), which is NOT vendored in
+ * the reference tree and NOT installed in the build container, so:
+ *
+ *   PARITY UNPINNED: the Sinkhorn control flow below is a restatement of the
+ *   published POT 0.9.x algorithm (ot/bregman/_sinkhorn.py::sinkhorn_stabilized
+ *   and ::sinkhorn2), not a diff against POT output.  What IS pinned:
+ *     - converged Sinkhorn values against an independent log-domain solver
+ *       (unique entropic optimum)            tests/test_oracle_sinkhorn.py
+ *     - exact EMD values against scipy.optimize.linprog(HiGHS) (unique LP
+ *       optimum value)                        tests/test_oracle_emd.py
+ *     - the reference's own loop / layout, run here through a stub import
+ *                                             tests/golden/gen_golden.py
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (pilot_amd/) never does.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* info[] slots filled by the Sinkhorn oracle (all optional) */
+enum {
+    ORACLE_INFO_ITERS = 0,        /* number of (v,u) updates executed            */
+    ORACLE_INFO_NABSORB = 1,      /* number of tau-absorptions                   */
+    ORACLE_INFO_LAST_ABSORB = 2,  /* ii of the last absorption, -1 if none       */
+    ORACLE_INFO_FLAGS = 3,        /* bit0: converged, bit1: NaN-revert,          */
+                                  /* bit2: absorption fell on the final update   */
+    ORACLE_INFO_N = 4
+};
+
+ORACLE_API int pilot_oracle_version(void) { return 1; }
+
+/* exp(-(M - alpha_i - beta_j)/reg): POT sinkhorn_stabilized.get_K */
+static void get_K(const double *M, const double *alpha, const double *beta,
+                  int na, int nb, double reg, double *K)
+{
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j)
+            K[(size_t)i * nb + j] = exp(-(M[(size_t)i * nb + j] - alpha[i] - beta[j]) / reg);
+}
+
+/* exp(-(M - alpha_i - beta_j)/reg + log u_i + log v_j): POT get_Gamma */
+static void get_Gamma(const double *M, const double *alpha, const double *beta,
+                      const double *u, const double *v, int na, int nb,
+                      double reg, double *G)
+{
+    for (int i = 0; i < na; ++i) {
+        const double lu = log(u[i]);
+        for (int j = 0; j < nb; ++j)
+            G[(size_t)i * nb + j] =
+                exp(-(M[(size_t)i * nb + j] - alpha[i] - beta[j]) / reg + lu + log(v[j]));
+    }
+}
+
+/*
+ * One ot.sinkhorn2(a, b, M, reg, method="sinkhorn_stabilized") call.
+ *
+ * POT 0.9.x sinkhorn_stabilized (single-histogram branch), defaults
+ * numItermax=1000, tau=1e3, stopThr=1e-9, print_period=20:
+ *
+ *   alpha=beta=0; u=1/na; v=1/nb; K=get_K(alpha,beta); err=1
+ *   for ii in range(numItermax):
+ *       uprev,vprev=u,v
+ *       v = b/(K.T@u); u = a/(K@v)
+ *       if max|u|>tau or max|v|>tau:
+ *           alpha+=reg*log(u); beta+=reg*log(v); u=1/na; v=1/nb; K=get_K(alpha,beta)
+ *       if ii % print_period == 0:
+ *           err = ||get_Gamma(alpha,beta,u,v).sum(0) - b||_2
+ *       if err <= stopThr: break
+ *       if any(isnan(u)) or any(isnan(v)): u,v=uprev,vprev; break
+ *   return sum(M * get_Gamma(alpha,beta,u,v))          # ot.sinkhorn2
+ *
+ * legacy_loop != 0 selects the POT <= 0.7 `while loop:` form in which the
+ * update at ii == numItermax still runs (numItermax+1 updates); kept only so
+ * the iteration-cap sensitivity can be measured ("parity unpinned").
+ *
+ * Note (restated faithfully, not "fixed"): right after an absorption u,v are
+ * reset to 1/na,1/nb rather than 1, so the plan evaluated in that same
+ * iteration is scaled by 1/(na*nb) until the next update restores the scale.
+ */
+ORACLE_API double pilot_oracle_sinkhorn2_stabilized(
+    const double *a, const double *b, const double *M, int na, int nb,
+    double reg, int numItermax, double tau, double stopThr, int print_period,
+    int legacy_loop, int *info, double *err_out)
+{
+    double *buf = (double *)malloc(sizeof(double) * ((size_t)2 * na * nb + 3 * (size_t)na + 3 * (size_t)nb));
+    double *K = buf, *G = K + (size_t)na * nb;
+    double *alpha = G + (size_t)na * nb, *u = alpha + na, *uprev = u + na;
+    double *beta = uprev + na, *v = beta + nb, *vprev = v + nb;
+    for (int i = 0; i < na; ++i) { alpha[i] = 0.0; u[i] = 1.0 / na; }
+    for (int j = 0; j < nb; ++j) { beta[j] = 0.0; v[j] = 1.0 / nb; }
+    get_K(M, alpha, beta, na, nb, reg, K);
+
+    double err = 1.0;
+    int iters = 0, nabs = 0, last_abs = -1, flags = 0;
+    const int last_ii = legacy_loop ? numItermax : numItermax - 1;
+    for (int ii = 0; ii <= last_ii; ++ii) {
+        memcpy(uprev, u, sizeof(double) * na);
+        memcpy(vprev, v, sizeof(double) * nb);
+        /* v = b / (K.T @ u) */
+        for (int j = 0; j < nb; ++j) v[j] = 0.0;
+        for (int i = 0; i < na; ++i) {
+            const double ui = u[i];
+            const double *Ki = K + (size_t)i * nb;
+            for (int j = 0; j < nb; ++j) v[j] += Ki[j] * ui;
+        }
+        for (int j = 0; j < nb; ++j) v[j] = b[j] / v[j];
+        /* u = a / (K @ v) */
+        for (int i = 0; i < na; ++i) {
+            const double *Ki = K + (size_t)i * nb;
+            double s = 0.0;
+            for (int j = 0; j < nb; ++j) s += Ki[j] * v[j];
+            u[i] = a[i] / s;
+        }
+        iters = ii + 1;
+
+        int has_nan = 0;
+        double mu = 0.0, mv = 0.0;
+        for (int i = 0; i < na; ++i) { if (isnan(u[i])) has_nan = 1; if (fabs(u[i]) > mu) mu = fabs(u[i]); }
+        for (int j = 0; j < nb; ++j) { if (isnan(v[j])) has_nan = 1; if (fabs(v[j]) > mv) mv = fabs(v[j]); }
+
+        /* np.max of an array holding a NaN is NaN and `NaN > tau` is False */
+        if (!has_nan && (mu > tau || mv > tau)) {
+            for (int i = 0; i < na; ++i) { alpha[i] += reg * log(u[i]); u[i] = 1.0 / na; }
+            for (int j = 0; j < nb; ++j) { beta[j] += reg * log(v[j]); v[j] = 1.0 / nb; }
+            get_K(M, alpha, beta, na, nb, reg, K);
+            ++nabs; last_abs = ii;
+        }
+        if (ii % print_period == 0) {
+            get_Gamma(M, alpha, beta, u, v, na, nb, reg, G);
+            double e2 = 0.0;
+            for (int j = 0; j < nb; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < na; ++i) s += G[(size_t)i * nb + j];
+                e2 += (s - b[j]) * (s - b[j]);
+            }
+            err = sqrt(e2);
+        }
+        if (err <= stopThr) { flags |= 1; break; }
+        if (has_nan) {
+            memcpy(u, uprev, sizeof(double) * na);
+            memcpy(v, vprev, sizeof(double) * nb);
+            flags |= 2;
+            break;
+        }
+    }
+    if (last_abs >= 0 && last_abs == iters - 1) flags |= 4;
+
+    get_Gamma(M, alpha, beta, u, v, na, nb, reg, G);
+    double val = 0.0;
+    for (size_t t = 0; t < (size_t)na * nb; ++t) val += M[t] * G[t];
+    if (info) {
+        info[ORACLE_INFO_ITERS] = iters;
+        info[ORACLE_INFO_NABSORB] = nabs;
+        info[ORACLE_INFO_LAST_ABSORB] = last_abs;
+        info[ORACLE_INFO_FLAGS] = flags;
+    }
+    if (err_out) *err_out = err;
+    free(buf);
+    return val;
+}
+
+/*
+ * The reference's pair loop, Trajectory.py:512-515, over rows
+ * row_begin, row_begin+row_step, ... < row_end and ALL N columns (diagonal
+ * included, no symmetry shortcut).  P is N x K row-major (one proportion
+ * vector per sample, Trajectory.py:428-430), M is K x K (already divided by
+ * its max, Trajectory.py:101).  emd receives one row of N values per selected
+ * row; iters/err (nullable) have the same shape.  n_threads<=1: the
+ * reference's single-threaded order; >1: OpenMP over pairs (bench baseline).
+ */
+ORACLE_API int pilot_oracle_sinkhorn_grid(
+    const double *P, int N, int K, const double *M, double reg,
+    int numItermax, double tau, double stopThr, int print_period, int legacy_loop,
+    int row_begin, int row_end, int row_step, int n_threads,
+    double *emd, int *iters, double *err, int *flags)
+{
+    if (N <= 0 || K <= 0 || row_step <= 0 || row_begin < 0 || row_end > N) return -1;
+    const int nrows = row_end > row_begin ? (row_end - row_begin + row_step - 1) / row_step : 0;
+    const long total = (long)nrows * N;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+#endif
+    for (long t = 0; t < total; ++t) {
+        const int r = (int)(t / N), j = (int)(t % N);
+        const int i = row_begin + r * row_step;
+        int info[ORACLE_INFO_N];
+        double e;
+        emd[t] = pilot_oracle_sinkhorn2_stabilized(P + (size_t)i * K, P + (size_t)j * K, M, K, K,
+                                                   reg, numItermax, tau, stopThr, print_period,
+                                                   legacy_loop, info, &e);
+        if (iters) iters[t] = info[ORACLE_INFO_ITERS];
+        if (err) err[t] = e;
+        if (flags) flags[t] = info[ORACLE_INFO_FLAGS];
+    }
+    (void)n_threads;
+    return 0;
+}
+
+/*
+ * Exact optimal-transport cost, the value ot.emd2(a, b, M) returns
+ * (Trajectory.py:511).  POT solves the transportation LP with a LEMON-derived
+ * network simplex (ot/lp/EMD_wrapper.cpp, network_simplex_simple.h; not in the
+ * reference tree).  The LP optimum VALUE is unique, so any exact method gives
+ * the same number up to rounding; this oracle uses successive shortest paths
+ * with node potentials on the dense bipartite residual graph (every
+ * augmentation keeps complementary slackness, so the final flow is optimal),
+ * after POT's own pre-step b *= sum(a)/sum(b) (ot/lp/__init__.py::emd2).
+ * Validated against scipy.optimize.linprog(HiGHS) in tests/test_oracle_emd.py.
+ * G (nullable, na x nb) receives the optimal plan.
+ */
+ORACLE_API double pilot_oracle_emd2(const double *a, const double *b_in, const double *M,
+                                    int na, int nb, double *G_out)
+{
+    const int nn = na + nb;
+    double *F = (double *)calloc((size_t)na * nb, sizeof(double));
+    double *w = (double *)malloc(sizeof(double) * ((size_t)3 * nn + nb));
+    int *iw = (int *)malloc(sizeof(int) * (size_t)2 * nn);
+    double *pu = w, *pv = pu + na, *ra = pv + nb, *rb = ra + na;
+    double *dist = rb + nb;            /* [0,na): rows, [na,nn): cols */
+    double *b = dist + nn;
+    int *parent = iw, *done = iw + nn; /* parent of a col = row index; of a row = col index */
+
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < na; ++i) sa += a[i];
+    for (int j = 0; j < nb; ++j) sb += b_in[j];
+    for (int j = 0; j < nb; ++j) b[j] = b_in[j] * (sa / sb);
+    for (int i = 0; i < na; ++i) {
+        double m = M[(size_t)i * nb];
+        for (int j = 1; j < nb; ++j) if (M[(size_t)i * nb + j] < m) m = M[(size_t)i * nb + j];
+        pu[i] = m; ra[i] = a[i];
+    }
+    for (int j = 0; j < nb; ++j) { pv[j] = 0.0; rb[j] = b[j]; }
+    const double tol = 1e-15 * (sa > 0 ? sa : 1.0);
+
+    for (int s = 0; s < na; ++s) {
+        while (ra[s] > tol) {
+            for (int n = 0; n < nn; ++n) { dist[n] = INFINITY; parent[n] = -1; done[n] = 0; }
+            dist[s] = 0.0;
+            int target = -1;
+            double dstar = 0.0;
+            for (;;) {
+                int best = -1; double bd = INFINITY;
+                for (int n = 0; n < nn; ++n) if (!done[n] && dist[n] < bd) { bd = dist[n]; best = n; }
+                if (best < 0) break;
+                done[best] = 1;
+                if (best >= na) {                     /* a column */
+                    const int j = best - na;
+                    if (rb[j] > 0.0) { target = j; dstar = bd; break; }
+                    for (int i = 0; i < na; ++i) {    /* backward arcs j -> i where F_ij > 0 */
+                        if (done[i] || F[(size_t)i * nb + j] <= 0.0) continue;
+                        double rc = M[(size_t)i * nb + j] - pu[i] - pv[j];   /* == 0 up to rounding */
+                        double nd = bd - rc; if (nd < bd) nd = bd;
+                        if (nd < dist[i]) { dist[i] = nd; parent[i] = j; }
+                    }
+                } else {                              /* a row: forward arcs i -> j */
+                    const int i = best;
+                    for (int j = 0; j < nb; ++j) {
+                        if (done[na + j]) continue;
+                        double rc = M[(size_t)i * nb + j] - pu[i] - pv[j];
+                        if (rc < 0.0) rc = 0.0;
+                        const double nd = bd + rc;
+                        if (nd < dist[na + j]) { dist[na + j] = nd; parent[na + j] = i; }
+                    }
+                }
+            }
+            if (target < 0) { ra[s] = 0.0; break; }   /* only rounding dust left */
+            /* potentials: rc'(i,j) = rc + min(d_i,d*) - min(d_j,d*) >= 0 */
+            for (int i = 0; i < na; ++i) pu[i] -= (dist[i] < dstar ? dist[i] : dstar);
+            for (int j = 0; j < nb; ++j) pv[j] += (dist[na + j] < dstar ? dist[na + j] : dstar);
+            /* bottleneck */
+            double delta = ra[s] < rb[target] ? ra[s] : rb[target];
+            for (int j = target;;) {
+                const int i = parent[na + j];
+                if (i == s) break;
+                const int jb = parent[i];
+                if (F[(size_t)i * nb + jb] < delta) delta = F[(size_t)i * nb + jb];
+                j = jb;
+            }
+            for (int j = target;;) {
+                const int i = parent[na + j];
+                F[(size_t)i * nb + j] += delta;
+                if (i == s) break;
+                const int jb = parent[i];
+                F[(size_t)i * nb + jb] -= delta;
+                j = jb;
+            }
+            ra[s] -= delta; rb[target] -= delta;
+        }
+    }
+    double cost = 0.0;
+    for (size_t t = 0; t < (size_t)na * nb; ++t) cost += F[t] * M[t];
+    if (G_out) memcpy(G_out, F, sizeof(double) * (size_t)na * nb);
+    free(F); free(w); free(iw);
+    return cost;
+}
+
+/* The reference's exact pair loop, Trajectory.py:507-511. */
+ORACLE_API int pilot_oracle_emd_grid(const double *P, int N, int K, const double *M,
+                                     int row_begin, int row_end, int row_step, int n_threads,
+                                     double *emd)
+{
+    if (N <= 0 || K <= 0 || row_step <= 0 || row_begin < 0 || row_end > N) return -1;
+    const int nrows = row_end > row_begin ? (row_end - row_begin + row_step - 1) / row_step : 0;
+    const long total = (long)nrows * N;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+#endif
+    for (long t = 0; t < total; ++t) {
+        const int i = row_begin + (int)(t / N) * row_step, j = (int)(t % N);
+        emd[t] = pilot_oracle_emd2(P + (size_t)i * K, P + (size_t)j * K, M, K, K, NULL);
+    }
+    (void)n_threads;
+    return 0;
+}

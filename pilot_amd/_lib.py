@@ -1,0 +1,105 @@
+"""ctypes binding of ``libpilot_ot.so`` (C ABI: ``include/pilot_ot.h``).
+
+This is the only way the Python host reaches the device.  There is no CPU code path behind
+it: if the shared library is missing or no gfx950 device is visible, the compute calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpilot_ot.so")
+
+OK, EINVAL, EHIP, ENOTSUP = 0, -1, -2, -3
+PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2}
+METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5}
+
+FLAG_CONVERGED, FLAG_NAN, FLAG_ABSORB_LAST, FLAG_ABSORBED, FLAG_F64 = 1, 2, 4, 8, 16
+
+# every symbol include/pilot_ot.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "pilot_ot_version", "pilot_ot_last_error", "pilot_ot_device_count", "pilot_ot_set_device",
+    "pilot_ot_device_name", "pilot_ot_dev_alloc", "pilot_ot_dev_free", "pilot_ot_memcpy_h2d",
+    "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
+    "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
+    "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision",
+]
+
+_lib = None
+
+
+class PilotOTError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libpilot_ot.so; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PilotOTError(
+            "libpilot_ot.so not found at %s -- build it with `make -C pilot_amd/csrc` "
+            "(or __graft_entry__.build()); pilot_amd has no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+    dp, ip = ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)
+    L.pilot_ot_version.restype = c_int
+    L.pilot_ot_last_error.restype = ctypes.c_char_p
+    L.pilot_ot_device_count.argtypes = [ip]
+    L.pilot_ot_set_device.argtypes = [c_int]
+    L.pilot_ot_device_name.argtypes = [ctypes.c_char_p, c_int]
+    L.pilot_ot_dev_alloc.argtypes = [ctypes.POINTER(c_vp), ctypes.c_ulonglong]
+    L.pilot_ot_dev_free.argtypes = [c_vp]
+    L.pilot_ot_memcpy_h2d.argtypes = [c_vp, c_vp, ctypes.c_ulonglong]
+    L.pilot_ot_memcpy_d2h.argtypes = [c_vp, c_vp, ctypes.c_ulonglong]
+    L.pilot_ot_stream_sync.argtypes = [c_vp]
+    L.pilot_ot_cost_matrix.argtypes = [dp, c_int, c_int, c_int, dp]
+    L.pilot_ot_cost_matrix_dev.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp]
+    L.pilot_ot_sinkhorn_grid.argtypes = [dp, c_int, c_int, dp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int,
+                                         c_dbl, c_int, c_int, c_int, c_int, dp, ip, dp, ip]
+    L.pilot_ot_plan_create.argtypes = [c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_plan_destroy.argtypes = [c_vp]
+    L.pilot_ot_sinkhorn_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl,
+                                             c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.pilot_ot_auto_precision.argtypes = [c_dbl]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name != "pilot_ot_last_error":
+            fn.restype = c_int
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc == OK:
+        return
+    msg = load().pilot_ot_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError("pilot_ot: " + msg)
+    if rc == ENOTSUP:
+        raise NotImplementedError("pilot_ot: " + msg)
+    raise PilotOTError("pilot_ot (HIP): " + msg)
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    check(load().pilot_ot_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name() -> str:
+    buf = ctypes.create_string_buffer(128)
+    check(load().pilot_ot_device_name(buf, 128))
+    return buf.value.decode()
+
+
+def dptr(x: np.ndarray):
+    return x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def iptr(x: np.ndarray):
+    return x.ctypes.data_as(ctypes.POINTER(ctypes.c_int))

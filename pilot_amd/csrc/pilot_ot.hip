@@ -1,0 +1,415 @@
+// libpilot_ot.so -- C ABI over the gfx950 kernels (declared in include/pilot_ot.h).
+// Host side of the drop-in boundary for pilotpy/tools/Trajectory.py:441-523.
+// There is deliberately no CPU implementation in this file: without a HIP device every compute
+// entry point returns PILOT_OT_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/pilot_ot.h"
+#include "sinkhorn_kernels.hpp"
+
+#define PILOT_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(PILOT_OT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// K1: centroid cost matrix (scipy pdist + squareform, Trajectory.py:468-469).  K <= a few hundred,
+// D <= a few hundred: one workgroup, one thread per unordered pair, fp64 like scipy.  Far below the
+// size where an MFMA contraction pays (K*K*D = 75k FMAs at c3).
+__global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, int metric,
+                                   double *__restrict__ C) {
+    extern __shared__ double stat[];  // per-row norm (cosine) or mean + centred norm (correlation)
+    double *nrm = stat, *mean = stat + K;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const double *x = X + (size_t)i * D;
+        double m = 0.0;
+        if (metric == PILOT_OT_METRIC_CORRELATION) {
+            for (int d = 0; d < D; ++d) m += x[d];
+            m /= D;
+        }
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += (x[d] - m) * (x[d] - m);
+        mean[i] = m;
+        nrm[i] = sqrt(s);
+        C[(size_t)i * K + i] = 0.0;
+    }
+    __syncthreads();
+    const int npairs = K * (K - 1) / 2;
+    for (int pidx = threadIdx.x; pidx < npairs; pidx += blockDim.x) {
+        // unrank (i < j) from the condensed pdist index
+        int i = 0, rem = pidx;
+        while (rem >= K - 1 - i) { rem -= K - 1 - i; ++i; }
+        const int j = i + 1 + rem;
+        const double *u = X + (size_t)i * D, *v = X + (size_t)j * D;
+        double out = 0.0;
+        switch (metric) {
+        case PILOT_OT_METRIC_COSINE:
+        case PILOT_OT_METRIC_CORRELATION: {
+            const double mu = mean[i], mv = mean[j];
+            double dot = 0.0;
+            for (int d = 0; d < D; ++d) dot += (u[d] - mu) * (v[d] - mv);
+            double c = dot / (nrm[i] * nrm[j]);
+            if (fabs(c) > 1.0) c = copysign(1.0, c);  // scipy clips rounding overshoot
+            out = 1.0 - c;
+            break;
+        }
+        case PILOT_OT_METRIC_EUCLIDEAN:
+        case PILOT_OT_METRIC_SQEUCLIDEAN: {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) { const double t = u[d] - v[d]; s += t * t; }
+            out = metric == PILOT_OT_METRIC_EUCLIDEAN ? sqrt(s) : s;
+            break;
+        }
+        case PILOT_OT_METRIC_CITYBLOCK: {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) s += fabs(u[d] - v[d]);
+            out = s;
+            break;
+        }
+        default: {  // chebyshev
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) { const double t = fabs(u[d] - v[d]); s = t > s ? t : s; }
+            out = s;
+        }
+        }
+        C[(size_t)i * K + j] = out;
+        C[(size_t)j * K + i] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int RT, bool SYM, bool TRACK>
+hipError_t launch_one(dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
+    auto kern = pilot::sinkhorn_grid_kernel<T, RT, SYM, TRACK>;
+    if (lds > 32 * 1024) {  // beyond the default dynamic-LDS window the limit must be raised explicitly
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(pilot::WAVE * pilot::WAVES_PER_WG), lds, s, p);
+    return hipGetLastError();
+}
+
+template <typename T, int RT>
+hipError_t launch_rt(bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
+    if (sym) return track ? launch_one<T, RT, true, true>(grid, lds, s, p) : launch_one<T, RT, true, false>(grid, lds, s, p);
+    return track ? launch_one<T, RT, false, true>(grid, lds, s, p) : launch_one<T, RT, false, false>(grid, lds, s, p);
+}
+
+template <typename T>
+hipError_t launch_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
+    switch (RT) {
+    case 1: return launch_rt<T, 1>(sym, track, grid, lds, s, p);
+    case 2: return launch_rt<T, 2>(sym, track, grid, lds, s, p);
+    case 3: return launch_rt<T, 3>(sym, track, grid, lds, s, p);
+    case 4: return launch_rt<T, 4>(sym, track, grid, lds, s, p);
+    default: break;
+    }
+    if constexpr (sizeof(T) == 8) {
+        switch (RT) {
+        case 5: return launch_rt<T, 5>(sym, track, grid, lds, s, p);
+        case 6: return launch_rt<T, 6>(sym, track, grid, lds, s, p);
+        case 7: return launch_rt<T, 7>(sym, track, grid, lds, s, p);
+        case 8: return launch_rt<T, 8>(sym, track, grid, lds, s, p);
+        default: break;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+constexpr int MAX_K = 128;
+constexpr size_t LDS_BYTES = 160 * 1024;
+
+}  // namespace
+
+struct pilot_ot_plan {
+    int N, K, device;
+    void *img;         // 3 operand images, sized for f64 at this K
+    float *p_f32;      // N x K proportions converted to f32
+    int *track_list;   // N x N
+    int *track_count;  // 1
+};
+
+// ------------------------------------------------------------------------------------------------
+PILOT_API int pilot_ot_version(void) { return PILOT_OT_VERSION; }
+PILOT_API const char *pilot_ot_last_error(void) { return g_err; }
+
+PILOT_API int pilot_ot_device_count(int *count) {
+    if (!count) return fail(PILOT_OT_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_device_name(char *buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(PILOT_OT_EINVAL, "bad buffer");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_dev_alloc(void **dptr, unsigned long long bytes) {
+    if (!dptr) return fail(PILOT_OT_EINVAL, "dptr is NULL");
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    return PILOT_OT_OK;
+}
+PILOT_API int pilot_ot_dev_free(void *dptr) {
+    HIP_TRY(hipFree(dptr));
+    return PILOT_OT_OK;
+}
+PILOT_API int pilot_ot_memcpy_h2d(void *dst, const void *src, unsigned long long bytes) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PILOT_OT_OK;
+}
+PILOT_API int pilot_ot_memcpy_d2h(void *dst, const void *src, unsigned long long bytes) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return PILOT_OT_OK;
+}
+PILOT_API int pilot_ot_stream_sync(void *stream) {
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PILOT_OT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+PILOT_API int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric, double *d_cost,
+                                       void *stream) {
+    if (!d_centroids || !d_cost) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (K <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "K=%d D=%d must be positive", K, D);
+    if (metric < PILOT_OT_METRIC_COSINE || metric > PILOT_OT_METRIC_CORRELATION)
+        return fail(PILOT_OT_EINVAL, "unknown metric id %d", metric);
+    if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 centroids", K);
+    hipLaunchKernelGGL(cost_matrix_kernel, dim3(1), dim3(1024), 2 * sizeof(double) * K,
+                       static_cast<hipStream_t>(stream), d_centroids, K, D, metric, d_cost);
+    HIP_TRY(hipGetLastError());
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_cost_matrix(const double *centroids, int K, int D, int metric, double *cost) {
+    if (!centroids || !cost) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (K <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "K=%d D=%d must be positive", K, D);
+    double *dx = nullptr, *dc = nullptr;
+    HIP_TRY(hipMalloc(&dx, sizeof(double) * K * D));
+    hipError_t e = hipMalloc(&dc, sizeof(double) * K * K);
+    if (e != hipSuccess) { (void)hipFree(dx); return fail(PILOT_OT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = PILOT_OT_OK;
+    if ((e = hipMemcpy(dx, centroids, sizeof(double) * K * D, hipMemcpyHostToDevice)) != hipSuccess)
+        rc = fail(PILOT_OT_EHIP, "hipMemcpy H2D: %s", hipGetErrorString(e));
+    if (rc == PILOT_OT_OK) rc = pilot_ot_cost_matrix_dev(dx, K, D, metric, dc, nullptr);
+    if (rc == PILOT_OT_OK && (e = hipMemcpy(cost, dc, sizeof(double) * K * K, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = fail(PILOT_OT_EHIP, "hipMemcpy D2H: %s", hipGetErrorString(e));
+    (void)hipFree(dx);
+    (void)hipFree(dc);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+PILOT_API int pilot_ot_auto_precision(double max_cost_over_reg) {
+    // f32 keeps every Gibbs-kernel entry exp(-M/reg) a well-scaled normal number only while
+    // max(M)/reg stays clear of the f32 exponent range (ln FLT_MIN = -87.3); beyond ~60 the
+    // far-transport entries lose bits, so AUTO switches to the f64 kernel.
+    return max_cost_over_reg <= 60.0 ? PILOT_OT_PREC_F32 : PILOT_OT_PREC_F64;
+}
+
+PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
+    if (!plan) return fail(PILOT_OT_EINVAL, "plan is NULL");
+    if (N <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "N=%d K=%d must be positive", N, K);
+    if (K > MAX_K) return fail(PILOT_OT_ENOTSUP, "K=%d > %d cell types is not supported yet", K, MAX_K);
+    if ((long long)N * N > 0x7fffffffLL) return fail(PILOT_OT_ENOTSUP, "N=%d: N*N overflows the pair index", N);
+    pilot_ot_plan *pl = new (std::nothrow) pilot_ot_plan();
+    if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
+    pl->N = N; pl->K = K;
+    pl->img = nullptr; pl->p_f32 = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
+    hipError_t e = hipGetDevice(&pl->device);
+    const int kp = ((K + 31) / 32) * 32;
+    if (e == hipSuccess) e = hipMalloc(&pl->img, 3 * sizeof(double) * kp * kp);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->p_f32), sizeof(float) * (size_t)N * K);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), sizeof(int));
+    if (e != hipSuccess) {
+        pilot_ot_plan_destroy(pl);
+        return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
+    }
+    *plan = pl;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
+    if (!pl) return PILOT_OT_OK;
+    if (pl->img) (void)hipFree(pl->img);
+    if (pl->p_f32) (void)hipFree(pl->p_f32);
+    if (pl->track_list) (void)hipFree(pl->track_list);
+    if (pl->track_count) (void)hipFree(pl->track_count);
+    delete pl;
+    return PILOT_OT_OK;
+}
+
+namespace {
+
+int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr, double tau, int check_period,
+                    int precision, int row_begin, int row_end, int row_step) {
+    if (N <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "N=%d K=%d must be positive", N, K);
+    if (!(reg > 0.0) || !std::isfinite(reg)) return fail(PILOT_OT_EINVAL, "reg=%g must be positive and finite", reg);
+    if (num_iter_max < 1) return fail(PILOT_OT_EINVAL, "num_iter_max=%d must be >= 1", num_iter_max);
+    if (check_period < 1) return fail(PILOT_OT_EINVAL, "check_period=%d must be >= 1", check_period);
+    if (!(stop_thr >= 0.0) || !(stop_thr < 1.0)) return fail(PILOT_OT_EINVAL, "stop_thr=%g must be in [0, 1)", stop_thr);
+    if (!(tau > 1.0)) return fail(PILOT_OT_EINVAL, "tau=%g must be > 1", tau);
+    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_F64)
+        return fail(PILOT_OT_EINVAL, "unknown precision id %d", precision);
+    if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
+        return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
+    if (K > MAX_K) return fail(PILOT_OT_ENOTSUP, "K=%d > %d cell types is not supported yet", K, MAX_K);
+    return PILOT_OT_OK;
+}
+
+template <typename T>
+int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
+             double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
+             int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s) {
+    using M = pilot::Mfma<T>;
+    const int N = pl->N, K = pl->K;
+    const int RT = (K + M::TILE - 1) / M::TILE;
+    const int KP = RT * M::TILE;
+    size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * sizeof(T);
+    if (lds > LDS_BYTES)
+        return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision",
+                    K, lds, LDS_BYTES);
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, sizeof(int), s));
+    T *img = static_cast<T *>(pl->img);
+    const void *Pt;
+    if constexpr (sizeof(T) == 4) {
+        hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<float>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img,
+                           d_P, pl->p_f32, (long)N * K);
+        Pt = pl->p_f32;
+    } else {
+        hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<double>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img,
+                           static_cast<const double *>(nullptr), static_cast<double *>(nullptr), 0L);
+        Pt = d_P;
+    }
+    HIP_TRY(hipGetLastError());
+    if (n_rows == 0) return PILOT_OT_OK;
+
+    pilot::GridParams p;
+    p.P = Pt; p.img = img; p.N = N; p.K = K;
+    p.n_pairs = n_rows * N;
+    p.list = nullptr; p.list_len = nullptr;
+    p.row_begin = row_begin; p.row_step = row_step;
+    p.max_iter = num_iter_max; p.period = check_period;
+    p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
+    p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
+    p.track_list = pl->track_list; p.track_count = pl->track_count;
+    const int tiles = (p.n_pairs + M::TILE - 1) / M::TILE;
+    const dim3 grid((tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG);
+    HIP_TRY((launch_any<T>(RT, sym, false, grid, lds, s, p)));
+    // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
+    p.list = pl->track_list; p.list_len = pl->track_count;
+    HIP_TRY((launch_any<T>(RT, sym, true, grid, lds, s, p)));
+    return PILOT_OT_OK;
+}
+
+}  // namespace
+
+PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg,
+                                         int num_iter_max, double stop_thr, double tau, int check_period,
+                                         int precision, double f32_floor_ulps, int cost_is_symmetric,
+                                         int row_begin, int row_end, int row_step, double *d_emd, int *d_iters,
+                                         double *d_err, int *d_flags, void *stream) {
+    if (!pl || !d_P || !d_M || !d_emd) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    int rc = check_grid_args(pl->N, pl->K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin,
+                             row_end, row_step);
+    if (rc != PILOT_OT_OK) return rc;
+    if (precision == PILOT_OT_PREC_AUTO) precision = pilot_ot_auto_precision(1.0 / reg);  // M is /max (Trajectory.py:101)
+    if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
+    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (precision == PILOT_OT_PREC_F32)
+        return run_grid<float>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
+                               cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
+    return run_grid<double>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
+                            cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
+}
+
+PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg, int num_iter_max,
+                                     double stop_thr, double tau, int check_period, int precision,
+                                     double f32_floor_ulps, int cost_is_symmetric, int row_begin, int row_end,
+                                     int row_step, double *emd, int *iters, double *err, int *flags) {
+    if (!P || !M || !emd) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    int rc = check_grid_args(N, K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin, row_end,
+                             row_step);
+    if (rc != PILOT_OT_OK) return rc;
+    if (precision == PILOT_OT_PREC_AUTO) {
+        double mx = 0.0;
+        for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
+        precision = pilot_ot_auto_precision(mx / reg);
+    }
+    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
+    const size_t n_out = (size_t)n_rows * N;
+    if (n_out == 0) return PILOT_OT_OK;
+
+    pilot_ot_plan *pl = nullptr;
+    rc = pilot_ot_plan_create(N, K, &pl);
+    if (rc != PILOT_OT_OK) return rc;
+    double *dP = nullptr, *dM = nullptr, *dE = nullptr, *dErr = nullptr;
+    int *dIt = nullptr, *dFl = nullptr;
+    hipError_t e = hipMalloc(&dP, sizeof(double) * (size_t)N * K);
+    if (e == hipSuccess) e = hipMalloc(&dM, sizeof(double) * (size_t)K * K);
+    if (e == hipSuccess) e = hipMalloc(&dE, sizeof(double) * n_out);
+    if (e == hipSuccess) e = hipMalloc(&dErr, sizeof(double) * n_out);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dIt), sizeof(int) * n_out);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dFl), sizeof(int) * n_out);
+    if (e == hipSuccess) e = hipMemcpy(dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    if (rc == PILOT_OT_OK)
+        rc = pilot_ot_sinkhorn_grid_dev(pl, dP, dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
+                                        f32_floor_ulps, cost_is_symmetric, row_begin, row_end, row_step, dE, dIt, dErr,
+                                        dFl, nullptr);
+    if (rc == PILOT_OT_OK) {
+        e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess) e = hipMemcpy(emd, dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && iters) e = hipMemcpy(iters, dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && err) e = hipMemcpy(err, dErr, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && flags) e = hipMemcpy(flags, dFl, sizeof(int) * n_out, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
+    }
+    if (dP) (void)hipFree(dP);
+    if (dM) (void)hipFree(dM);
+    if (dE) (void)hipFree(dE);
+    if (dErr) (void)hipFree(dErr);
+    if (dIt) (void)hipFree(dIt);
+    if (dFl) (void)hipFree(dFl);
+    pilot_ot_plan_destroy(pl);
+    return rc;
+}

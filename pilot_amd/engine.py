@@ -1,0 +1,158 @@
+"""NumPy-level face of the device engine (host buffers in, host buffers out).
+
+These are the array-level operators ``tl.wasserstein_d`` / ``tl.cost_matrix`` are built on; they go
+straight to ``libpilot_ot.so`` through ctypes.  No torch, no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+# POT defaults of ot.sinkhorn2 / sinkhorn_stabilized (what Trajectory.py:515 runs with)
+NUM_ITER_MAX = 1000
+STOP_THR = 1e-9
+TAU = 1e3
+CHECK_PERIOD = 20
+
+
+def _as_f64(x, name):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if not np.all(np.isfinite(a)):
+        raise ValueError("%s contains NaN or inf" % name)
+    return a
+
+
+def n_rows_of(N, row_begin, row_end, row_step):
+    return len(range(row_begin, N if row_end is None else row_end, row_step))
+
+
+def sinkhorn_grid(P, M, reg, num_iter_max=NUM_ITER_MAX, stop_thr=STOP_THR, tau=TAU,
+                  check_period=CHECK_PERIOD, precision="auto", f32_floor_ulps=0.0,
+                  row_begin=0, row_end=None, row_step=1, return_info=False):
+    """Entropic OT cost <Gamma, M> for ordered pairs (selected rows x all N columns).
+
+    Device replacement of the loop at pilotpy/tools/Trajectory.py:512-515; each pair follows
+    ``ot.sinkhorn2(P[i], P[j], M, reg, method="sinkhorn_stabilized")``.
+
+    P : (N, K) proportion vectors; M : (K, K) cost (already divided by its max).
+    Returns float64 (n_rows, N) and, with ``return_info``, a dict of iters / err / flags arrays.
+    """
+    P = _as_f64(P, "P")
+    M = _as_f64(M, "M")
+    if P.ndim != 2 or M.ndim != 2 or M.shape[0] != M.shape[1] or M.shape[0] != P.shape[1]:
+        raise ValueError("shape mismatch: P %s, M %s" % (P.shape, M.shape))
+    N, K = P.shape
+    if precision not in _lib.PREC:
+        raise ValueError("precision must be one of %s" % sorted(_lib.PREC))
+    row_end = N if row_end is None else int(row_end)
+    n_rows = n_rows_of(N, row_begin, row_end, row_step)
+    emd = np.zeros((n_rows, N), dtype=np.float64)
+    iters = np.zeros((n_rows, N), dtype=np.int32)
+    err = np.zeros((n_rows, N), dtype=np.float64)
+    flags = np.zeros((n_rows, N), dtype=np.int32)
+    L = _lib.load()
+    sym = int(np.array_equal(M, M.T))
+    _lib.check(L.pilot_ot_sinkhorn_grid(
+        _lib.dptr(P), N, K, _lib.dptr(M), float(reg), int(num_iter_max), float(stop_thr), float(tau),
+        int(check_period), _lib.PREC[precision], float(f32_floor_ulps), sym,
+        int(row_begin), row_end, int(row_step),
+        _lib.dptr(emd), _lib.iptr(iters), _lib.dptr(err), _lib.iptr(flags)))
+    if return_info:
+        return emd, dict(iters=iters, err=err, flags=flags)
+    return emd
+
+
+def pdist_square(centroids, metric="cosine"):
+    """Square pairwise-distance matrix of the K centroids (device replacement of
+    ``squareform(pdist(centroids, metric))``, pilotpy/tools/Trajectory.py:468-469)."""
+    X = _as_f64(centroids, "centroids")
+    if X.ndim != 2:
+        raise ValueError("centroids must be 2-D (K, D)")
+    if metric not in _lib.METRICS:
+        raise NotImplementedError("metric %r: the device kernel implements %s" % (metric, sorted(_lib.METRICS)))
+    K, D = X.shape
+    out = np.zeros((K, K), dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_cost_matrix(_lib.dptr(X), K, D, _lib.METRICS[metric], _lib.dptr(out)))
+    return out
+
+
+class DevicePlan:
+    """Device-resident pair-grid problem: P, M and the outputs live in HBM across calls.
+
+    Used by ``bench.py`` (inputs resident before the timed region) and by the multi-GPU driver.
+    Device memory comes from the library's own allocator (no torch needed); pointers can equally
+    be torch ``data_ptr()`` values when the caller wants torch to own the buffers.
+    """
+
+    def __init__(self, P, M, n_rows_max=None):
+        P = _as_f64(P, "P")
+        M = _as_f64(M, "M")
+        self.N, self.K = P.shape
+        self.sym = int(np.array_equal(M, M.T))
+        self.L = _lib.load()
+        self._bufs = []
+        self.plan = ctypes.c_void_p()
+        _lib.check(self.L.pilot_ot_plan_create(self.N, self.K, ctypes.byref(self.plan)))
+        self.n_rows_max = self.N if n_rows_max is None else n_rows_max
+        n_out = self.n_rows_max * self.N
+        self.dP = self._alloc(P.nbytes)
+        self.dM = self._alloc(M.nbytes)
+        self.dE = self._alloc(8 * n_out)
+        self.dErr = self._alloc(8 * n_out)
+        self.dIt = self._alloc(4 * n_out)
+        self.dFl = self._alloc(4 * n_out)
+        _lib.check(self.L.pilot_ot_memcpy_h2d(self.dP, P.ctypes.data, P.nbytes))
+        _lib.check(self.L.pilot_ot_memcpy_h2d(self.dM, M.ctypes.data, M.nbytes))
+
+    def _alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(self.L.pilot_ot_dev_alloc(ctypes.byref(p), int(nbytes)))
+        self._bufs.append(p)
+        return p
+
+    def run(self, reg, row_begin=0, row_end=None, row_step=1, precision="auto", num_iter_max=NUM_ITER_MAX,
+            stop_thr=STOP_THR, tau=TAU, check_period=CHECK_PERIOD, f32_floor_ulps=0.0, stream=None,
+            d_emd=None):
+        """Enqueue one pass over the selected rows (asynchronous)."""
+        row_end = self.N if row_end is None else row_end
+        if n_rows_of(self.N, row_begin, row_end, row_step) > self.n_rows_max:
+            raise ValueError("row selection exceeds the plan's n_rows_max")
+        _lib.check(self.L.pilot_ot_sinkhorn_grid_dev(
+            self.plan, self.dP, self.dM, float(reg), int(num_iter_max), float(stop_thr), float(tau),
+            int(check_period), _lib.PREC[precision], float(f32_floor_ulps), self.sym,
+            int(row_begin), int(row_end), int(row_step),
+            self.dE if d_emd is None else ctypes.c_void_p(d_emd), self.dIt, self.dErr, self.dFl,
+            ctypes.c_void_p(stream) if stream else None))
+
+    def sync(self, stream=None):
+        _lib.check(self.L.pilot_ot_stream_sync(ctypes.c_void_p(stream) if stream else None))
+
+    def fetch(self, n_rows=None):
+        n_rows = self.n_rows_max if n_rows is None else n_rows
+        n = n_rows * self.N
+        emd = np.empty((n_rows, self.N), dtype=np.float64)
+        iters = np.empty((n_rows, self.N), dtype=np.int32)
+        err = np.empty((n_rows, self.N), dtype=np.float64)
+        flags = np.empty((n_rows, self.N), dtype=np.int32)
+        _lib.check(self.L.pilot_ot_memcpy_d2h(emd.ctypes.data, self.dE, 8 * n))
+        _lib.check(self.L.pilot_ot_memcpy_d2h(iters.ctypes.data, self.dIt, 4 * n))
+        _lib.check(self.L.pilot_ot_memcpy_d2h(err.ctypes.data, self.dErr, 8 * n))
+        _lib.check(self.L.pilot_ot_memcpy_d2h(flags.ctypes.data, self.dFl, 4 * n))
+        return emd, dict(iters=iters, err=err, flags=flags)
+
+    def close(self):
+        for p in self._bufs:
+            self.L.pilot_ot_dev_free(p)
+        self._bufs = []
+        if self.plan:
+            self.L.pilot_ot_plan_destroy(self.plan)
+            self.plan = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
