@@ -107,6 +107,24 @@ int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *plan, const double *d_P, const dou
                                int row_begin, int row_end, int row_step,
                                double *d_emd, int *d_iters, double *d_err, int *d_flags,
                                void *stream);
+/* ---- exact OT pair grid: replaces the loop at Trajectory.py:507-511 (the reference default) ---- */
+/* Each pair returns the exact transportation-LP optimum, the value ot.emd2(a, b, M) returns
+ * (after POT's own pre-step b *= sum(a)/sum(b)).  fp64 throughout.
+ * mode: PILOT_OT_EMD_ALL    every selected (row, column) pair is solved;
+ *       PILOT_OT_EMD_UPPER  only pairs with column >= row are solved, the rest of emd is left
+ *                           untouched (valid when M is symmetric: the caller mirrors);
+ *       PILOT_OT_EMD_MIRROR like UPPER, then the lower triangle is filled from the upper one on the
+ *                           device (requires the full square grid: rows 0..N step 1).
+ * n_aug (nullable): augmenting paths used per pair (negative: iteration guard tripped, emd = NaN). */
+#define PILOT_OT_EMD_ALL 0
+#define PILOT_OT_EMD_UPPER 1
+#define PILOT_OT_EMD_MIRROR 2
+int pilot_ot_emd_grid(const double *P, int N, int K, const double *M, int mode,
+                      int row_begin, int row_end, int row_step, double *emd, int *n_aug);
+int pilot_ot_emd_grid_dev(pilot_ot_plan *plan, const double *d_P, const double *d_M, int mode,
+                          int row_begin, int row_end, int row_step, double *d_emd, int *d_n_aug,
+                          void *stream);
+
 /* precision actually selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (1 or 2) */
 int pilot_ot_auto_precision(double max_cost_over_reg);
 

@@ -17,6 +17,7 @@ OK, EINVAL, EHIP, ENOTSUP = 0, -1, -2, -3
 PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2}
 METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5}
 
+EMD_ALL, EMD_UPPER, EMD_MIRROR = 0, 1, 2
 FLAG_CONVERGED, FLAG_NAN, FLAG_ABSORB_LAST, FLAG_ABSORBED, FLAG_F64 = 1, 2, 4, 8, 16
 
 # every symbol include/pilot_ot.h declares (tests check the library exports all of them)
@@ -25,7 +26,7 @@ SYMBOLS = [
     "pilot_ot_device_name", "pilot_ot_dev_alloc", "pilot_ot_dev_free", "pilot_ot_memcpy_h2d",
     "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
     "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
-    "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision",
+    "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
 ]
 
 _lib = None
@@ -66,6 +67,8 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_sinkhorn_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl,
                                              c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.pilot_ot_auto_precision.argtypes = [c_dbl]
+    L.pilot_ot_emd_grid.argtypes = [dp, c_int, c_int, dp, c_int, c_int, c_int, c_int, dp, ip]
+    L.pilot_ot_emd_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name != "pilot_ot_last_error":

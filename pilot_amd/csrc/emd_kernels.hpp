@@ -1,0 +1,282 @@
+// Exact optimal-transport pair grid for gfx950: one wavefront per ordered pair.
+// Replaces the ot.emd2 loop of pilotpy/tools/Trajectory.py:507-511 (the reference's DEFAULT mode).
+//
+// POT solves each K x K transportation LP with a LEMON-derived network simplex on the CPU.  The LP
+// optimum VALUE is unique, so any exact algorithm returns the same number up to rounding; on the
+// GPU the problem is solved by successive shortest augmenting paths with node potentials
+// (complementary slackness is kept after every augmentation, so the final flow is optimal):
+//   * lane l owns row l and column l (and l+64 when K > 64): supplies/demands, potentials, Dijkstra
+//     labels and predecessor links live in registers;
+//   * one Dijkstra step = wave-wide arg-min over the unscanned labels (xor-shuffle reduction) and ONE
+//     parallel relaxation: a scanned row relaxes all K columns at once (row of M from LDS, coalesced),
+//     a scanned column relaxes all rows that currently ship to it (column of the flow matrix);
+//   * the flow matrix is stored column-major so that column scans are conflict-free; it lives in LDS
+//     for K <= 64 and in an L2-resident global slab per wave above that;
+//   * path tracing / bottleneck / flow update walk the predecessor links with wave-uniform indices
+//     (v_readlane), touching one flow entry per hop.
+// All arithmetic is fp64 like POT's.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pilot {
+
+constexpr int EMD_MAX_WAVES_PER_WG = 16;
+
+struct EmdParams {
+    const double *P;    // N x K
+    const double *M;    // K x K
+    int N, K;
+    int n_rows, row_begin, row_step;
+    int upper_only;     // 1: only pairs with j >= i are solved (symmetric cost); others left untouched
+    double *emd;        // n_rows x N
+    int *n_aug;         // nullable: augmentations per pair (diagnostic; negative = guard tripped)
+    double *f_slab;     // global flow slabs (one K*K block per resident wave) when !F_IN_LDS
+};
+
+__device__ inline double rl_f64(double x, int lane) {
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return r.d;
+}
+__device__ inline int rl_i32(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+// make a value that IS wave-uniform also LOOK uniform to the compiler (scalar branches, no exec-mask loops)
+__device__ inline double uni_f64(double x) {
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    r.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return r.d;
+}
+__device__ inline int uni_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// wave-wide minimum of a double (all lanes get the result)
+__device__ inline double wave_min_f64(double x) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double y = __shfl_xor(x, off);
+        x = y < x ? y : x;
+    }
+    return x;
+}
+__device__ inline double wave_sum_f64(double x) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+// NK = rows/columns per lane (1: K <= 64, 2: K <= 128).  F_IN_LDS: flow matrix in LDS, else global slab.
+template <int NK, bool F_IN_LDS>
+__global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(EmdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = p.K, N = p.N;
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    double *Msh = reinterpret_cast<double *>(smem_raw);  // K*K (only when F_IN_LDS; else M is read from global/L2)
+    const double *Mrd;
+    double *FT;                                          // column-major flows: FT[j*K + i] = F[i][j]
+    if constexpr (F_IN_LDS) {
+        for (int t = threadIdx.x; t < K * K; t += blockDim.x) Msh[t] = p.M[t];
+        __syncthreads();
+        Mrd = Msh;
+        FT = Msh + (size_t)K * K + (size_t)wave * K * K;
+    } else {
+        Mrd = p.M;
+        FT = p.f_slab + ((size_t)blockIdx.x * (blockDim.x / 64) + wave) * K * K;
+    }
+    const double INF = __builtin_inf();
+    const long total = (long)p.n_rows * N;
+
+    // pairs are dealt round-robin to the resident waves (wave-uniform loop bounds)
+    const long n_waves = (long)gridDim.x * (blockDim.x / 64);
+    const long first = uni_i32(blockIdx.x * (blockDim.x / 64) + wave);
+    for (long q = first; q < total; q += n_waves) {
+        const int r = (int)(q / N), j_s = (int)(q % N);
+        const int i_s = p.row_begin + r * p.row_step;
+        if (p.upper_only && j_s < i_s) continue;   // wave-uniform
+
+        double pu[NK], pv[NK], ra[NK], rb[NK], dR[NK], dC[NK];
+        int parR[NK], parC[NK];
+        bool doneR[NK], doneC[NK];
+        // POT pre-step: b *= sum(a) / sum(b)   (ot/lp/__init__.py::emd2)
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int e = 0; e < NK; ++e) {
+            const int idx = lane + 64 * e;
+            ra[e] = idx < K ? p.P[(size_t)i_s * K + idx] : 0.0;
+            rb[e] = idx < K ? p.P[(size_t)j_s * K + idx] : 0.0;
+            sa += ra[e]; sb += rb[e];
+        }
+        sa = uni_f64(wave_sum_f64(sa)); sb = uni_f64(wave_sum_f64(sb));
+        const double scale = sa / sb;
+        const double tol = 1e-15 * (sa > 0.0 ? sa : 1.0);
+#pragma unroll
+        for (int e = 0; e < NK; ++e) {
+            const int idx = lane + 64 * e;
+            rb[e] *= scale;
+            pv[e] = 0.0;
+            double m = INF;   // pu_i = min_j M_ij keeps every reduced cost >= 0 at the start
+            if (idx < K)
+                for (int j = 0; j < K; ++j) { const double v = Mrd[(size_t)idx * K + j]; m = v < m ? v : m; }
+            pu[e] = idx < K ? m : 0.0;
+        }
+        for (int t = lane; t < K * K; t += 64) FT[t] = 0.0;
+        int n_aug = 0;
+        const int aug_guard = 64 * K + 64;   // far above the O(K) augmentations SSP needs; bounds every loop
+        bool tripped = false;
+        int trip_code = 0;
+        const unsigned long long t_start = wall_clock64();
+        const unsigned long long watchdog_ticks = 400000000ull;  // 4 s of the 100 MHz constant clock per pair
+
+        for (int s = 0; s < K && !tripped; ++s) {
+            const int se = s / 64, sl = s % 64;
+            for (;;) {
+                double ra_s = 0.0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == se) ra_s = rl_f64(ra[e], sl);
+                if (!(ra_s > tol)) break;
+                if (n_aug > aug_guard) { tripped = true; trip_code = 5; break; }
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    dR[e] = INF; dC[e] = INF; parR[e] = -1; parC[e] = -1;
+                    doneR[e] = false; doneC[e] = false;
+                    if (lane + 64 * e == s) dR[e] = 0.0;
+                }
+                int target = -1;
+                double dstar = 0.0;
+                for (int step = 0;; ++step) {
+                    if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: one node is scanned per step
+                    if ((step & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
+                    // arg-min over the unscanned labels of all rows and columns
+                    double best = INF;
+                    int code = -1;  // node id: rows 0..K-1, columns 128..128+K-1
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) {
+                        const int idx = lane + 64 * e;
+                        if (idx < K) {
+                            if (!doneR[e] && dR[e] < best) { best = dR[e]; code = idx; }
+                            if (!doneC[e] && dC[e] < best) { best = dC[e]; code = 128 + idx; }
+                        }
+                    }
+                    const double bd = uni_f64(wave_min_f64(best));
+                    if (!(bd < INF)) break;                        // nothing reachable: only rounding dust left
+                    const unsigned long long holders = __ballot(best == bd && code >= 0);
+                    const int win = uni_i32(__builtin_ctzll(holders));
+                    const int node = rl_i32(code, win);
+                    if (node >= 128) {                              // a column
+                        const int jn = node - 128, je = jn / 64, jl = jn % 64;
+                        double rb_j = 0.0;
+#pragma unroll
+                        for (int e = 0; e < NK; ++e) {
+                            if (e == je) { rb_j = rl_f64(rb[e], jl); if (lane == jl) doneC[e] = true; }
+                        }
+                        if (rb_j > 0.0) { target = jn; dstar = bd; break; }
+                        // backward arcs jn -> i for rows currently shipping to jn (reduced cost 0)
+#pragma unroll
+                        for (int e = 0; e < NK; ++e) {
+                            const int idx = lane + 64 * e;
+                            if (idx < K && !doneR[e]) {
+                                const double f = FT[(size_t)jn * K + idx];
+                                if (f > 0.0 && bd < dR[e]) { dR[e] = bd; parR[e] = jn; }
+                            }
+                        }
+                    } else {                                        // a row: forward arcs to every column
+                        const int in = node, ie = in / 64, il = in % 64;
+                        double pu_i = 0.0;
+#pragma unroll
+                        for (int e = 0; e < NK; ++e) {
+                            if (e == ie) { pu_i = rl_f64(pu[e], il); if (lane == il) doneR[e] = true; }
+                        }
+#pragma unroll
+                        for (int e = 0; e < NK; ++e) {
+                            const int idx = lane + 64 * e;
+                            if (idx < K && !doneC[e]) {
+                                double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e];
+                                rc = rc < 0.0 ? 0.0 : rc;
+                                const double nd = bd + rc;
+                                if (nd < dC[e]) { dC[e] = nd; parC[e] = in; }
+                            }
+                        }
+                    }
+                }
+                if (tripped) break;
+                if (target < 0) {   // numerically exhausted: drop the dust (<= tol-scale mass)
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) if (lane + 64 * e == s) ra[e] = 0.0;
+                    break;
+                }
+                // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the path
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    pu[e] -= dR[e] < dstar ? dR[e] : dstar;
+                    pv[e] += dC[e] < dstar ? dC[e] : dstar;
+                }
+                // bottleneck along target <- ... <- s
+                double delta = ra_s;
+                {
+                    double rb_t = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
+                    delta = uni_f64(rb_t < delta ? rb_t : delta);
+                }
+                for (int j = target, hop = 0;; ++hop) {
+                    if (hop > K + 1 || j < 0) { tripped = true; trip_code = 2; break; }
+                    int i = 0;
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
+                    if (i == s) break;
+                    if (i < 0) { tripped = true; trip_code = 3; break; }
+                    int jb = 0;
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
+                    if (jb < 0) { tripped = true; trip_code = 4; break; }
+                    const double f = uni_f64(FT[(size_t)jb * K + i]);
+                    delta = f < delta ? f : delta;
+                    j = jb;
+                }
+                if (tripped) break;
+                for (int j = target;;) {
+                    int i = 0;
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
+                    if (lane == 0) FT[(size_t)j * K + i] += delta;
+                    if (i == s) break;
+                    int jb = 0;
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
+                    if (lane == 0) FT[(size_t)jb * K + i] -= delta;
+                    j = jb;
+                }
+                if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    if (lane + 64 * e == s) ra[e] -= delta;
+                    if (lane + 64 * e == target) rb[e] -= delta;
+                }
+                ++n_aug;
+            }
+        }
+        double cost = 0.0;
+        for (int t = lane; t < K * K; t += 64) {
+            const int j = t / K, i = t % K;
+            cost += FT[t] * Mrd[(size_t)i * K + j];
+        }
+        cost = uni_f64(wave_sum_f64(cost));
+        if (lane == 0) {
+            p.emd[q] = tripped ? __builtin_nan("") : cost;
+            if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;
+        }
+    }
+}
+
+// mirror the strictly-lower triangle from the upper one (full square grids only)
+__global__ void emd_mirror_kernel(double *E, int N) {
+    const long total = (long)N * N;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / N), j = (int)(t % N);
+        if (j < i) E[t] = E[(size_t)j * N + i];
+    }
+}
+
+}  // namespace pilot

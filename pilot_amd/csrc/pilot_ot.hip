@@ -12,6 +12,7 @@
 
 #include "../../include/pilot_ot.h"
 #include "sinkhorn_kernels.hpp"
+#include "emd_kernels.hpp"
 
 #define PILOT_API extern "C" __attribute__((visibility("default")))
 
@@ -141,6 +142,7 @@ hipError_t launch_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipSt
 }
 
 constexpr int MAX_K = 128;
+constexpr int EMD_SLAB_WGS_PER_CU = 2, EMD_SLAB_WAVES = 4;  // resident waves of the K > 64 exact kernel
 constexpr size_t LDS_BYTES = 160 * 1024;
 
 }  // namespace
@@ -151,6 +153,9 @@ struct pilot_ot_plan {
     float *p_f32;      // N x K proportions converted to f32
     int *track_list;   // N x N
     int *track_count;  // 1
+    int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
+    double *f_slab;    // exact-EMD flow slabs for K > 64 (one K*K block per resident wave)
+    int n_cu;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -252,12 +257,22 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_f32 = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
+    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
     hipError_t e = hipGetDevice(&pl->device);
+    if (e == hipSuccess) {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, pl->device) == hipSuccess && n_cu > 0)
+            pl->n_cu = n_cu;
+    }
     const int kp = ((K + 31) / 32) * 32;
     if (e == hipSuccess) e = hipMalloc(&pl->img, 3 * sizeof(double) * kp * kp);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->p_f32), sizeof(float) * (size_t)N * K);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
+    if (e == hipSuccess && K > 64)
+        e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
+                      sizeof(double) * (size_t)K * K * EMD_SLAB_WGS_PER_CU * pl->n_cu * EMD_SLAB_WAVES);
     if (e != hipSuccess) {
         pilot_ot_plan_destroy(pl);
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
@@ -272,6 +287,8 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->p_f32) (void)hipFree(pl->p_f32);
     if (pl->track_list) (void)hipFree(pl->track_list);
     if (pl->track_count) (void)hipFree(pl->track_count);
+    if (pl->emd_counter) (void)hipFree(pl->emd_counter);
+    if (pl->f_slab) (void)hipFree(pl->f_slab);
     delete pl;
     return PILOT_OT_OK;
 }
@@ -410,6 +427,92 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     if (dErr) (void)hipFree(dErr);
     if (dIt) (void)hipFree(dIt);
     if (dFl) (void)hipFree(dFl);
+    pilot_ot_plan_destroy(pl);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const double *d_M, int mode, int row_begin,
+                                    int row_end, int row_step, double *d_emd, int *d_n_aug, void *stream) {
+    if (!pl || !d_P || !d_M || !d_emd) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    const int N = pl->N, K = pl->K;
+    if (mode < PILOT_OT_EMD_ALL || mode > PILOT_OT_EMD_MIRROR) return fail(PILOT_OT_EINVAL, "unknown mode %d", mode);
+    if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
+        return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
+    if (mode == PILOT_OT_EMD_MIRROR && !(row_begin == 0 && row_end == N && row_step == 1))
+        return fail(PILOT_OT_EINVAL, "PILOT_OT_EMD_MIRROR needs the full square grid");
+    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
+    if (n_rows == 0) return PILOT_OT_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    pilot::EmdParams p;
+    p.P = d_P; p.M = d_M; p.N = N; p.K = K;
+    p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
+    p.upper_only = mode != PILOT_OT_EMD_ALL;
+    p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab;
+    const long total = (long)n_rows * N;
+    const size_t mat = sizeof(double) * (size_t)K * K;
+    if (K <= 64) {
+        // M + one flow matrix per wave in LDS; as many waves per workgroup as fit (<= 16)
+        int waves = (int)((LDS_BYTES - mat) / mat);
+        if (waves > pilot::EMD_MAX_WAVES_PER_WG) waves = pilot::EMD_MAX_WAVES_PER_WG;
+        if (waves > 8 && mat * (waves + 1) > LDS_BYTES / 2) waves = 8;  // prefer two smaller workgroups per CU
+        if (waves < 1) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
+        const size_t lds = mat * (size_t)(waves + 1);
+        long wgs = (total + waves - 1) / waves;
+        const long cap = (long)pl->n_cu * (lds * 2 <= LDS_BYTES ? 2 : 1) * 2;
+        if (wgs > cap) wgs = cap;
+        auto kern = pilot::emd_grid_kernel<1, true>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
+    } else {
+        const long cap = (long)EMD_SLAB_WGS_PER_CU * pl->n_cu;
+        long wgs = (total + EMD_SLAB_WAVES - 1) / EMD_SLAB_WAVES;
+        if (wgs > cap) wgs = cap;
+        hipLaunchKernelGGL((pilot::emd_grid_kernel<2, false>), dim3((unsigned)wgs), dim3(64 * EMD_SLAB_WAVES), 0, s, p);
+    }
+    HIP_TRY(hipGetLastError());
+    if (mode == PILOT_OT_EMD_MIRROR) {
+        hipLaunchKernelGGL(pilot::emd_mirror_kernel, dim3(1024), dim3(256), 0, s, d_emd, N);
+        HIP_TRY(hipGetLastError());
+    }
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_emd_grid(const double *P, int N, int K, const double *M, int mode, int row_begin, int row_end,
+                                int row_step, double *emd, int *n_aug) {
+    if (!P || !M || !emd) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (N <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "N=%d K=%d must be positive", N, K);
+    if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
+        return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
+    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
+    const size_t n_out = (size_t)n_rows * N;
+    if (n_out == 0) return PILOT_OT_OK;
+    pilot_ot_plan *pl = nullptr;
+    int rc = pilot_ot_plan_create(N, K, &pl);
+    if (rc != PILOT_OT_OK) return rc;
+    double *dP = nullptr, *dM = nullptr, *dE = nullptr;
+    int *dA = nullptr;
+    hipError_t e = hipMalloc(&dP, sizeof(double) * (size_t)N * K);
+    if (e == hipSuccess) e = hipMalloc(&dM, sizeof(double) * (size_t)K * K);
+    if (e == hipSuccess) e = hipMalloc(&dE, sizeof(double) * n_out);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dA), sizeof(int) * n_out);
+    if (e == hipSuccess) e = hipMemcpy(dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dE, 0, sizeof(double) * n_out);
+    if (e == hipSuccess) e = hipMemset(dA, 0, sizeof(int) * n_out);
+    if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    if (rc == PILOT_OT_OK) rc = pilot_ot_emd_grid_dev(pl, dP, dM, mode, row_begin, row_end, row_step, dE, dA, nullptr);
+    if (rc == PILOT_OT_OK) {
+        e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess) e = hipMemcpy(emd, dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_aug) e = hipMemcpy(n_aug, dA, sizeof(int) * n_out, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
+    }
+    if (dP) (void)hipFree(dP);
+    if (dM) (void)hipFree(dM);
+    if (dE) (void)hipFree(dE);
+    if (dA) (void)hipFree(dA);
     pilot_ot_plan_destroy(pl);
     return rc;
 }

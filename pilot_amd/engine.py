@@ -156,3 +156,35 @@ class DevicePlan:
             self.close()
         except Exception:
             pass
+
+
+def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, mode="auto", return_info=False):
+    """Exact OT cost for ordered pairs (device replacement of the ``ot.emd2`` loop,
+    pilotpy/tools/Trajectory.py:507-511).
+
+    mode: "all" solves every (row, column) pair; "upper" only column >= row (rest left 0);
+    "mirror" = upper + device-side mirroring (full square grid only); "auto" picks "mirror"
+    when M is exactly symmetric and the full grid is requested, else "all".
+    """
+    P = _as_f64(P, "P")
+    M = _as_f64(M, "M")
+    if P.ndim != 2 or M.ndim != 2 or M.shape[0] != M.shape[1] or M.shape[0] != P.shape[1]:
+        raise ValueError("shape mismatch: P %s, M %s" % (P.shape, M.shape))
+    N, K = P.shape
+    row_end = N if row_end is None else int(row_end)
+    full = (row_begin == 0 and row_end == N and row_step == 1)
+    if mode == "auto":
+        mode = "mirror" if (full and np.array_equal(M, M.T)) else "all"
+    modes = {"all": _lib.EMD_ALL, "upper": _lib.EMD_UPPER, "mirror": _lib.EMD_MIRROR}
+    if mode not in modes:
+        raise ValueError("mode must be one of %s" % sorted(modes))
+    n_rows = n_rows_of(N, row_begin, row_end, row_step)
+    emd = np.zeros((n_rows, N), dtype=np.float64)
+    n_aug = np.zeros((n_rows, N), dtype=np.int32)
+    _lib.check(_lib.load().pilot_ot_emd_grid(_lib.dptr(P), N, K, _lib.dptr(M), modes[mode], int(row_begin), row_end,
+                                             int(row_step), _lib.dptr(emd), _lib.iptr(n_aug)))
+    if (n_aug < 0).any():
+        raise _lib.PilotOTError("exact-EMD kernel: augmentation guard tripped on %d pairs" % int((n_aug < 0).sum()))
+    if return_info:
+        return emd, dict(n_aug=n_aug)
+    return emd

@@ -1,0 +1,240 @@
+"""``pilot_amd.tl`` -- host-side mirror of the ``pilotpy.tl`` functions on the Wasserstein path.
+
+Same names, arguments, defaults, ``adata.uns`` keys and Python types as the reference
+(``pilotpy/tools/Trajectory.py``), so code written against ``pilotpy.tl.wasserstein_distance``
+runs unchanged; the pair loop and the centroid distance matrix execute on the MI355X through
+``libpilot_ot.so`` (``pilot_amd.engine``).  Nothing here falls back to a CPU solver.
+
+=============================================  ==========================================
+this module                                    reference (``/root/reference/pilotpy/tools/``)
+=============================================  ==========================================
+wasserstein_distance                           Trajectory.py:36-115
+extract_data_anno_scRNA_from_h5ad              Trajectory.py:234-266
+extract_data_anno_pathomics_from_h5ad          Trajectory.py:270-299
+set_path_for_results                           Trajectory.py:146-164
+Cluster_Representations                        Trajectory.py:377-436
+cost_matrix                                    Trajectory.py:441-475
+wasserstein_d                                  Trajectory.py:479-523
+return_real_labels                             Trajectory.py:617-642
+Precomputed_distance                           Trajectory.py:1687-1727
+=============================================  ==========================================
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pandas as pd
+
+from . import engine
+
+path_to_results = None  # module global, as in the reference (Trajectory.py:254)
+
+# engine options that have no counterpart in the reference signature; set via `engine_options`
+_DEFAULT_ENGINE_OPTIONS = dict(precision="auto")
+
+
+def set_path_for_results():
+    """Create ``Results_PILOT/plots`` under the cwd and return it (Trajectory.py:146-164).
+
+    The reference does this as a side effect of every ``wasserstein_distance`` call; set
+    ``PILOT_AMD_NO_RESULTS_DIR=1`` to skip the mkdir (the path is still returned).
+    """
+    if os.environ.get("PILOT_AMD_NO_RESULTS_DIR", "") not in ("", "0"):
+        return "Results_PILOT/plots"
+    if not os.path.exists("Results_PILOT/plots"):
+        os.makedirs("Results_PILOT/plots")
+    return "Results_PILOT/plots"
+
+
+def extract_data_anno_scRNA_from_h5ad(adata, emb_matrix="PCA", clusters_col="cell_type",
+                                      sample_col="sampleID", status="status"):
+    """(data, annot) for scRNA input: ``adata.obsm[emb_matrix]`` as a frame with columns
+    ``PCA_1..D``; ``adata.obs`` columns renamed ``cell_type, sampleID, status`` (Trajectory.py:234-266)."""
+    global path_to_results
+    data = adata.obsm[emb_matrix]
+    col_add = ["PCA_" + str(i) for i in range(1, data.shape[1] + 1)]
+    data = pd.DataFrame(data, columns=col_add)
+    data = data.reset_index(drop=True)
+    annot = adata.obs[[clusters_col, sample_col, status]].copy()
+    annot.columns = ["cell_type", "sampleID", "status"]
+    annot = annot.reset_index(drop=True)
+    path_to_results = set_path_for_results()
+    return data, annot
+
+
+def extract_data_anno_pathomics_from_h5ad(adata, var_names=[], clusters_col="Cell_type",
+                                          sample_col="sampleID", status="status"):
+    """(data, annot) for pathomics input: ``adata[:, var_names].X`` (Trajectory.py:270-299)."""
+    global path_to_results
+    data = adata[:, var_names].X
+    data = pd.DataFrame(data, columns=var_names)
+    data = data.reset_index(drop=True)
+    annot = adata.obs[[clusters_col, sample_col, status]].copy()
+    annot.columns = ["cell_type", "sampleID", "status"]
+    annot = annot.reset_index(drop=True)
+    path_to_results = set_path_for_results()
+    return data, annot
+
+
+def _first_appearance_codes(series):
+    """(codes, uniques) with uniques in first-appearance order, as ``Series.unique()`` gives."""
+    codes, uniques = pd.factorize(series, sort=False, use_na_sentinel=True)
+    return codes, np.asarray(uniques)
+
+
+def Cluster_Representations(df, cell_col=0, sample_col=1, regulizer=0.2, normalization=True):
+    """Proportions of clusters per sample (Trajectory.py:377-436).
+
+    Returns an insertion-ordered dict ``{sampleID: float64[K]}``: samples and cell types in
+    first-appearance order (``.unique()``, :402/:412); prior_k = regulizer * n_k / (C - 1)
+    (:405-409, note C - 1); with ``normalization`` p = (counts + prior) / (sum counts + sum prior)
+    (:428-430).  One vectorised histogram instead of the reference's per-sample pandas masks.
+    """
+    cell_col = df.columns[cell_col]
+    sample_col = df.columns[sample_col]
+    ccodes, cells = _first_appearance_codes(df[cell_col])
+    scodes, samples = _first_appearance_codes(df[sample_col])
+    K, N = len(cells), len(samples)
+    # the reference counts n_k in the column literally named 'cell_type' (:403-407)
+    n_by_name = df["cell_type"].value_counts(sort=False)
+    prior = np.ones(len(df["cell_type"].unique()))
+    for k, cell in enumerate(cells):
+        prior[k] = int(n_by_name.get(cell, 0)) / (len(df) - 1)
+    prior = prior * regulizer
+    ok = (ccodes >= 0) & (scodes >= 0)
+    counts = np.bincount(scodes[ok].astype(np.int64) * K + ccodes[ok], minlength=N * K)
+    counts = counts.reshape(N, K).astype(np.float64)
+    out = {}
+    if normalization:
+        sum_prior = sum(prior)            # Python sum, left to right, like the reference
+        for n in range(N):
+            out[samples[n]] = (counts[n] + prior) / (sum(counts[n]) + sum_prior)
+    else:
+        for n in range(N):
+            out[samples[n]] = counts[n].copy()
+    return out
+
+
+def _centroid_medians(data, codes, K):
+    """Column-wise median of the rows of each cell type, in the frame's own dtype (:465-466)."""
+    X = data.to_numpy() if isinstance(data, pd.DataFrame) else np.asarray(data)
+    order = np.argsort(codes, kind="stable")
+    sorted_codes = codes[order]
+    starts = np.searchsorted(sorted_codes, np.arange(K), side="left")
+    ends = np.searchsorted(sorted_codes, np.arange(K), side="right")
+    cent = np.empty((K, X.shape[1]), dtype=np.float64)
+    for k in range(K):
+        rows = X[order[starts[k]:ends[k]]]
+        cent[k] = np.median(rows, axis=0) if rows.shape[0] else np.nan
+    return cent
+
+
+def cost_matrix(annot, data, metric="cosine"):
+    """Ground-cost matrix between cell types (Trajectory.py:441-475): per-type column-wise MEDIAN
+    centroids, pairwise ``metric`` distance (device kernel; scipy ``pdist`` names), returned as
+    ``(ndarray K x K, DataFrame indexed 'cell_types')``.  NOT normalised (the caller divides by max)."""
+    codes, cells = _first_appearance_codes(annot[annot.columns[0]])
+    centroids = _centroid_medians(data, codes, len(cells))
+    dis = engine.pdist_square(centroids, metric=metric)
+    cost = pd.DataFrame.from_dict(dis).T
+    names = annot.cell_type.unique()
+    cost.columns = names
+    cost["cell_types"] = names
+    cost = cost.set_index("cell_types")
+    return dis, cost
+
+
+def wasserstein_d(Clu_rep, cost, regularized="unreg", reg=0.1, engine_options=None):
+    """Wasserstein distances among all ordered sample pairs (Trajectory.py:479-523).
+
+    ``regularized == "unreg"`` -> exact OT (``ot.emd2``); anything else -> entropic OT with POT's
+    ``sinkhorn_stabilized`` semantics (``ot.sinkhorn2``).  Returns ``(EMD float64 N x N, DataFrame)``;
+    the frame is ``DataFrame.from_dict(EMD).T`` indexed by sample id, exactly as the reference builds it.
+    """
+    opts = dict(_DEFAULT_ENGINE_OPTIONS)
+    opts.update(engine_options or {})
+    samples_id = list(Clu_rep.keys())
+    n_samples = len(samples_id)
+    if n_samples == 0:
+        EMD = np.zeros((0, 0))
+    else:
+        P = np.stack([np.asarray(Clu_rep[s], dtype=np.float64) for s in samples_id])
+        cost = np.asarray(cost, dtype=np.float64)
+        if regularized == "unreg":
+            EMD = engine.emd_grid(P, cost)
+        else:
+            EMD = engine.sinkhorn_grid(P, cost, reg, **opts)
+    emd = pd.DataFrame.from_dict(EMD).T
+    emd.columns = samples_id
+    emd["sampleID"] = samples_id
+    emd = emd.set_index("sampleID")
+    return EMD, emd
+
+
+def return_real_labels(df, category="status", sample_col=1):
+    """First status value of every sample, samples in first-appearance order (Trajectory.py:617-642)."""
+    scodes, samples = _first_appearance_codes(df[df.columns[sample_col]])
+    cond = df[category].to_numpy()
+    first_row = np.full(len(samples), -1, dtype=np.int64)
+    idx = np.flatnonzero(scodes >= 0)
+    # first occurrence of each sample code
+    uniq, first = np.unique(scodes[idx], return_index=True)
+    first_row[uniq] = idx[first]
+    return [cond[r] for r in first_row]
+
+
+def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", sample_col="sampleID",
+                         status="status", metric="cosine", regulizer=0.2, normalization=True,
+                         regularized="unreg", reg=0.1, res=0.01, steper=0.01, data_type="scRNA",
+                         return_sil_ari=False, engine_options=None):
+    """Wasserstein distance among samples (Trajectory.py:36-115); results go to ``adata.uns``:
+    ``data, annot, proportions, cost, EMD_df, EMD, real_labels``.
+
+    ``engine_options`` (not in the reference): dict forwarded to the device engine, e.g.
+    ``{"precision": "fp64"}``.
+    """
+    if data_type == "scRNA":
+        data, annot = extract_data_anno_scRNA_from_h5ad(adata, emb_matrix=emb_matrix, clusters_col=clusters_col,
+                                                        sample_col=sample_col, status=status)
+    else:
+        data, annot = extract_data_anno_pathomics_from_h5ad(adata, var_names=list(adata.var_names),
+                                                            clusters_col=clusters_col, sample_col=sample_col,
+                                                            status=status)
+    adata.uns["data"] = data
+    adata.uns["annot"] = annot
+    proportions = Cluster_Representations(annot, regulizer=regulizer, normalization=normalization)
+    adata.uns["proportions"] = proportions
+
+    cost, cost_df = cost_matrix(annot, data, metric=metric)
+    adata.uns["cost"] = cost_df
+
+    EMD, emd_df = wasserstein_d(proportions, cost / cost.max(), regularized=regularized, reg=reg,
+                                engine_options=engine_options)
+    adata.uns["EMD_df"] = emd_df
+    adata.uns["EMD"] = EMD
+    if return_sil_ari:
+        # Leiden clustering + silhouette of the finished matrix (Trajectory.py:108-113) are downstream
+        # consumers that need scanpy/leidenalg; outside the accelerated path.
+        raise NotImplementedError("return_sil_ari=True needs scanpy/leidenalg (downstream of the EMD matrix); "
+                                  "run pilotpy's Clustering/Sil_computing on adata.uns['EMD']")
+    adata.uns["real_labels"] = return_real_labels(annot)
+
+
+def Precomputed_distance(adata, distances, cost_df, features_matrix, emb_matrix="X_PCA",
+                         clusters_col="cell_types", sample_col="sampleID", status="status", data_type="scRNA"):
+    """Store externally computed distances in ``adata.uns`` (Trajectory.py:1687-1727; the reference
+    reads an undefined ``data_type`` at :1716 -- here it is an explicit argument)."""
+    if data_type == "scRNA":
+        data, annot = extract_data_anno_scRNA_from_h5ad(adata, emb_matrix=emb_matrix, clusters_col=clusters_col,
+                                                        sample_col=sample_col, status=status)
+    else:
+        data, annot = extract_data_anno_pathomics_from_h5ad(adata, var_names=list(adata.var_names),
+                                                            clusters_col=clusters_col, sample_col=sample_col,
+                                                            status=status)
+    adata.uns["data"] = data
+    adata.uns["annot"] = annot
+    adata.uns["proportions"] = features_matrix
+    adata.uns["cost"] = cost_df
+    adata.uns["EMD"] = distances
+    adata.uns["real_labels"] = return_real_labels(annot)

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference); the GPU box uses the committed .npz files.
+
+What is reference-executed: ``pilotpy/tools/Trajectory.py`` is imported from /root/reference with a
+``sys.meta_path`` stub finder standing in for the ~15 third-party packages that are not installed
+(scanpy, seaborn, ... -- none of them is touched by the functions called here), and the real
+``extract_data_anno_*``, ``Cluster_Representations``, ``cost_matrix``, ``return_real_labels`` and the
+``wasserstein_d`` double loop run on pandas/numpy/scipy.
+
+What is NOT reference-executed: the per-pair OT arithmetic.  POT is not installable here, so the
+``ot`` module the reference imports is a shim whose ``emd2`` / ``sinkhorn2`` call the CPU oracle
+(oracle/pilot_oracle.c).  The fixtures therefore pin the reference's data handling, ordering, loop
+and output layout -- and record the oracle's numbers, so a later oracle change is caught -- but do
+not pin POT itself ("parity unpinned").
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import tempfile
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+from pilot_amd.synthetic import make_cells  # noqa: E402
+
+REFERENCE = "/root/reference"
+MISSING = ["scanpy", "anndata", "seaborn", "pydiffmap", "sknetwork", "elpigraph", "adjustText", "gprofiler",
+           "plotnine", "joypy", "shap", "rpy2", "gseapy", "leidenalg", "igraph", "statsmodels", "h5py",
+           "matplotlib_venn", "networkx", "upsetplot", "pingouin"]
+
+
+class _Stub(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Stub(self.__name__ + "." + name)
+
+    def __call__(self, *a, **k):
+        return _Stub(self.__name__ + "()")
+
+    def __iter__(self):
+        return iter(())
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        top = fullname.split(".")[0]
+        if top in MISSING:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _Stub(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    for name in list(MISSING):
+        try:
+            __import__(name)
+            MISSING.remove(name)
+        except Exception:
+            pass
+    sys.meta_path.insert(0, _StubFinder())
+    ot = types.ModuleType("ot")          # POT shim -> CPU oracle (see module docstring)
+    ot.emd2 = lambda a, b, M, *args, **kw: O.emd2(a, b, M)
+
+    def sinkhorn2(a, b, M, reg, method="sinkhorn", **kw):
+        assert method == "sinkhorn_stabilized", method
+        return O.sinkhorn2(a, b, M, reg)
+    ot.sinkhorn2 = sinkhorn2
+    sys.modules["ot"] = ot
+    sys.path.insert(0, REFERENCE)
+    import pilotpy.tools.Trajectory as T
+    return T
+
+
+def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.1, clusters_col="cell_types"):
+    obs = adata.obs
+    results = {}
+    for mode in ("unreg", "reg"):
+        adata.uns = {}
+        T.wasserstein_distance(adata, emb_matrix=emb_key, clusters_col=clusters_col, sample_col="sampleID",
+                               status="status", regularized=mode, reg=reg, data_type=data_type)
+        results[mode] = dict(adata.uns)
+    u = results["unreg"]
+    samples = list(u["proportions"].keys())
+    cells = list(u["cost"].columns)
+    np.savez_compressed(
+        os.path.join(out_dir, name + ".npz"),
+        emb=np.asarray(adata.obsm[emb_key]),
+        obs_cell=np.asarray(obs[clusters_col].astype(str)), obs_sample=np.asarray(obs["sampleID"].astype(str)),
+        obs_status=np.asarray(obs["status"].astype(str)),
+        samples=np.asarray(samples, dtype=str), cells=np.asarray(cells, dtype=str),
+        proportions=np.stack([u["proportions"][s] for s in samples]),
+        cost=u["cost"].to_numpy(), cost_index_name=np.asarray(u["cost"].index.name),
+        real_labels=np.asarray(u["real_labels"], dtype=str),
+        emd_unreg=u["EMD"], emd_unreg_df=u["EMD_df"].to_numpy(),
+        emd_reg=results["reg"]["EMD"], emd_reg_df=results["reg"]["EMD_df"].to_numpy(),
+        emd_df_index_name=np.asarray(u["EMD_df"].index.name),
+        reg=np.asarray(reg), data_type=np.asarray(data_type),
+        uns_keys=np.asarray(sorted(u.keys()), dtype=str),
+    )
+    print(name, "N=%d K=%d C=%d" % (len(samples), len(cells), len(obs)), "EMD unreg max", u["EMD"].max(),
+          "reg max", results["reg"]["EMD"].max())
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    T = import_reference()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as scratch:   # the reference mkdirs Results_PILOT/plots in cwd
+        os.chdir(scratch)
+        try:
+            # c1: BASELINE config 1 (20 x 10 x 10)
+            run_case(T, "c1_20x10x10", make_cells(20, 10, 10, seed=0, cells_per_patient=200), out_dir)
+            # c2-shaped (100 x 30 x 30) with 100 cells per patient to keep the fixture small
+            run_case(T, "c2s_100x30x30", make_cells(100, 30, 30, seed=1, cells_per_patient=100), out_dir)
+            # ragged: shuffled cell order, categorical dtype columns, types missing from some samples
+            ad = make_cells(12, 7, 5, seed=7, cells_per_patient=40)
+            perm = np.random.default_rng(7).permutation(len(ad.obs))
+            ad.obs = ad.obs.iloc[perm].reset_index(drop=True)
+            ad.obsm["X_pca"] = ad.obsm["X_pca"][perm]
+            ad.X = ad.obsm["X_pca"]
+            for c in ("cell_types", "sampleID", "status"):
+                ad.obs[c] = ad.obs[c].astype("category")
+            run_case(T, "ragged_categorical_12x7x5", ad, out_dir)
+            # pathomics branch (adata.X over var_names), float64 features, euclidean-scale data
+            ad = make_cells(15, 6, 8, seed=11, cells_per_patient=60)
+            ad.X = ad.X.astype(np.float64) * 3.0 + 1.0
+            ad.obsm["X_pca"] = ad.X
+            ad.obs = ad.obs.rename(columns={"cell_types": "Cell_type"})
+            run_case(T, "pathomics_15x6x8", ad, out_dir, data_type="Pathomics", clusters_col="Cell_type")
+        finally:
+            os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main()
