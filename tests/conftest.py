@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("PILOT_AMD_NO_RESULTS_DIR", "1")
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = ["c1_20x10x10", "c2s_100x30x30", "ragged_categorical_12x7x5", "pathomics_15x6x8"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the native pieces once (hipcc cross-compiles on the CPU box; no-op when up to date)."""
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def golden_adata(g, categorical=False):
+    """Rebuild the duck-typed AnnData the fixture was generated from."""
+    import pandas as pd
+    from pilot_amd.synthetic import Cohort
+    pathomics = str(g["data_type"]) != "scRNA"
+    cell_col = "Cell_type" if pathomics else "cell_types"
+    obs = pd.DataFrame({cell_col: g["obs_cell"].astype(object), "sampleID": g["obs_sample"].astype(object),
+                        "status": g["obs_status"].astype(object)})
+    if categorical:
+        for c in obs.columns:
+            obs[c] = obs[c].astype("category")
+    ad = Cohort(g["emb"], obs, emb_key="X_pca")
+    return ad, cell_col

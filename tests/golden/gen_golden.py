@@ -104,15 +104,15 @@ def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.
     np.savez_compressed(
         os.path.join(out_dir, name + ".npz"),
         emb=np.asarray(adata.obsm[emb_key]),
-        obs_cell=np.asarray(obs[clusters_col].astype(str)), obs_sample=np.asarray(obs["sampleID"].astype(str)),
-        obs_status=np.asarray(obs["status"].astype(str)),
+        obs_cell=np.asarray(obs[clusters_col].astype(str), dtype=str), obs_sample=np.asarray(obs["sampleID"].astype(str), dtype=str),
+        obs_status=np.asarray(obs["status"].astype(str), dtype=str),
         samples=np.asarray(samples, dtype=str), cells=np.asarray(cells, dtype=str),
         proportions=np.stack([u["proportions"][s] for s in samples]),
-        cost=u["cost"].to_numpy(), cost_index_name=np.asarray(u["cost"].index.name),
+        cost=u["cost"].to_numpy(), cost_index_name=np.asarray(str(u["cost"].index.name)),
         real_labels=np.asarray(u["real_labels"], dtype=str),
         emd_unreg=u["EMD"], emd_unreg_df=u["EMD_df"].to_numpy(),
         emd_reg=results["reg"]["EMD"], emd_reg_df=results["reg"]["EMD_df"].to_numpy(),
-        emd_df_index_name=np.asarray(u["EMD_df"].index.name),
+        emd_df_index_name=np.asarray(str(u["EMD_df"].index.name)),
         reg=np.asarray(reg), data_type=np.asarray(data_type),
         uns_keys=np.asarray(sorted(u.keys()), dtype=str),
     )

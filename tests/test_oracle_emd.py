@@ -1,0 +1,71 @@
+"""The exact-OT oracle against scipy's HiGHS LP solver (the LP optimum value is unique).  CPU only."""
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+from conftest import GOLDEN_CASES, load_golden
+from oracle import oracle as O
+from pilot_amd.synthetic import CONFIGS, make_problem
+
+
+def lp_emd(a, b, M):
+    na, nb = len(a), len(b)
+    A = np.zeros((na + nb, na * nb))
+    for i in range(na):
+        A[i, i * nb:(i + 1) * nb] = 1
+    for j in range(nb):
+        A[na + j, j::nb] = 1
+    b2 = b * (a.sum() / b.sum())
+    res = linprog(M.ravel(), A_eq=A, b_eq=np.concatenate([a, b2]), bounds=(0, None), method="highs")
+    assert res.status == 0
+    return res.fun
+
+
+def test_against_highs_on_pilot_shaped_pairs():
+    P, M = make_problem(**CONFIGS["c2"])
+    rng = np.random.default_rng(1)
+    for _ in range(15):
+        i, j = rng.integers(0, P.shape[0], 2)
+        assert abs(O.emd2(P[i], P[j], M) - lp_emd(P[i], P[j], M)) < 1e-10
+
+
+def test_against_highs_on_ragged_and_degenerate_problems():
+    rng = np.random.default_rng(2)
+    for na, nb in [(1, 1), (1, 5), (4, 1), (3, 7), (8, 8), (12, 5)]:
+        a = rng.dirichlet(np.ones(na)); b = rng.dirichlet(np.ones(nb))
+        M = rng.random((na, nb))
+        assert abs(O.emd2(a, b, M) - lp_emd(a, b, M)) < 1e-10
+    # zero-mass bins (POT drops them), unequal total mass (POT rescales b)
+    a = np.array([0.5, 0.0, 0.5, 0.0]); b = np.array([0.0, 0.3, 0.3, 0.0]) 
+    M = rng.random((4, 4))
+    b_eff = np.where(b > 0, b, 0)
+    assert abs(O.emd2(a, b, M) - lp_emd(a, b_eff, M)) < 1e-10
+
+
+def test_identical_histograms_cost_zero_and_plan_is_feasible():
+    P, M = make_problem(**CONFIGS["c1"])
+    for i in range(5):
+        assert abs(O.emd2(P[i], P[i], M)) < 1e-15
+    val, G = O.emd2(P[0], P[1], M, return_plan=True)
+    np.testing.assert_allclose(G.sum(1), P[0], atol=1e-14)
+    np.testing.assert_allclose(G.sum(0), P[1], atol=1e-14)
+    assert (G >= 0).all() and abs((G * M).sum() - val) < 1e-15
+    assert (G > 0).sum() <= 2 * len(P[0]) - 1 + 2      # (near-)basic solution
+
+
+def test_grid_is_symmetric_with_zero_diagonal_for_pdist_costs():
+    P, M = make_problem(**CONFIGS["c1"])
+    E = O.emd_grid(P, M)
+    assert np.abs(E - E.T).max() < 1e-14 and np.abs(np.diag(E)).max() < 1e-15
+    # triangle inequality holds for a metric-like ground cost only approximately; sanity: bounded by max M
+    assert E.max() <= M.max() + 1e-12
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_unreg_matrix_is_reproduced(name):
+    g = load_golden(name)
+    P = g["proportions"]
+    M = g["cost"] / g["cost"].max()
+    E = O.emd_grid(P, M, n_threads=4)
+    np.testing.assert_allclose(E, g["emd_unreg"], rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(g["emd_unreg_df"], g["emd_unreg"].T)
