@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- W2 patient-pairs/sec for the full N x N distance matrix (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete pass of the hot path over the workload: every one of the N^2 ordered
+patient pairs solved with POT's sinkhorn_stabilized semantics (setup kernel + pair-grid kernel +
+tau-tracking kernel), and for N_gpus > 1 the RCCL all-gather that assembles the full matrix on
+every rank.  Inputs (N x K proportions, K x K cost) are resident in HBM before the timed region.
+
+Workload: BASELINE configs[2] at reg = 0.1 -- 600 patients x 50 cell types x 30 PCA dims, the
+configuration the metric is quoted on (it fits one GPU).  Total work is fixed as GPUs are added
+(the 600^2 pair grid is row-sharded round-robin), hence "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32 MFMA pair-grid kernel):
+achieved = algorithmic flop of one launch / its mean duration (HIP events on the launch stream).
+`cpu_baseline` is the CPU oracle (C fp64 restatement of POT's loop) timed on this box's host cores on
+a bounded sample of the same workload (rank 0, 1 GPU runs only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA == f32 vector peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+
+
+def algorithmic_flops(iters, K, period=20):
+    """per pair, iters*(4K^2+2K) + ceil(iters/period)*(2K^2+3K) + 3K^2."""
+    it = iters.astype(np.float64)
+    return float(np.sum(it * (4 * K * K + 2 * K) + np.ceil(it / period) * (2 * K * K + 3 * K) + 3 * K * K))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", help="synthetic config (c2 | c3 | c4)")
+    ap.add_argument("--reg", type=float, default=0.1)
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import torch  # device memory for the all-gather buffers, streams, torch.distributed (RCCL): plumbing only
+    import torch.distributed as dist
+
+    from pilot_amd import _lib, engine, sharding
+    from pilot_amd.synthetic import CONFIGS, make_problem
+
+    if not torch.cuda.is_available() or _lib.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X; pilot_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.load().pilot_ot_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    P, M = make_problem(**cfg)
+    N, K = P.shape
+    prec = args.precision
+    if prec == "auto":
+        prec = "fp32" if _lib.load().pilot_ot_auto_precision(float(M.max()) / args.reg) == 1 else "fp64"
+    rb, re_, rs = sharding.shard_rows(N, rank, world)
+    n_local = sharding.n_local_rows(N, rank, world)
+    n_pad = sharding.n_padded_rows(N, world)
+
+    plan = engine.DevicePlan(P, M, n_rows_max=max(n_pad, 1))       # P, M -> HBM (resident from here on)
+    plan.enable_timing(True)
+    local = torch.zeros((n_pad, N), dtype=torch.float64, device="cuda")   # this rank's row block (padded)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=prec, stream=stream,
+                 d_emd=local.data_ptr())
+        return sharding.all_gather_rows(local, N) if world > 1 else local
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        full = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N * N / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (this rank's launches inside the timed region) -------------
+    main_ms, track_ms = plan.kernel_times_ms(max_n=min(args.steps, 64))
+    _, info = plan.fetch(n_rows=n_local)
+    iters = info["iters"]
+    flops_launch = algorithmic_flops(iters, K)
+    kern_ms = float(np.mean(main_ms)) if len(main_ms) else float("nan")
+    achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
+    s_bytes = 4 if prec == "fp32" else 8
+    bytes_launch = float(iters.size) * (2 * K * s_bytes + s_bytes)     # 2*K*s + s per pair
+    roofline = {
+        "bound": "mfma", "kernel": "sinkhorn_grid_kernel<%s>" % ("float" if prec == "fp32" else "double"),
+        "achieved": round(achieved_tf, 3), "peak": PEAK_F32_MFMA_TFLOPS if prec == "fp32" else 78.6,
+        "unit": "TFLOP/s", "frac": round(achieved_tf / (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else 78.6), 4),
+        "traffic": None,
+        "kernel_ms": round(kern_ms, 4), "track_kernel_ms": round(float(np.mean(track_ms)), 4) if len(track_ms) else None,
+        "algorithmic_flop_per_launch": flops_launch, "pairs_per_launch": int(iters.size),
+        "mean_updates_per_pair": round(float(iters.mean()), 2),
+    }
+    roofline_hbm = {
+        "bound": "hbm", "achieved": round(bytes_launch / (kern_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+        "unit": "GB/s", "frac": round(bytes_launch / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+        "algorithmic_bytes_per_pair": 2 * K * s_bytes + s_bytes,
+    }
+
+    # ---- sanity: the assembled matrix is the full N x N grid ---------------------------------------
+    E = full[:N].cpu().numpy() if world > 1 else local[:N].cpu().numpy()
+    assert E.shape == (N, N) and np.isfinite(E).all(), "bench produced a non-finite matrix"
+
+    out = {
+        "metric": "W2 patient-pairs/sec (full NxN EMD matrix)", "value": round(value, 1), "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if prec == "fp32" else "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d patients x %d cell types x %d PCA dims, Sinkhorn reg=%g "
+                               "(POT sinkhorn_stabilized semantics), all N^2 ordered pairs"
+                               % (args.config, N, K, cfg["n_dims"], args.reg),
+                   "n_patients": N, "n_cell_types": K, "n_pca": cfg["n_dims"], "reg": args.reg,
+                   "pairs_per_step": N * N,
+                   "parallelism": "pair-grid rows dealt round-robin over %d GPU(s)%s"
+                                  % (world, " + 1 RCCL all-gather" if world > 1 else "")},
+        "roofline": roofline, "roofline_hbm": roofline_hbm,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(P, M, args.reg, args.cpu_seconds, E)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(P, M, reg, budget_s, E_gpu):
+    """Time the CPU oracle on a bounded sample of the SAME workload (rows 0, s, 2s, ... x all columns);
+    also the checker: the sampled rows must agree with what the GPU produced."""
+    from oracle import oracle as O
+    N = P.shape[0]
+    t = time.perf_counter()
+    O.sinkhorn_grid(P, M, reg, row_begin=0, row_end=1)              # one row: per-pair cost estimate
+    per_pair = (time.perf_counter() - t) / N
+    n_rows = int(max(1, min(N, budget_s / max(per_pair * N, 1e-9))))
+    step = max(1, N // n_rows)
+    t = time.perf_counter()
+    Eo = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=1)
+    dt1 = time.perf_counter() - t
+    err = float(np.abs(E_gpu[::step] - Eo).max())
+    base = {"value": round(Eo.size / dt1, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "rows 0,%d,2*%d,.. (%d rows x %d columns = %d ordered pairs) of the same workload, "
+                      "single thread like the reference's Python loop; max|gpu-oracle| on the sample = %.2e"
+                      % (step, step, Eo.shape[0], N, Eo.size, err)}
+    ncpu = os.cpu_count() or 1
+    t = time.perf_counter()
+    Eo2 = O.sinkhorn_grid(P, M, reg, row_step=max(1, step // 4), n_threads=ncpu)
+    dt2 = time.perf_counter() - t
+    allc = {"value": round(Eo2.size / dt2, 1), "unit": "pairs/s", "cores": ncpu, "kind": "port",
+            "sample": "%d ordered pairs, OpenMP over pairs" % Eo2.size}
+    return base, allc
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,13 @@ int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *plan, const double *d_P, const dou
                                int row_begin, int row_end, int row_step,
                                double *d_emd, int *d_iters, double *d_err, int *d_flags,
                                void *stream);
+/* Per-launch kernel timing (HIP events recorded on the call's own stream, around the main pair-grid
+ * kernel and around the tau-tracking kernel).  A ring of the 64 most recent sinkhorn_grid_dev calls is
+ * kept; read it after synchronising the stream.  main_ms / track_ms receive up to max_n entries, oldest
+ * first; *n_out = entries written. */
+int pilot_ot_plan_enable_timing(pilot_ot_plan *plan, int enable);
+int pilot_ot_plan_kernel_times(pilot_ot_plan *plan, int max_n, float *main_ms, float *track_ms, int *n_out);
+
 /* ---- exact OT pair grid: replaces the loop at Trajectory.py:507-511 (the reference default) ---- */
 /* Each pair returns the exact transportation-LP optimum, the value ot.emd2(a, b, M) returns
  * (after POT's own pre-step b *= sum(a)/sum(b)).  fp64 throughout.

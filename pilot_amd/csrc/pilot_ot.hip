@@ -142,6 +142,7 @@ hipError_t launch_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipSt
 }
 
 constexpr int MAX_K = 128;
+constexpr int TIMING_RING = 64;
 constexpr int EMD_SLAB_WGS_PER_CU = 2, EMD_SLAB_WAVES = 4;  // resident waves of the K > 64 exact kernel
 constexpr size_t LDS_BYTES = 160 * 1024;
 
@@ -156,6 +157,10 @@ struct pilot_ot_plan {
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
     double *f_slab;    // exact-EMD flow slabs for K > 64 (one K*K block per resident wave)
     int n_cu;
+    // event ring for per-launch kernel timing (bench.py roofline)
+    int timing;                       // 0 off
+    long n_timed;                     // calls recorded so far
+    hipEvent_t ev[TIMING_RING][4];    // [slot]{main begin, main end, track begin, track end}
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -258,6 +263,8 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_f32 = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
+    pl->timing = 0; pl->n_timed = 0;
+    for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) pl->ev[i][j] = nullptr;
     hipError_t e = hipGetDevice(&pl->device);
     if (e == hipSuccess) {
         int n_cu = 0;
@@ -289,6 +296,7 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->track_count) (void)hipFree(pl->track_count);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
     if (pl->f_slab) (void)hipFree(pl->f_slab);
+    for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) if (pl->ev[i][j]) (void)hipEventDestroy(pl->ev[i][j]);
     delete pl;
     return PILOT_OT_OK;
 }
@@ -349,10 +357,14 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     p.track_list = pl->track_list; p.track_count = pl->track_count;
     const int tiles = (p.n_pairs + M::TILE - 1) / M::TILE;
     const dim3 grid((tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG);
+    hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     HIP_TRY((launch_any<T>(RT, sym, false, grid, lds, s, p)));
+    if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count;
     HIP_TRY((launch_any<T>(RT, sym, true, grid, lds, s, p)));
+    if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
     return PILOT_OT_OK;
 }
 
@@ -515,4 +527,30 @@ PILOT_API int pilot_ot_emd_grid(const double *P, int N, int K, const double *M, 
     if (dA) (void)hipFree(dA);
     pilot_ot_plan_destroy(pl);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+PILOT_API int pilot_ot_plan_enable_timing(pilot_ot_plan *pl, int enable) {
+    if (!pl) return fail(PILOT_OT_EINVAL, "plan is NULL");
+    if (enable)
+        for (int i = 0; i < TIMING_RING; ++i)
+            for (int j = 0; j < 4; ++j)
+                if (!pl->ev[i][j]) HIP_TRY(hipEventCreate(&pl->ev[i][j]));
+    pl->timing = enable ? 1 : 0;
+    pl->n_timed = 0;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_plan_kernel_times(pilot_ot_plan *pl, int max_n, float *main_ms, float *track_ms, int *n_out) {
+    if (!pl || !main_ms || !track_ms || !n_out) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    long n = pl->n_timed < TIMING_RING ? pl->n_timed : TIMING_RING;
+    if (n > max_n) n = max_n;
+    for (long t = 0; t < n; ++t) {
+        const long call = pl->n_timed - n + t;
+        hipEvent_t *ev = pl->ev[call % TIMING_RING];
+        HIP_TRY(hipEventElapsedTime(&main_ms[t], ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&track_ms[t], ev[2], ev[3]));
+    }
+    *n_out = (int)n;
+    return PILOT_OT_OK;
 }

@@ -127,6 +127,17 @@ class DevicePlan:
             self.dE if d_emd is None else ctypes.c_void_p(d_emd), self.dIt, self.dErr, self.dFl,
             ctypes.c_void_p(stream) if stream else None))
 
+    def enable_timing(self, enable=True):
+        _lib.check(self.L.pilot_ot_plan_enable_timing(self.plan, int(enable)))
+
+    def kernel_times_ms(self, max_n=64):
+        """(main_ms, track_ms) float arrays of the most recent timed calls (sync the stream first)."""
+        a = (ctypes.c_float * max_n)()
+        b = (ctypes.c_float * max_n)()
+        n = ctypes.c_int(0)
+        _lib.check(self.L.pilot_ot_plan_kernel_times(self.plan, max_n, a, b, ctypes.byref(n)))
+        return np.array(a[:n.value]), np.array(b[:n.value])
+
     def sync(self, stream=None):
         _lib.check(self.L.pilot_ot_stream_sync(ctypes.c_void_p(stream) if stream else None))
 

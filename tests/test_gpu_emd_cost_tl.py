@@ -1,0 +1,147 @@
+"""Exact-EMD kernel, cost-matrix kernel and the tl.* surface on the GPU, against oracle + golden fixtures."""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.spatial.distance as ssd
+
+from conftest import GOLDEN_CASES, golden_adata, load_golden
+from oracle import oracle as O
+from pilot_amd import _lib, engine, tl
+from pilot_amd.synthetic import CONFIGS, make_cells, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------- exact EMD
+@pytest.mark.parametrize("cfg,step", [("c1", 1), ("c2", 9), ("c3", 75)])
+def test_emd_parity(cfg, step):
+    P, M = make_problem(**CONFIGS[cfg])
+    Eo = O.emd_grid(P, M, row_step=step, n_threads=16)
+    Eg, info = engine.emd_grid(P, M, row_step=step, mode="all", return_info=True)
+    assert np.abs(Eg - Eo).max() <= 1e-12
+    assert (info["n_aug"] > 0).all()
+
+
+def test_emd_modes_and_symmetry():
+    P, M = make_problem(**CONFIGS["c2"])
+    full = engine.emd_grid(P, M)                                   # auto -> mirror
+    allp = engine.emd_grid(P, M, mode="all")
+    up = engine.emd_grid(P, M, mode="upper")
+    assert np.array_equal(full, full.T) and np.abs(np.diag(full)).max() < 1e-15
+    assert np.abs(full - allp).max() < 1e-13
+    np.testing.assert_array_equal(np.triu(up), np.triu(full))
+    assert np.all(np.tril(up, -1) == 0)
+    rows = engine.emd_grid(P, M, row_begin=2, row_step=8, mode="upper")
+    np.testing.assert_array_equal(rows, up[2::8])
+    with pytest.raises(ValueError):
+        engine.emd_grid(P, M, row_begin=1, mode="mirror")
+
+
+@pytest.mark.parametrize("K", [1, 2, 17, 64, 65, 100, 128])
+def test_emd_every_k_regime(K):
+    """K <= 64: flows in LDS; K > 64: two rows/columns per lane and flows in a global slab."""
+    P, M = make_problem(12, K, 6, seed=200 + K, cells_per_patient=500)
+    if K == 1:
+        M = np.zeros((1, 1))
+    Eo = O.emd_grid(P, M, n_threads=16)
+    Eg = engine.emd_grid(P, M, mode="all")
+    assert np.abs(Eg - Eo).max() <= 1e-12
+
+
+def test_emd_nonsymmetric_cost_and_sparse_histograms():
+    rng = np.random.default_rng(8)
+    K = 24
+    P = rng.dirichlet(0.2 * np.ones(K), size=15)
+    P[P < 1e-3] = 0.0                                             # zero-mass bins (POT drops them)
+    P /= P.sum(1, keepdims=True)
+    M = rng.random((K, K))
+    Eo = O.emd_grid(P, M, n_threads=16)
+    Eg = engine.emd_grid(P, M)                                     # auto -> all (not symmetric)
+    assert np.abs(Eg - Eo).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_emd_golden(name):
+    g = load_golden(name)
+    E = engine.emd_grid(g["proportions"], g["cost"] / g["cost"].max())
+    assert np.abs(E - g["emd_unreg"]).max() <= 1e-12
+
+
+# ------------------------------------------------------------------------------- cost matrix
+@pytest.mark.parametrize("metric", ["cosine", "euclidean", "sqeuclidean", "cityblock", "chebyshev", "correlation"])
+@pytest.mark.parametrize("K,D", [(2, 3), (50, 30), (100, 50), (130, 7)])
+def test_pdist_kernel_vs_scipy(metric, K, D):
+    X = np.random.default_rng(K * D).standard_normal((K, D))
+    ref = ssd.squareform(ssd.pdist(X, metric=metric))
+    got = engine.pdist_square(X, metric=metric)
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-14)
+    assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_cost_matrix_golden(name):
+    g = load_golden(name)
+    ad, cell_col = golden_adata(g)
+    data, annot = (tl.extract_data_anno_scRNA_from_h5ad(ad, "X_pca", cell_col, "sampleID", "status")
+                   if str(g["data_type"]) == "scRNA" else
+                   tl.extract_data_anno_pathomics_from_h5ad(ad, list(ad.var_names), cell_col, "sampleID", "status"))
+    dis, df = tl.cost_matrix(annot, data, metric="cosine")
+    np.testing.assert_allclose(dis, g["cost"], rtol=0, atol=1e-14)
+    assert isinstance(df, pd.DataFrame) and df.index.name == str(g["cost_index_name"]) == "cell_types"
+    assert [str(c) for c in df.columns] == list(g["cells"]) == [str(c) for c in df.index]
+
+
+# ------------------------------------------------------------------------------- tl surface
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("mode", ["unreg", "reg"])
+def test_wasserstein_distance_end_to_end_vs_reference_fixture(name, mode, tmp_path, monkeypatch):
+    """Mirror of the reference's own test (test/test_pilot.py:9-28) plus numbers: same call, same uns keys,
+    same Python types, values within tolerance of what the reference's code produced (golden)."""
+    monkeypatch.chdir(tmp_path)
+    g = load_golden(name)
+    ad, cell_col = golden_adata(g, categorical=(name.startswith("ragged")))
+    kw = dict(clusters_col=cell_col, sample_col="sampleID", status="status", regularized=mode, reg=float(g["reg"]))
+    if str(g["data_type"]) == "scRNA":
+        tl.wasserstein_distance(ad, emb_matrix="X_pca", engine_options={"precision": "fp64"}, **kw)
+    else:
+        tl.wasserstein_distance(ad, data_type="Pathomics", engine_options={"precision": "fp64"}, **kw)
+    u = ad.uns
+    assert sorted(u.keys()) == list(g["uns_keys"])
+    E = u["EMD"]
+    assert isinstance(E, np.ndarray) and E.dtype == np.float64
+    assert E.shape[0] == E.shape[1] == len(u["real_labels"]) == len(g["samples"])       # test_pilot.py:26-28
+    want = g["emd_unreg"] if mode == "unreg" else g["emd_reg"]
+    assert np.abs(E - want).max() <= 1e-12
+    df = u["EMD_df"]
+    assert isinstance(df, pd.DataFrame) and df.index.name == "sampleID"
+    assert [str(s) for s in df.index] == list(g["samples"]) == [str(s) for s in df.columns]
+    np.testing.assert_array_equal(df.to_numpy(), E.T)              # from_dict(EMD).T, Trajectory.py:518
+    assert isinstance(u["proportions"], dict) and [str(k) for k in u["proportions"]] == list(g["samples"])
+    np.testing.assert_array_equal(np.stack(list(u["proportions"].values())), g["proportions"])
+    np.testing.assert_allclose(u["cost"].to_numpy(), g["cost"], atol=1e-14)              # stored UN-normalised
+    assert [str(x) for x in u["real_labels"]] == list(g["real_labels"])
+    assert isinstance(u["annot"], pd.DataFrame) and isinstance(u["data"], pd.DataFrame)
+    assert (E + E).shape == E.shape and (E / E.max()).max() == 1.0                        # test_pilot.py:30, ploting.py:95
+
+
+def test_wasserstein_distance_default_precision_c2_shape(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    ad = make_cells(100, 30, 30, seed=1, cells_per_patient=300)
+    tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized="reg", reg=0.1)
+    P = np.stack(list(ad.uns["proportions"].values()))
+    M = ad.uns["cost"].to_numpy(); M = M / M.max()
+    Eo = O.sinkhorn_grid(P, M, 0.1, row_step=10, n_threads=16)
+    assert np.abs(ad.uns["EMD"][::10] - Eo).max() <= 1e-5
+    ad.uns = {}
+    tl.wasserstein_distance(ad, emb_matrix="X_pca")                 # reference default: exact OT
+    Eo = O.emd_grid(P, M, row_step=10, n_threads=16)
+    assert np.abs(ad.uns["EMD"][::10] - Eo).max() <= 1e-12
+
+
+def test_unsupported_metric_and_sil_ari_raise(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    ad = make_cells(6, 4, 3, seed=2, cells_per_patient=30)
+    with pytest.raises(NotImplementedError):
+        tl.wasserstein_distance(ad, emb_matrix="X_pca", metric="mahalanobis")
+    with pytest.raises(NotImplementedError):
+        tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized="reg", return_sil_ari=True)

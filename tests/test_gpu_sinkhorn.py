@@ -1,0 +1,183 @@
+"""Parity of the HIP Sinkhorn pair grid (through the C ABI) against the CPU oracle.  GPU only.
+
+Tolerances (BASELINE.json north star): |EMD_gpu - EMD_oracle|_inf <= 1e-5 in f32, <= 1e-12 in f64."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+from oracle import oracle as O
+from pilot_amd import _lib, engine
+from pilot_amd.synthetic import CONFIGS, make_problem
+
+pytestmark = pytest.mark.gpu
+TOL32, TOL64 = 1e-5, 1e-12
+
+
+def test_device_is_gfx950():
+    assert _lib.device_count() >= 1
+    assert "gfx950" in _lib.device_name()
+
+
+@pytest.mark.parametrize("cfg,step", [("c1", 1), ("c2", 5), ("c3", 40)])
+@pytest.mark.parametrize("reg", [1.0, 0.1])
+def test_parity_f32_and_f64(cfg, step, reg):
+    P, M = make_problem(**CONFIGS[cfg])
+    Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=16, return_info=True)
+    E32, i32 = engine.sinkhorn_grid(P, M, reg, precision="fp32", row_step=step, return_info=True)
+    E64, i64 = engine.sinkhorn_grid(P, M, reg, precision="fp64", row_step=step, return_info=True)
+    assert np.abs(E32 - Eo).max() <= TOL32
+    assert np.abs(E64 - Eo).max() <= TOL64
+    # f64 follows POT's control flow update for update
+    np.testing.assert_array_equal(i64["iters"], io["iters"])
+    assert np.all((i64["flags"] & _lib.FLAG_CONVERGED) == (io["flags"] & O.FLAG_CONVERGED))
+    assert np.all((i64["flags"] & _lib.FLAG_F64) > 0) and np.all((i32["flags"] & _lib.FLAG_F64) == 0)
+    # f32 stops at an earlier check when the true error is below its stop-threshold floor, never later
+    assert np.all(i32["iters"] <= io["iters"]) and np.all(i32["iters"] % 20 == 1)
+    np.testing.assert_allclose(i64["err"], io["err"], rtol=1e-3, atol=1e-13)
+
+
+def test_small_reg_goes_through_absorption_tracking_f64():
+    """reg = 0.01: every pair tau-absorbs, ~half hit the 1000-update cap; the f64 kernel must follow the
+    oracle's iteration semantics exactly, including POT's absorb-on-the-final-update scaling."""
+    P, M = make_problem(**CONFIGS["c3"])
+    rows = dict(row_begin=275, row_end=276, row_step=1)             # contains two known absorb-on-last pairs
+    Eo, io = O.sinkhorn_grid(P, M, 0.01, n_threads=16, return_info=True, **rows)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="auto", return_info=True, **rows)
+    assert np.all((ig["flags"] & _lib.FLAG_F64) > 0)                 # auto -> f64 at max(M)/reg = 100
+    assert np.abs(Eg - Eo).max() <= 1e-9
+    np.testing.assert_array_equal(ig["iters"], io["iters"])
+    hit_o = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0
+    hit_g = (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
+    assert hit_o.sum() >= 2
+    np.testing.assert_array_equal(hit_g, hit_o)
+    assert ((ig["flags"] & _lib.FLAG_ABSORBED) > 0).mean() > 0.9
+    capped = io["iters"] == 1000
+    assert 0.2 < capped.mean() < 0.9
+
+
+def test_small_reg_f32_stays_within_tolerance_on_this_distribution():
+    P, M = make_problem(**CONFIGS["c3"])
+    rows = dict(row_begin=100, row_end=102, row_step=1)
+    Eo, io = O.sinkhorn_grid(P, M, 0.01, n_threads=16, return_info=True, **rows)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="fp32", return_info=True, **rows)
+    ok = (io["flags"] & O.FLAG_ABSORB_ON_LAST) == 0
+    same = ig["iters"] == io["iters"]
+    # capped pairs ran the same 1000 updates; converged pairs may stop a check early
+    assert np.abs(Eg - Eo)[ok & same].max() <= TOL32
+    assert np.abs(Eg - Eo)[ok].max() <= 1e-4
+    assert not np.isnan(Eg).any()
+
+
+@pytest.mark.parametrize("K", [1, 2, 7, 31, 32, 33, 48, 64, 65, 96, 100, 128])
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("fp64", TOL64)])
+def test_every_tile_shape(K, prec, tol):
+    """K sweeps the row-tile counts (f32: 32 rows per tile, f64: 16) incl. padding edges; N=37 is not a
+    multiple of the 32 / 16 pairs a wave handles."""
+    P, M = make_problem(37, K, 8, seed=100 + K, cells_per_patient=400)
+    if K == 1:
+        M = np.zeros((1, 1))
+    Eo = O.sinkhorn_grid(P, M, 0.2, n_threads=16)
+    Eg = engine.sinkhorn_grid(P, M, 0.2, precision=prec)
+    assert Eg.shape == (37, 37)
+    assert np.abs(Eg - Eo).max() <= tol
+
+
+def test_k_above_128_is_rejected_not_emulated():
+    P, M = make_problem(5, 130, 4, seed=1, cells_per_patient=500)
+    with pytest.raises(NotImplementedError):
+        engine.sinkhorn_grid(P, M, 0.1)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("fp64", TOL64)])
+def test_nonsymmetric_cost(prec, tol):
+    rng = np.random.default_rng(4)
+    P, _ = make_problem(20, 40, 6, seed=9, cells_per_patient=300)
+    M = rng.random((40, 40))
+    M /= M.max()
+    assert not np.array_equal(M, M.T)
+    Eo = O.sinkhorn_grid(P, M, 0.3, n_threads=16)
+    Eg = engine.sinkhorn_grid(P, M, 0.3, precision=prec)
+    assert np.abs(Eg - Eo).max() <= tol
+
+
+def test_row_selection_and_single_row_grids():
+    P, M = make_problem(**CONFIGS["c2"])
+    full = engine.sinkhorn_grid(P, M, 0.1, precision="fp64")
+    part = engine.sinkhorn_grid(P, M, 0.1, precision="fp64", row_begin=3, row_end=77, row_step=8)
+    np.testing.assert_array_equal(part, full[3:77:8])                # same pair -> same bits, whatever the tile
+    one = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", row_begin=99, row_end=100)
+    f32 = engine.sinkhorn_grid(P, M, 0.1, precision="fp32")
+    np.testing.assert_array_equal(one[0], f32[99])
+    empty = engine.sinkhorn_grid(P, M, 0.1, row_begin=5, row_end=5)
+    assert empty.shape == (0, 100)
+
+
+def test_deterministic_across_runs():
+    P, M = make_problem(**CONFIGS["c2"])
+    a = engine.sinkhorn_grid(P, M, 0.1, precision="fp32")
+    b = engine.sinkhorn_grid(P, M, 0.1, precision="fp32")
+    np.testing.assert_array_equal(a, b)
+
+
+def test_tau_tracking_path_is_exercised_at_moderate_reg():
+    """A tiny tau forces absorptions at reg=0.5, so pairs flow fast kernel -> track list -> tracking
+    kernel in f32 too; values must not change (absorption is value-neutral except on the last update)."""
+    P, M = make_problem(40, 20, 6, seed=12, cells_per_patient=300)
+    Eo, io = O.sinkhorn_grid(P, M, 0.5, tau=1.5, n_threads=16, return_info=True)
+    for prec, tol in (("fp32", TOL32), ("fp64", TOL64)):
+        Eg, ig = engine.sinkhorn_grid(P, M, 0.5, tau=1.5, precision=prec, return_info=True)
+        assert ((ig["flags"] & _lib.FLAG_ABSORBED) > 0).mean() > 0.5
+        ok = (io["flags"] & O.FLAG_ABSORB_ON_LAST) == 0
+        assert np.abs(Eg - Eo)[ok].max() <= tol
+
+
+def test_iteration_cap_and_check_period_arguments():
+    P, M = make_problem(**CONFIGS["c1"])
+    for kw in (dict(numItermax=7), dict(numItermax=45, print_period=5), dict(stopThr=1e-4)):
+        Eo, io = O.sinkhorn_grid(P, M, 0.1, return_info=True, **kw)
+        gk = dict(num_iter_max=kw.get("numItermax", 1000), check_period=kw.get("print_period", 20),
+                  stop_thr=kw.get("stopThr", 1e-9))
+        Eg, ig = engine.sinkhorn_grid(P, M, 0.1, precision="fp64", return_info=True, **gk)
+        np.testing.assert_array_equal(ig["iters"], io["iters"])
+        assert np.abs(Eg - Eo).max() <= TOL64
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_fixture_matrix(name):
+    g = load_golden(name)
+    P, M = g["proportions"], g["cost"] / g["cost"].max()
+    E = engine.sinkhorn_grid(P, M, float(g["reg"]), precision="fp64")
+    assert np.abs(E - g["emd_reg"]).max() <= TOL64
+    E = engine.sinkhorn_grid(P, M, float(g["reg"]), precision="fp32")
+    assert np.abs(E - g["emd_reg"]).max() <= TOL32
+
+
+def test_full_size_properties_c3():
+    """BASELINE full size (600 x 50): size-independent properties instead of a full oracle pass."""
+    P, M = make_problem(**CONFIGS["c3"])
+    E, info = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", return_info=True)
+    assert E.shape == (600, 600) and np.isfinite(E).all()
+    assert ((info["flags"] & _lib.FLAG_CONVERGED) > 0).all()
+    assert np.abs(E - E.T).max() < 1e-6                             # converged entropic costs are symmetric
+    assert (np.diag(E) > 1e-3).all() and E.min() > 0 and E.max() < 1.0
+    # entropic cost upper-bounds the exact cost and is within reg*log(K^2)-ish of it
+    Ex = engine.emd_grid(P, M)
+    assert (E >= Ex - 1e-6).all()
+    # row shards reproduce the full matrix bit for bit (what the multi-GPU path relies on)
+    for rank in (0, 5):
+        part = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", row_begin=rank, row_step=8)
+        np.testing.assert_array_equal(part, E[rank::8])
+    # sampled rows against the oracle
+    Eo = O.sinkhorn_grid(P, M, 0.1, row_begin=7, row_step=150, n_threads=16)
+    assert np.abs(E[7::150] - Eo).max() <= TOL32
+
+
+def test_c4_shape_sampled_rows():
+    """2000 x 100 x 50 (K = 100: four f32 row tiles) on a few rows."""
+    P, M = make_problem(**CONFIGS["c4"])
+    rows = dict(row_begin=11, row_end=2000, row_step=997)
+    Eo = O.sinkhorn_grid(P, M, 0.1, n_threads=16, **rows)
+    Eg = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", **rows)
+    assert np.abs(Eg - Eo).max() <= TOL32
+    Eg = engine.sinkhorn_grid(P, M, 0.1, precision="fp64", **rows)
+    assert np.abs(Eg - Eo).max() <= TOL64
