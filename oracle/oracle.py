@@ -44,6 +44,7 @@ PRINT_PERIOD = 20
 FLAG_CONVERGED = 1
 FLAG_NAN_REVERT = 2
 FLAG_ABSORB_ON_LAST = 4
+FLAG_ABSORBED = 8
 
 
 def build(force: bool = False) -> str:

@@ -37,7 +37,8 @@ enum {
     ORACLE_INFO_NABSORB = 1,      /* number of tau-absorptions                   */
     ORACLE_INFO_LAST_ABSORB = 2,  /* ii of the last absorption, -1 if none       */
     ORACLE_INFO_FLAGS = 3,        /* bit0: converged, bit1: NaN-revert,          */
-                                  /* bit2: absorption fell on the final update   */
+                                  /* bit2: absorption fell on the final update,  */
+                                  /* bit3: at least one absorption happened      */
     ORACLE_INFO_N = 4
 };
 
@@ -158,6 +159,7 @@ ORACLE_API double pilot_oracle_sinkhorn2_stabilized(
         }
     }
     if (last_abs >= 0 && last_abs == iters - 1) flags |= 4;
+    if (nabs > 0) flags |= 8;
 
     get_Gamma(M, alpha, beta, u, v, na, nb, reg, G);
     double val = 0.0;

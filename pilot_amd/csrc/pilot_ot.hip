@@ -104,7 +104,7 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 // ------------------------------------------------------------------------------------------------
 template <typename T, int RT, bool SYM, bool TRACK>
 hipError_t launch_one(dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
-    auto kern = pilot::sinkhorn_grid_kernel<T, RT, SYM, TRACK>;
+    auto kern = pilot::sinkhorn_stream_kernel<T, RT, SYM, TRACK>;
     if (lds > 32 * 1024) {  // beyond the default dynamic-LDS window the limit must be raised explicitly
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -141,6 +141,38 @@ hipError_t launch_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipSt
     return hipErrorInvalidValue;
 }
 
+template <typename T, int RT> hipError_t launch_value_rt(dim3 grid, hipStream_t s, const pilot::GridParams &p) {
+    hipLaunchKernelGGL((pilot::sinkhorn_value_kernel<T, RT>), grid, dim3(pilot::WAVE * pilot::WAVES_PER_WG), 0, s, p);
+    return hipGetLastError();
+}
+template <typename T> hipError_t launch_value(int RT, dim3 grid, hipStream_t s, const pilot::GridParams &p) {
+    switch (RT) {
+    case 1: return launch_value_rt<T, 1>(grid, s, p);
+    case 2: return launch_value_rt<T, 2>(grid, s, p);
+    case 3: return launch_value_rt<T, 3>(grid, s, p);
+    case 4: return launch_value_rt<T, 4>(grid, s, p);
+    default: break;
+    }
+    if constexpr (sizeof(T) == 8) {
+        switch (RT) {
+        case 5: return launch_value_rt<T, 5>(grid, s, p);
+        case 6: return launch_value_rt<T, 6>(grid, s, p);
+        case 7: return launch_value_rt<T, 7>(grid, s, p);
+        case 8: return launch_value_rt<T, 8>(grid, s, p);
+        default: break;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+// workgroups of the persistent stream kernel resident per CU (register file and LDS both bound it)
+template <typename T> int stream_wgs_per_cu(int RT, bool track, size_t lds) {
+    const int regs = (track ? 7 : 5) * RT * pilot::Mfma<T>::NREG * int(sizeof(T) / 4) + 72;
+    int occ = regs <= 256 ? 2 : 1;
+    const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+    if (by_lds < occ) occ = by_lds;
+    return occ < 1 ? 1 : occ;
+}
+
 constexpr int MAX_K = 128;
 constexpr int TIMING_RING = 64;
 constexpr int EMD_SLAB_WGS_PER_CU = 2, EMD_SLAB_WAVES = 4;  // resident waves of the K > 64 exact kernel
@@ -154,6 +186,10 @@ struct pilot_ot_plan {
     float *p_f32;      // N x K proportions converted to f32
     int *track_list;   // N x N
     int *track_count;  // 1
+    void *scratch;     // parked (u, v) records of the Sinkhorn stream kernel, grown on demand
+    size_t scratch_bytes;
+    int *flags_ws;     // per-pair flags when the caller passes none
+    size_t flags_ws_n;
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
     double *f_slab;    // exact-EMD flow slabs for K > 64 (one K*K block per resident wave)
     int n_cu;
@@ -263,6 +299,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_f32 = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
+    pl->scratch = nullptr; pl->scratch_bytes = 0; pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) pl->ev[i][j] = nullptr;
     hipError_t e = hipGetDevice(&pl->device);
@@ -272,7 +309,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
             pl->n_cu = n_cu;
     }
     const int kp = ((K + 31) / 32) * 32;
-    if (e == hipSuccess) e = hipMalloc(&pl->img, 3 * sizeof(double) * kp * kp);
+    if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->p_f32), sizeof(float) * (size_t)N * K);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), sizeof(int));
@@ -294,6 +331,8 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->p_f32) (void)hipFree(pl->p_f32);
     if (pl->track_list) (void)hipFree(pl->track_list);
     if (pl->track_count) (void)hipFree(pl->track_count);
+    if (pl->scratch) (void)hipFree(pl->scratch);
+    if (pl->flags_ws) (void)hipFree(pl->flags_ws);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
     if (pl->f_slab) (void)hipFree(pl->f_slab);
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) if (pl->ev[i][j]) (void)hipEventDestroy(pl->ev[i][j]);
@@ -328,9 +367,9 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     const int RT = (K + M::TILE - 1) / M::TILE;
     const int KP = RT * M::TILE;
     size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * sizeof(T);
-    if (lds > LDS_BYTES)
+    if (lds + (size_t)KP * sizeof(T) > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision",
-                    K, lds, LDS_BYTES);
+                    K, lds + (size_t)KP * sizeof(T), LDS_BYTES);
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, sizeof(int), s));
     T *img = static_cast<T *>(pl->img);
     const void *Pt;
@@ -346,25 +385,55 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     HIP_TRY(hipGetLastError());
     if (n_rows == 0) return PILOT_OT_OK;
 
+    const int n_pairs = n_rows * N;
+    // device workspace that scales with the number of pairs: grown on demand (first call at a new size
+    // allocates; later calls at the same or a smaller size do not, so they stay graph-capturable)
+    const size_t scr_bytes = (size_t)n_pairs * pilot::scratch_stride<T>(RT) * sizeof(T);
+    if (scr_bytes > pl->scratch_bytes) {
+        if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
+        pl->scratch = nullptr; pl->scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&pl->scratch, scr_bytes));
+        pl->scratch_bytes = scr_bytes;
+    }
+    if (!d_flags) {
+        if ((size_t)n_pairs > pl->flags_ws_n) {
+            if (pl->flags_ws) HIP_TRY(hipFree(pl->flags_ws));
+            pl->flags_ws = nullptr; pl->flags_ws_n = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->flags_ws), sizeof(int) * (size_t)n_pairs));
+            pl->flags_ws_n = (size_t)n_pairs;
+        }
+        d_flags = pl->flags_ws;
+    }
+
     pilot::GridParams p;
-    p.P = Pt; p.img = img; p.N = N; p.K = K;
-    p.n_pairs = n_rows * N;
+    p.P = Pt; p.img = img; p.scratch = pl->scratch; p.N = N; p.K = K;
+    p.n_pairs = n_pairs;
     p.list = nullptr; p.list_len = nullptr;
     p.row_begin = row_begin; p.row_step = row_step;
     p.max_iter = num_iter_max; p.period = check_period;
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
     p.track_list = pl->track_list; p.track_count = pl->track_count;
-    const int tiles = (p.n_pairs + M::TILE - 1) / M::TILE;
-    const dim3 grid((tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG);
+    lds += (size_t)KP * sizeof(T);   // first-product table next to the operand image(s)
+    const int tiles = (n_pairs + M::TILE - 1) / M::TILE;
+    const int wgs_needed = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+    int wgs = pl->n_cu * stream_wgs_per_cu<T>(RT, false, lds);
+    if (wgs > wgs_needed) wgs = wgs_needed;
     hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    HIP_TRY((launch_any<T>(RT, sym, false, grid, lds, s, p)));
+    HIP_TRY((launch_any<T>(RT, sym, false, dim3(wgs), lds, s, p)));
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count;
-    HIP_TRY((launch_any<T>(RT, sym, true, grid, lds, s, p)));
+    int wgs_t = pl->n_cu * stream_wgs_per_cu<T>(RT, true, lds);
+    if (wgs_t > wgs_needed) wgs_t = wgs_needed;
+    HIP_TRY((launch_any<T>(RT, sym, true, dim3(wgs_t), lds, s, p)));
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
+    // third pass: cost <Gamma, M> of every pair from its parked scalings
+    p.list = nullptr; p.list_len = nullptr;
+    int wgs_v = pl->n_cu * 8;
+    if (wgs_v > wgs_needed) wgs_v = wgs_needed;
+    HIP_TRY((launch_value<T>(RT, dim3(wgs_v), s, p)));
     return PILOT_OT_OK;
 }
 
