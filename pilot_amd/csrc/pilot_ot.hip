@@ -185,7 +185,10 @@ struct pilot_ot_plan {
     void *img;         // 3 operand images, sized for f64 at this K
     float *p_f32;      // N x K proportions converted to f32
     int *track_list;   // N x N
-    int *track_count;  // 1
+    int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch
+    int *order_list;   // N x N: longest-first work order of the fast launch
+    unsigned char *order_bucket;  // N x N
+    int *order_hist;   // 2 * ORDER_NB: histogram + scatter cursors
     void *scratch;     // parked (u, v) records of the Sinkhorn stream kernel, grown on demand
     size_t scratch_bytes;
     int *flags_ws;     // per-pair flags when the caller passes none
@@ -299,6 +302,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_f32 = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
+    pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->scratch = nullptr; pl->scratch_bytes = 0; pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) pl->ev[i][j] = nullptr;
@@ -312,7 +316,10 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->p_f32), sizeof(float) * (size_t)N * K);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_hist), sizeof(int) * 2 * pilot::ORDER_NB);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
     if (e == hipSuccess && K > 64)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
@@ -331,6 +338,9 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->p_f32) (void)hipFree(pl->p_f32);
     if (pl->track_list) (void)hipFree(pl->track_list);
     if (pl->track_count) (void)hipFree(pl->track_count);
+    if (pl->order_list) (void)hipFree(pl->order_list);
+    if (pl->order_bucket) (void)hipFree(pl->order_bucket);
+    if (pl->order_hist) (void)hipFree(pl->order_hist);
     if (pl->scratch) (void)hipFree(pl->scratch);
     if (pl->flags_ws) (void)hipFree(pl->flags_ws);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
@@ -370,7 +380,7 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     if (lds + (size_t)KP * sizeof(T) > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision",
                     K, lds + (size_t)KP * sizeof(T), LDS_BYTES);
-    HIP_TRY(hipMemsetAsync(pl->track_count, 0, sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, 4 * sizeof(int), s));
     T *img = static_cast<T *>(pl->img);
     const void *Pt;
     if constexpr (sizeof(T) == 4) {
@@ -391,7 +401,7 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     const size_t scr_bytes = (size_t)n_pairs * pilot::scratch_stride<T>(RT) * sizeof(T);
     if (scr_bytes > pl->scratch_bytes) {
         if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
-        pl->scratch = nullptr; pl->scratch_bytes = 0;
+    pl->scratch = nullptr; pl->scratch_bytes = 0;
         HIP_TRY(hipMalloc(&pl->scratch, scr_bytes));
         pl->scratch_bytes = scr_bytes;
     }
@@ -413,18 +423,30 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     p.max_iter = num_iter_max; p.period = check_period;
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
-    p.track_list = pl->track_list; p.track_count = pl->track_count;
+    p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
     lds += (size_t)KP * sizeof(T);   // first-product table next to the operand image(s)
     const int tiles = (n_pairs + M::TILE - 1) / M::TILE;
     const int wgs_needed = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
     int wgs = pl->n_cu * stream_wgs_per_cu<T>(RT, false, lds);
     if (wgs > wgs_needed) wgs = wgs_needed;
+    // longest-first work order (see order_bucket_kernel)
+    {
+        HIP_TRY(hipMemsetAsync(pl->order_hist, 0, sizeof(int) * 2 * pilot::ORDER_NB, s));
+        int ob = (n_pairs + 255) / 256;
+        if (ob > pl->n_cu * 8) ob = pl->n_cu * 8;
+        hipLaunchKernelGGL((pilot::order_bucket_kernel<T>), dim3(ob), dim3(256), 0, s, static_cast<const T *>(Pt), N, K,
+                           n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist);
+        hipLaunchKernelGGL(pilot::order_scatter_kernel, dim3(ob), dim3(256), 0, s, pl->order_bucket, n_pairs,
+                           pl->order_hist, pl->order_hist + pilot::ORDER_NB, pl->order_list);
+        HIP_TRY(hipGetLastError());
+        p.list = pl->order_list;
+    }
     hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     HIP_TRY((launch_any<T>(RT, sym, false, dim3(wgs), lds, s, p)));
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
-    p.list = pl->track_list; p.list_len = pl->track_count;
+    p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
     int wgs_t = pl->n_cu * stream_wgs_per_cu<T>(RT, true, lds);
     if (wgs_t > wgs_needed) wgs_t = wgs_needed;
     HIP_TRY((launch_any<T>(RT, sym, true, dim3(wgs_t), lds, s, p)));

@@ -96,14 +96,16 @@ template <typename T> __device__ inline T group_max(T x) {
 template <typename T> __device__ inline T abs_t(T x) { return x < T(0) ? -x : x; }
 
 // OUT[t] = sum over k of X_img[out row][k] * IN[k]   for the whole K x TILE panel
+// `last_init` seeds the accumulator of the last row-tile (1 in padded slots keeps 0 / OUT finite there).
 template <typename T, int RT>
 __device__ inline void panel_product(const T *__restrict__ img, const typename Mfma<T>::acc_t (&IN)[RT],
-                                     typename Mfma<T>::acc_t (&OUT)[RT], int K, int lane) {
+                                     typename Mfma<T>::acc_t (&OUT)[RT], int K, int lane,
+                                     const typename Mfma<T>::acc_t &last_init) {
     using M = Mfma<T>;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < M::NREG; ++r) OUT[t][r] = T(0);
+        for (int r = 0; r < M::NREG; ++r) OUT[t][r] = (t == RT - 1) ? last_init[r] : T(0);
     // k-steps of row-tiles tp < RT-1 are always inside K (RT = ceil(K / TILE)); only the last tile has
     // padding, skipped per chunk of CH registers with a wave-uniform branch.
     constexpr int CH = (M::NREG >= 16) ? 4 : 1;
@@ -162,6 +164,7 @@ struct GridParams {
     int *flags;
     int *track_list;      // fast kernel appends pairs that need POT absorption tracking
     int *track_count;
+    int *queue_head;      // dynamic work queue of this launch (zeroed by the host before the launch)
 };
 
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
@@ -186,9 +189,8 @@ sinkhorn_stream_kernel(GridParams p) {
     T *lds = reinterpret_cast<T *>(smem_raw);
 
     const int n_items = p.list_len ? *p.list_len : p.n_pairs;
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    const int n_waves = gridDim.x * WAVES_PER_WG;
-    if (blockIdx.x * WAVES_PER_WG * TILE >= n_items) return;  // whole workgroup idle
+    const int lane = threadIdx.x % WAVE;
+    if (blockIdx.x * WAVES_PER_WG * TILE >= n_items) return;  // more workgroups than work (tracking launch)
 
     // stage the stationary operand: image 0 (and image 1 unless G is symmetric) + first-product table
     {
@@ -202,8 +204,6 @@ sinkhorn_stream_kernel(GridParams p) {
     const T *img_g = SYM ? lds : lds + KP * KP;                    // out = G in
     const T *acc0 = lds + (SYM ? 1 : 2) * KP * KP;                 // G^T u0, u0 = 1/K (a new pair's first product)
 
-    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_WG + wave);
-    if (gw * TILE >= n_items) return;
     const int col = lane % TILE, grp = lane / TILE;
     const int K = p.K, N = p.N;
     const T *Pt = static_cast<const T *>(p.P);
@@ -215,6 +215,11 @@ sinkhorn_stream_kernel(GridParams p) {
 
     acc_t A[RT], B[RT], U[RT], V[RT], ACC[RT];
     acc_t RU[TRACK ? RT : 1], RV[TRACK ? RT : 1];
+    // 1 in the padded accumulator slots of the last row-tile, 0 elsewhere: seeds every product so that
+    // b/acc and a/acc are 0/1 = 0 there (a, b are 0 in padded slots) without per-element selects
+    acc_t PADC;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) PADC[r] = M::lidx(RT - 1, r, grp) >= K ? T(1) : T(0);
     // per-column state (replicated in the lane groups of the column)
     bool active = false;
     int q = 0, ii = 0, flags = 0, abs_at = -1;
@@ -223,84 +228,102 @@ sinkhorn_stream_kernel(GridParams p) {
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
-            A[t][r] = B[t][r] = U[t][r] = V[t][r] = ACC[t][r] = T(0);
+            A[t][r] = B[t][r] = U[t][r] = V[t][r] = T(0);
+            ACC[t][r] = T(1);
             if constexpr (TRACK) { RU[t][r] = RV[t][r] = T(0); }
         }
 
-    // queue of this wave: sequence number s -> item (s % TILE) + gw*TILE + (s / TILE) * n_waves*TILE
-    int seq_next = 0;
+    // work queue: waves draw batches of TILE items from one device-wide counter, so a wave that got
+    // long-running pairs simply draws fewer batches
+    int res_next = 0, res_end = 0;
+    bool exhausted = false;
     bool want = true;  // column asks for a (new) pair
+    unsigned loop_count = 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
         const unsigned long long wmask = __ballot(want) & colmask;
         if (wmask) {
-            const int rank = __popcll(wmask & ((1ull << col) - 1ull));
-            const int s = seq_next + rank;
-            seq_next = __builtin_amdgcn_readfirstlane(seq_next + (int)__popcll(wmask));
-            if (want) {
-                const long item = (long)(s % TILE) + (long)gw * TILE + (long)(s / TILE) * n_waves * TILE;
-                active = item < n_items;
+            if (res_next >= res_end && !exhausted) {
+                int base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = __builtin_amdgcn_readfirstlane(base);
+                exhausted = base >= n_items;
+                res_next = exhausted ? n_items : base;
+                res_end = (base + TILE < n_items) ? base + TILE : n_items;
+                if (exhausted) res_end = n_items;
+            }
+            const int avail = res_end - res_next;
+            const int n_want = (int)__popcll(wmask);
+            const int rank = (int)__popcll(wmask & ((1ull << col) - 1ull));
+            const int item = res_next + rank;
+            const bool take = want && rank < avail;
+            res_next = __builtin_amdgcn_readfirstlane(res_next + (n_want < avail ? n_want : avail));
+            if (want && !take && exhausted) {   // no work left: the slot goes dark
                 want = false;
-                if (active) {
-                    q = p.list ? p.list[item] : (int)item;
-                    const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
-                    T bnorm2 = T(0);
 #pragma unroll
-                    for (int t = 0; t < RT; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
-                        for (int r = 0; r < NREG; ++r) {
-                            const int l = M::lidx(t, r, grp);
-                            const bool ok = l < K;
-                            A[t][r] = ok ? Pt[(size_t)i * K + l] : T(0);
-                            B[t][r] = ok ? Pt[(size_t)j * K + l] : T(0);
-                            U[t][r] = ok ? uinit : T(0);
-                            V[t][r] = ok ? uinit : T(0);
-                            ACC[t][r] = acc0[(t * NREG + r) * NGRP + grp];
-                            bnorm2 += B[t][r] * B[t][r];
-                            if constexpr (TRACK) { RU[t][r] = ok ? T(1) : T(0); RV[t][r] = ok ? T(1) : T(0); }
-                        }
-                    bnorm2 = bnorm2 + __shfl_xor(bnorm2, 32);
-                    if constexpr (NGRP == 4) bnorm2 = bnorm2 + __shfl_xor(bnorm2, 16);
-                    thr = T(p.stop_thr);
-                    if constexpr (sizeof(T) == 4) {
-                        const T fl = T(p.floor_ulps) * M::eps() * sqrtf(bnorm2);
-                        thr = thr > fl ? thr : fl;
+                    for (int r = 0; r < NREG; ++r) { A[t][r] = B[t][r] = U[t][r] = V[t][r] = T(0); ACC[t][r] = T(1); }
+            }
+            if (take) {
+                want = false;
+                active = true;
+                q = p.list ? p.list[item] : item;
+                const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
+                T bnorm2 = T(0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        const int l = M::lidx(t, r, grp);
+                        const bool ok = l < K;
+                        A[t][r] = ok ? Pt[(size_t)i * K + l] : T(0);
+                        B[t][r] = ok ? Pt[(size_t)j * K + l] : T(0);
+                        U[t][r] = ok ? uinit : T(0);
+                        V[t][r] = ok ? uinit : T(0);
+                        ACC[t][r] = acc0[(t * NREG + r) * NGRP + grp];
+                        bnorm2 += B[t][r] * B[t][r];
+                        if constexpr (TRACK) { RU[t][r] = ok ? T(1) : T(0); RV[t][r] = ok ? T(1) : T(0); }
                     }
-                    ii = 0; flags = 0; abs_at = -1; errv = T(1);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-#pragma unroll
-                        for (int r = 0; r < NREG; ++r) { A[t][r] = B[t][r] = U[t][r] = V[t][r] = T(0); }
+                bnorm2 = bnorm2 + __shfl_xor(bnorm2, 32);
+                if constexpr (NGRP == 4) bnorm2 = bnorm2 + __shfl_xor(bnorm2, 16);
+                thr = T(p.stop_thr);
+                if constexpr (sizeof(T) == 4) {
+                    const T fl = T(p.floor_ulps) * M::eps() * sqrtf(bnorm2);
+                    thr = thr > fl ? thr : fl;
                 }
+                ii = 0; flags = 0; abs_at = -1; errv = T(1);
             }
         }
-        if (__ballot(active) == 0ull) break;
+        if (__ballot(active || want) == 0ull) break;
+
+        // a pair's updates are a serial chain: waves carrying old pairs go first on the shared matrix pipe
+        if ((loop_count++ & 7) == 0) {
+            const bool old2 = __ballot(active && ii > 8 * p.period) != 0ull;
+            const bool old1 = __ballot(active && ii > 4 * p.period) != 0ull;
+            if (old2) __builtin_amdgcn_s_setprio(3);
+            else if (old1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- v = b / (G^T u) --------------------------------------------------------------------------
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int r = 0; r < NREG; ++r) {
-                T vn = B[t][r] * M::rcp(ACC[t][r]);
-                if (t == RT - 1 && M::lidx(t, r, grp) >= K) vn = T(0);   // padded slots stay 0
-                V[t][r] = vn;
-            }
+            for (int r = 0; r < NREG; ++r) V[t][r] = B[t][r] * M::rcp(ACC[t][r]);
         // ---- u = a / (G v) ----------------------------------------------------------------------------
-        panel_product<T, RT>(img_g, V, ACC, K, lane);
+        panel_product<T, RT>(img_g, V, ACC, K, lane, PADC);
         T mx = T(0);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
-                T un = A[t][r] * M::rcp(ACC[t][r]);
-                if (t == RT - 1 && M::lidx(t, r, grp) >= K) un = T(0);
+                const T un = A[t][r] * M::rcp(ACC[t][r]);
                 U[t][r] = un;
-                T mu, mv;
-                if constexpr (TRACK) { mu = abs_t(un * RU[t][r]); mv = abs_t(V[t][r] * RV[t][r]); }
-                else { mu = abs_t(un); mv = abs_t(V[t][r]); }
-                mx = mx > mu ? mx : mu;
-                mx = mx > mv ? mx : mv;
+                // scalings are positive, so max|.| needs no abs; NaN operands drop out of max (as in POT,
+                // where `max(abs(u)) > tau` is False for a NaN) and are caught by the error test instead
+                if constexpr (TRACK) mx = fmax(fmax(mx, un * RU[t][r]), V[t][r] * RV[t][r]);
+                else mx = fmax(fmax(mx, un), V[t][r]);
             }
         mx = group_max<T>(mx);
         const bool over = active && mx > tau;   // POT: max|u| > tau or max|v| > tau  ->  absorb
@@ -312,7 +335,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
-                        const bool pad = (t == RT - 1 && M::lidx(t, r, grp) >= K);
+                        const bool pad = M::lidx(t, r, grp) >= K;
                         RU[t][r] = pad ? T(0) : M::rcp(U[t][r] * T(K));
                         RV[t][r] = pad ? T(0) : T(K) * M::rcp(V[t][r]);
                     }
@@ -324,7 +347,7 @@ sinkhorn_stream_kernel(GridParams p) {
             const unsigned long long omask = __ballot(over) & colmask;
             if (omask) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(p.track_count, (int)__popcll(omask));
+                if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(omask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (over) {
                     if (grp == 0) p.track_list[base + __popcll(omask & ((1ull << col) - 1ull))] = q;
@@ -336,7 +359,7 @@ sinkhorn_stream_kernel(GridParams p) {
         ++ii;   // ii updates of (v, u) are done for this column
 
         // ---- ACC = G^T u: feeds the stopping test of this update and the next v ----------------------
-        panel_product<T, RT>(img_gt, U, ACC, K, lane);
+        panel_product<T, RT>(img_gt, U, ACC, K, lane, PADC);
 
         // ---- POT's stopping rule: the error of update ii-1 is evaluated when (ii-1) % period == 0 ---
         const bool pending = active && ((ii - 1) % p.period == 0);
@@ -349,7 +372,9 @@ sinkhorn_stream_kernel(GridParams p) {
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) {
-                    const T d = V[t][r] * ACC[t][r] * sc - B[t][r];
+                    T d;
+                    if constexpr (TRACK) d = V[t][r] * ACC[t][r] * sc - B[t][r];
+                    else d = V[t][r] * ACC[t][r] - B[t][r];
                     e2 += d * d;
                 }
             e2 = group_sum<T>(e2);
@@ -412,7 +437,10 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(Gri
             load_regs<T>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
         }
         const T scale = rec[2 * KP];
-        panel_product<T, RT>(img_gm, V, ACC, p.K, lane);
+        acc_t zero;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) zero[r] = T(0);
+        panel_product<T, RT>(img_gm, V, ACC, p.K, lane, zero);
         T val = T(0);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -463,10 +491,69 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
         double s = 0.0;
         if (j < K)
             for (int k = 0; k < K; ++k) s += exp(-Msrc[(size_t)k * K + j] / reg);
-        img[3 * nimg + idx] = T(s / K);
+        img[3 * nimg + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
     }
     if (Pdst)
         for (long idx = tid; idx < n_p; idx += nthr) Pdst[idx] = T(Psrc[idx]);
+}
+
+// ---- longest-first work order ------------------------------------------------------------------------
+// Sinkhorn needs more updates the closer the two histograms are (the diagonal pairs a == b are the slowest
+// by far), and a pair's updates are a serial chain, so the long pairs must START first or they become the
+// tail of the launch.  Pairs are bucketed by -log2 of their L1 distance (NB buckets, 4 per octave, exact
+// duplicates in the last one) and the work list is emitted from the highest bucket down.  Three tiny
+// launches: bucket ids + histogram, (prefix is folded into) scatter.
+constexpr int ORDER_NB = 48;
+
+template <typename T>
+__global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int K, int n_items, int row_begin, int row_step,
+                                    unsigned char *__restrict__ bucket, int *__restrict__ hist) {
+    __shared__ int lh[ORDER_NB];
+    for (int i = threadIdx.x; i < ORDER_NB; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_items; q += gridDim.x * blockDim.x) {
+        const int i = row_begin + (q / N) * row_step, j = q % N;
+        float l1 = 0.f;
+        for (int k = 0; k < K; ++k) l1 += fabsf(float(Pt[(size_t)i * K + k]) - float(Pt[(size_t)j * K + k]));
+        int b = ORDER_NB - 1;
+        if (l1 > 0.f) {
+            const float v = 4.f * (1.f - log2f(l1));      // l1 = 2 -> 0, halves add 4
+            b = v < 0.f ? 0 : (v > float(ORDER_NB - 2) ? ORDER_NB - 2 : int(v));
+        }
+        bucket[q] = (unsigned char)b;
+        atomicAdd(&lh[b], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ORDER_NB; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// list position of bucket b = (number of items in higher buckets) + a range reserved per workgroup.
+// Every workgroup owns a contiguous chunk of items: LDS histogram of the chunk, ONE global atomic per
+// (workgroup, bucket) to reserve the range, then LDS cursors -- a handful of hot global addresses would
+// otherwise serialise all N^2 atomics.
+__global__ void order_scatter_kernel(const unsigned char *__restrict__ bucket, int n_items, const int *__restrict__ hist,
+                                     int *__restrict__ cursor, int *__restrict__ list) {
+    __shared__ int offs[ORDER_NB], lh[ORDER_NB], lbase[ORDER_NB];
+    if (threadIdx.x < ORDER_NB) lh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = ORDER_NB - 1; b >= 0; --b) { offs[b] = run; run += hist[b]; }
+    }
+    __syncthreads();
+    const int chunk = (n_items + gridDim.x - 1) / gridDim.x;
+    const int q0 = blockIdx.x * chunk, q1 = (q0 + chunk < n_items) ? q0 + chunk : n_items;
+    for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) atomicAdd(&lh[bucket[q]], 1);
+    __syncthreads();
+    if (threadIdx.x < ORDER_NB) {
+        const int c = lh[threadIdx.x];
+        lbase[threadIdx.x] = offs[threadIdx.x] + (c ? atomicAdd(&cursor[threadIdx.x], c) : 0);
+        lh[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+        const int b = bucket[q];
+        list[lbase[b] + atomicAdd(&lh[b], 1)] = q;
+    }
 }
 
 }  // namespace pilot
