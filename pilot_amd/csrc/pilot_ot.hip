@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -424,13 +425,17 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
     p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
+    {
+        const char *dbg = getenv("PILOT_OT_DEBUG");
+        p.debug = dbg ? atoi(dbg) : 0;
+    }
     lds += (size_t)KP * sizeof(T);   // first-product table next to the operand image(s)
     const int tiles = (n_pairs + M::TILE - 1) / M::TILE;
     const int wgs_needed = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
     int wgs = pl->n_cu * stream_wgs_per_cu<T>(RT, false, lds);
     if (wgs > wgs_needed) wgs = wgs_needed;
     // longest-first work order (see order_bucket_kernel)
-    {
+    if (!(p.debug & 2)) {
         HIP_TRY(hipMemsetAsync(pl->order_hist, 0, sizeof(int) * 2 * pilot::ORDER_NB, s));
         int ob = (n_pairs + 255) / 256;
         if (ob > pl->n_cu * 8) ob = pl->n_cu * 8;

@@ -97,32 +97,52 @@ template <typename T> __device__ inline T abs_t(T x) { return x < T(0) ? -x : x;
 
 // OUT[t] = sum over k of X_img[out row][k] * IN[k]   for the whole K x TILE panel
 // `last_init` seeds the accumulator of the last row-tile (1 in padded slots keeps 0 / OUT finite there).
+//
+// k-steps of row-tiles tp < RT-1 are always inside K (RT = ceil(K / TILE)); only the last tile has padding.
+// The number of k-steps it needs is wave-uniform but only known at run time, so the tail is a jump table
+// over straight-line variants (NLAST = CH, 2*CH, ... registers): no branch sits between an operand's
+// ds_read and its MFMA, and the scheduler sees one block per variant.
+template <typename T, int RT, int NLAST>
+__device__ inline void panel_product_fixed(const T *__restrict__ img, const typename Mfma<T>::acc_t (&IN)[RT],
+                                           typename Mfma<T>::acc_t (&OUT)[RT], int lane,
+                                           const typename Mfma<T>::acc_t &last_init) {
+    using M = Mfma<T>;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) OUT[t][r] = (t == RT - 1) ? last_init[r] : T(0);
+#pragma unroll
+        for (int tp = 0; tp < RT; ++tp)
+#pragma unroll
+            for (int r = 0; r < (tp < RT - 1 ? M::NREG : NLAST); ++r)
+                OUT[t] = M::mfma(img[img_index<T>(RT, tp, r, t, lane)], IN[tp][r], OUT[t]);
+    }
+}
+
 template <typename T, int RT>
 __device__ inline void panel_product(const T *__restrict__ img, const typename Mfma<T>::acc_t (&IN)[RT],
                                      typename Mfma<T>::acc_t (&OUT)[RT], int K, int lane,
                                      const typename Mfma<T>::acc_t &last_init) {
     using M = Mfma<T>;
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < M::NREG; ++r) OUT[t][r] = (t == RT - 1) ? last_init[r] : T(0);
-    // k-steps of row-tiles tp < RT-1 are always inside K (RT = ceil(K / TILE)); only the last tile has
-    // padding, skipped per chunk of CH registers with a wave-uniform branch.
-    constexpr int CH = (M::NREG >= 16) ? 4 : 1;
-#pragma unroll
-    for (int tp = 0; tp < RT; ++tp) {
-#pragma unroll
-        for (int c = 0; c < M::NREG / CH; ++c) {
-            if (tp < RT - 1 || M::lidx(tp, c * CH, 0) < K) {
-#pragma unroll
-                for (int rr = 0; rr < CH; ++rr) {
-                    const int r = c * CH + rr;
-                    const T x = IN[tp][r];
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-                        OUT[t] = M::mfma(img[img_index<T>(RT, tp, r, t, lane)], x, OUT[t]);
-                }
-            }
+    // registers of the last row-tile that hold a cell type (group 0 holds the smallest index of a register)
+    const int n_last = (K - M::lidx(RT - 1, 0, 0) + M::NGRP - 1) / M::NGRP;
+    if constexpr (M::NREG == 16) {
+        switch ((n_last + 1) / 2) {
+        case 1: panel_product_fixed<T, RT, 2>(img, IN, OUT, lane, last_init); break;
+        case 2: panel_product_fixed<T, RT, 4>(img, IN, OUT, lane, last_init); break;
+        case 3: panel_product_fixed<T, RT, 6>(img, IN, OUT, lane, last_init); break;
+        case 4: panel_product_fixed<T, RT, 8>(img, IN, OUT, lane, last_init); break;
+        case 5: panel_product_fixed<T, RT, 10>(img, IN, OUT, lane, last_init); break;
+        case 6: panel_product_fixed<T, RT, 12>(img, IN, OUT, lane, last_init); break;
+        case 7: panel_product_fixed<T, RT, 14>(img, IN, OUT, lane, last_init); break;
+        default: panel_product_fixed<T, RT, 16>(img, IN, OUT, lane, last_init); break;
+        }
+    } else {
+        switch (n_last) {
+        case 1: panel_product_fixed<T, RT, 1>(img, IN, OUT, lane, last_init); break;
+        case 2: panel_product_fixed<T, RT, 2>(img, IN, OUT, lane, last_init); break;
+        case 3: panel_product_fixed<T, RT, 3>(img, IN, OUT, lane, last_init); break;
+        default: panel_product_fixed<T, RT, 4>(img, IN, OUT, lane, last_init); break;
         }
     }
 }
@@ -165,6 +185,7 @@ struct GridParams {
     int *track_list;      // fast kernel appends pairs that need POT absorption tracking
     int *track_count;
     int *queue_head;      // dynamic work queue of this launch (zeroed by the host before the launch)
+    int debug;            // experiment switches (PILOT_OT_DEBUG): bit0 no priority, bit1 no longest-first order
 };
 
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
@@ -298,7 +319,7 @@ sinkhorn_stream_kernel(GridParams p) {
         if (__ballot(active || want) == 0ull) break;
 
         // a pair's updates are a serial chain: waves carrying old pairs go first on the shared matrix pipe
-        if ((loop_count++ & 7) == 0) {
+        if ((loop_count++ & 7) == 0 && !(p.debug & 1)) {
             const bool old2 = __ballot(active && ii > 8 * p.period) != 0ull;
             const bool old1 = __ballot(active && ii > 4 * p.period) != 0ull;
             if (old2) __builtin_amdgcn_s_setprio(3);
