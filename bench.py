@@ -135,6 +135,16 @@ def main():
         "algorithmic_flop_per_launch": flops_launch, "pairs_per_launch": int(iters.size),
         "mean_updates_per_pair": round(float(iters.mean()), 2),
     }
+    # HBM traffic per launch: measured offline with rocprofv3 --pmc (bench.py cannot profile itself); the committed
+    # measurement for this exact workload is attached, else null
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
+            tr = json.load(fh).get("%s|%g|%s" % (args.config, args.reg, prec))
+        if tr and world == 1:
+            roofline["traffic"] = tr["traffic_bytes"]
+            roofline["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+    except (OSError, ValueError):
+        pass
     roofline_hbm = {
         "bound": "hbm", "achieved": round(bytes_launch / (kern_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
         "unit": "GB/s", "frac": round(bytes_launch / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
