@@ -184,7 +184,7 @@ constexpr size_t LDS_BYTES = 160 * 1024;
 struct pilot_ot_plan {
     int N, K, device;
     void *img;         // 3 operand images, sized for f64 at this K
-    float *p_f32;      // N x K proportions converted to f32
+    void *p_slot;      // N x KP proportions in accumulator-slot order (f32 or f64; sized for f64)
     int *track_list;   // N x N
     int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch
     int *order_list;   // N x N: longest-first work order of the fast launch
@@ -301,7 +301,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pilot_ot_plan *pl = new (std::nothrow) pilot_ot_plan();
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
     pl->N = N; pl->K = K;
-    pl->img = nullptr; pl->p_f32 = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
+    pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->scratch = nullptr; pl->scratch_bytes = 0; pl->flags_ws = nullptr; pl->flags_ws_n = 0;
@@ -315,7 +315,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     }
     const int kp = ((K + 31) / 32) * 32;
     if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->p_f32), sizeof(float) * (size_t)N * K);
+    if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * (size_t)N * kp);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), 4 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
@@ -336,7 +336,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
 PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (!pl) return PILOT_OT_OK;
     if (pl->img) (void)hipFree(pl->img);
-    if (pl->p_f32) (void)hipFree(pl->p_f32);
+    if (pl->p_slot) (void)hipFree(pl->p_slot);
     if (pl->track_list) (void)hipFree(pl->track_list);
     if (pl->track_count) (void)hipFree(pl->track_count);
     if (pl->order_list) (void)hipFree(pl->order_list);
@@ -383,16 +383,9 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
                     K, lds + (size_t)KP * sizeof(T), LDS_BYTES);
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, 4 * sizeof(int), s));
     T *img = static_cast<T *>(pl->img);
-    const void *Pt;
-    if constexpr (sizeof(T) == 4) {
-        hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<float>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img,
-                           d_P, pl->p_f32, (long)N * K);
-        Pt = pl->p_f32;
-    } else {
-        hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<double>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img,
-                           static_cast<const double *>(nullptr), static_cast<double *>(nullptr), 0L);
-        Pt = d_P;
-    }
+    T *Pt = static_cast<T *>(pl->p_slot);
+    hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<T>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img, d_P, Pt,
+                       (long)N * KP);
     HIP_TRY(hipGetLastError());
     if (n_rows == 0) return PILOT_OT_OK;
 
@@ -439,7 +432,7 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
         HIP_TRY(hipMemsetAsync(pl->order_hist, 0, sizeof(int) * 2 * pilot::ORDER_NB, s));
         int ob = (n_pairs + 255) / 256;
         if (ob > pl->n_cu * 8) ob = pl->n_cu * 8;
-        hipLaunchKernelGGL((pilot::order_bucket_kernel<T>), dim3(ob), dim3(256), 0, s, static_cast<const T *>(Pt), N, K,
+        hipLaunchKernelGGL((pilot::order_bucket_kernel<T>), dim3(ob), dim3(256), 0, s, static_cast<const T *>(Pt), N, KP,
                            n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist);
         hipLaunchKernelGGL(pilot::order_scatter_kernel, dim3(ob), dim3(256), 0, s, pl->order_bucket, n_pairs,
                            pl->order_hist, pl->order_hist + pilot::ORDER_NB, pl->order_list);

@@ -168,7 +168,7 @@ template <typename T> __device__ inline void load_regs(const T *src, typename Mf
 }
 
 struct GridParams {
-    const void *P;        // N x K, element type T
+    const void *P;        // N x KP, element type T, every row in accumulator-slot order [tile][group][reg], 0 in padding
     const void *img;      // 3 images of KP*KP elements of T (G^T-form, G-form, (G o M)-form) + KP first-product values
     void *scratch;        // n_items records of scratch_stride<T>(RT) elements of T
     int N, K;
@@ -243,7 +243,7 @@ sinkhorn_stream_kernel(GridParams p) {
     for (int r = 0; r < NREG; ++r) PADC[r] = M::lidx(RT - 1, r, grp) >= K ? T(1) : T(0);
     // per-column state (replicated in the lane groups of the column)
     bool active = false;
-    int q = 0, ii = 0, flags = 0, abs_at = -1;
+    int q = 0, ii = 0, chk = 1, flags = 0, abs_at = -1;
     T errv = T(1), thr = T(0);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -291,21 +291,22 @@ sinkhorn_stream_kernel(GridParams p) {
                 active = true;
                 q = p.list ? p.list[item] : item;
                 const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
+                const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
                 T bnorm2 = T(0);
 #pragma unroll
-                for (int t = 0; t < RT; ++t)
+                for (int t = 0; t < RT; ++t) {
+                    load_regs<T>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
+                    load_regs<T>(pb + t * NGRP * NREG, B[t]);
+                    load_regs<T>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
-                        const int l = M::lidx(t, r, grp);
-                        const bool ok = l < K;
-                        A[t][r] = ok ? Pt[(size_t)i * K + l] : T(0);
-                        B[t][r] = ok ? Pt[(size_t)j * K + l] : T(0);
-                        U[t][r] = ok ? uinit : T(0);
-                        V[t][r] = ok ? uinit : T(0);
-                        ACC[t][r] = acc0[(t * NREG + r) * NGRP + grp];
+                        const T ui = (t == RT - 1) ? uinit - uinit * PADC[r] : uinit;   // 0 in padded slots
+                        U[t][r] = ui;
+                        V[t][r] = ui;
                         bnorm2 += B[t][r] * B[t][r];
-                        if constexpr (TRACK) { RU[t][r] = ok ? T(1) : T(0); RV[t][r] = ok ? T(1) : T(0); }
+                        if constexpr (TRACK) { RU[t][r] = T(1); RV[t][r] = T(1); }
                     }
+                }
                 bnorm2 = bnorm2 + __shfl_xor(bnorm2, 32);
                 if constexpr (NGRP == 4) bnorm2 = bnorm2 + __shfl_xor(bnorm2, 16);
                 thr = T(p.stop_thr);
@@ -313,6 +314,7 @@ sinkhorn_stream_kernel(GridParams p) {
                     const T fl = T(p.floor_ulps) * M::eps() * sqrtf(bnorm2);
                     thr = thr > fl ? thr : fl;
                 }
+                chk = 1;
                 ii = 0; flags = 0; abs_at = -1; errv = T(1);
             }
         }
@@ -383,7 +385,8 @@ sinkhorn_stream_kernel(GridParams p) {
         panel_product<T, RT>(img_gt, U, ACC, K, lane, PADC);
 
         // ---- POT's stopping rule: the error of update ii-1 is evaluated when (ii-1) % period == 0 ---
-        const bool pending = active && ((ii - 1) % p.period == 0);
+        const bool pending = active && ii == chk;
+        if (pending) chk += p.period;
         const bool capped = active && ii >= p.max_iter;
         if (__ballot(pending || capped)) {
             T e2 = T(0);
@@ -505,8 +508,8 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
     }
     // first product of every pair: (G^T u0)[j] = (1/K) * sum_k G[k][j], in accumulator-slot order
     for (int idx = tid; idx < KP; idx += nthr) {
-        const int g = idx % M::NGRP;
-        const int r = (idx / M::NGRP) % M::NREG;
+        const int r = idx % M::NREG;                              // slot order [tile][group][reg]
+        const int g = (idx / M::NREG) % M::NGRP;
         const int t = idx / (M::NGRP * M::NREG);
         const int j = M::lidx(t, r, g);
         double s = 0.0;
@@ -514,8 +517,14 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
             for (int k = 0; k < K; ++k) s += exp(-Msrc[(size_t)k * K + j] / reg);
         img[3 * nimg + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
     }
-    if (Pdst)
-        for (long idx = tid; idx < n_p; idx += nthr) Pdst[idx] = T(Psrc[idx]);
+    // proportions: N rows of KP values in slot order, zero in padding (n_p = N * KP)
+    for (long idx = tid; idx < n_p; idx += nthr) {
+        const long row = idx / KP;
+        const int sidx = (int)(idx % KP);
+        const int r = sidx % M::NREG, g = (sidx / M::NREG) % M::NGRP, t = sidx / (M::NGRP * M::NREG);
+        const int l = M::lidx(t, r, g);
+        Pdst[idx] = l < K ? T(Psrc[row * K + l]) : T(0);
+    }
 }
 
 // ---- longest-first work order ------------------------------------------------------------------------
