@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (gloo: host all-gather; used to test the multi-rank "
+                         "path on a single-GPU box together with --single-device)")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses HIP device 0 (testing only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,11 +75,15 @@ def main():
 
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X; pilot_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    _lib.check(_lib.load().pilot_ot_set_device(local_rank))
+    dev = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev)
+    _lib.check(_lib.load().pilot_ot_set_device(dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))     # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     cfg = CONFIGS[args.config]
     P, M = make_problem(**cfg)
@@ -95,7 +103,12 @@ def main():
     def step():
         plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=prec, stream=stream,
                  d_emd=local.data_ptr())
-        return sharding.all_gather_rows(local, N) if world > 1 else local
+        if world == 1:
+            return local
+        if args.dist_backend == "nccl":
+            return sharding.all_gather_rows(local, N)          # RCCL all-gather of the HBM-resident row blocks
+        torch.cuda.synchronize()
+        return sharding.all_gather_rows(local.cpu(), N)
 
     def fence():
         if world > 1:
@@ -111,7 +124,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -127,7 +140,7 @@ def main():
     s_bytes = 4 if prec == "fp32" else 8
     bytes_launch = float(iters.size) * (2 * K * s_bytes + s_bytes)     # 2*K*s + s per pair
     roofline = {
-        "bound": "mfma", "kernel": "sinkhorn_grid_kernel<%s>" % ("float" if prec == "fp32" else "double"),
+        "bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % ("float" if prec == "fp32" else "double"),
         "achieved": round(achieved_tf, 3), "peak": PEAK_F32_MFMA_TFLOPS if prec == "fp32" else 78.6,
         "unit": "TFLOP/s", "frac": round(achieved_tf / (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else 78.6), 4),
         "traffic": None,
@@ -154,6 +167,8 @@ def main():
     # ---- sanity: the assembled matrix is the full N x N grid ---------------------------------------
     E = full[:N].cpu().numpy() if world > 1 else local[:N].cpu().numpy()
     assert E.shape == (N, N) and np.isfinite(E).all(), "bench produced a non-finite matrix"
+    if args.reg >= 0.05:   # converged entropic costs are symmetric; a bad row interleave would break this
+        assert float(np.abs(E - E.T).max()) < 1e-5, "assembled matrix is not symmetric: bad row interleave?"
 
     out = {
         "metric": "W2 patient-pairs/sec (full NxN EMD matrix)", "value": round(value, 1), "unit": "pairs/s",

@@ -16,7 +16,7 @@
  *   - every function returns PILOT_OT_OK (0) or a negative PILOT_OT_E* code; the message of the
  *     last failure on the calling thread is pilot_ot_last_error().  No exceptions cross the ABI.
  *   - "host" entry points take caller-owned host buffers, copy in/out internally and retain no
- *     pointer after returning.  "_dev" entry points take device pointers (hipMalloc'ed by the
+ *     pointer to them after returning (device workspace is cached per thread: pilot_ot_shutdown).  "_dev" entry points take device pointers (hipMalloc'ed by the
  *     caller or by pilot_ot_dev_alloc) and enqueue on the given hipStream_t without synchronising.
  *   - there is NO CPU implementation behind this ABI: without a gfx950 device every compute entry
  *     point fails with PILOT_OT_EHIP.
@@ -67,6 +67,7 @@ const char *pilot_ot_last_error(void);
 int pilot_ot_device_count(int *count);            /* number of visible HIP devices (0 is not an error) */
 int pilot_ot_set_device(int device);              /* device used by the calling thread's later calls   */
 int pilot_ot_device_name(char *buf, int buflen);  /* gcnArchName of the current device                 */
+int pilot_ot_shutdown(void);                      /* free the calling thread's cached host-API workspace */
 
 /* thin device-memory helpers so a host language without a HIP binding can keep data resident */
 int pilot_ot_dev_alloc(void **dptr, unsigned long long bytes);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
     "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
-    "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times",
+    "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_shutdown",
 ]
 
 _lib = None

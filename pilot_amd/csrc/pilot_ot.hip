@@ -479,6 +479,66 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
                             cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Host-buffer entry points keep one plan + staging buffers per calling thread and reuse them while the
+// shape stays the same (a PILOT session calls with one (N, K)); pilot_ot_shutdown() releases them.
+namespace {
+struct HostCtx {
+    pilot_ot_plan *plan = nullptr;
+    int N = 0, K = 0, device = -1;
+    size_t n_out = 0;
+    double *dP = nullptr, *dM = nullptr, *dE = nullptr, *dErr = nullptr;
+    int *dIt = nullptr, *dFl = nullptr;
+    void release() {
+        if (dP) (void)hipFree(dP);
+        if (dM) (void)hipFree(dM);
+        if (dE) (void)hipFree(dE);
+        if (dErr) (void)hipFree(dErr);
+        if (dIt) (void)hipFree(dIt);
+        if (dFl) (void)hipFree(dFl);
+        dP = dM = dE = dErr = nullptr; dIt = dFl = nullptr;
+        if (plan) pilot_ot_plan_destroy(plan);
+        plan = nullptr; N = K = 0; n_out = 0; device = -1;
+    }
+    ~HostCtx() {}   // device memory is released by pilot_ot_shutdown() or at process exit
+};
+thread_local HostCtx g_host;
+
+int host_ctx_prepare(int N, int K, size_t n_out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HostCtx &h = g_host;
+    if (h.plan && (h.N != N || h.K != K || h.device != dev)) h.release();
+    if (!h.plan) {
+        int rc = pilot_ot_plan_create(N, K, &h.plan);
+        if (rc != PILOT_OT_OK) return rc;
+        h.N = N; h.K = K; h.device = dev;
+        hipError_t e = hipMalloc(&h.dP, sizeof(double) * (size_t)N * K);
+        if (e == hipSuccess) e = hipMalloc(&h.dM, sizeof(double) * (size_t)K * K);
+        if (e != hipSuccess) { h.release(); return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e)); }
+    }
+    if (n_out > h.n_out) {
+        if (h.dE) (void)hipFree(h.dE);
+        if (h.dErr) (void)hipFree(h.dErr);
+        if (h.dIt) (void)hipFree(h.dIt);
+        if (h.dFl) (void)hipFree(h.dFl);
+        h.dE = h.dErr = nullptr; h.dIt = h.dFl = nullptr; h.n_out = 0;
+        hipError_t e = hipMalloc(&h.dE, sizeof(double) * n_out);
+        if (e == hipSuccess) e = hipMalloc(&h.dErr, sizeof(double) * n_out);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h.dIt), sizeof(int) * n_out);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h.dFl), sizeof(int) * n_out);
+        if (e != hipSuccess) { h.release(); return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e)); }
+        h.n_out = n_out;
+    }
+    return PILOT_OT_OK;
+}
+}  // namespace
+
+PILOT_API int pilot_ot_shutdown(void) {
+    g_host.release();
+    return PILOT_OT_OK;
+}
+
 PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg, int num_iter_max,
                                      double stop_thr, double tau, int check_period, int precision,
                                      double f32_floor_ulps, int cost_is_symmetric, int row_begin, int row_end,
@@ -496,40 +556,23 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     const size_t n_out = (size_t)n_rows * N;
     if (n_out == 0) return PILOT_OT_OK;
 
-    pilot_ot_plan *pl = nullptr;
-    rc = pilot_ot_plan_create(N, K, &pl);
+    rc = host_ctx_prepare(N, K, n_out);
     if (rc != PILOT_OT_OK) return rc;
-    double *dP = nullptr, *dM = nullptr, *dE = nullptr, *dErr = nullptr;
-    int *dIt = nullptr, *dFl = nullptr;
-    hipError_t e = hipMalloc(&dP, sizeof(double) * (size_t)N * K);
-    if (e == hipSuccess) e = hipMalloc(&dM, sizeof(double) * (size_t)K * K);
-    if (e == hipSuccess) e = hipMalloc(&dE, sizeof(double) * n_out);
-    if (e == hipSuccess) e = hipMalloc(&dErr, sizeof(double) * n_out);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dIt), sizeof(int) * n_out);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dFl), sizeof(int) * n_out);
-    if (e == hipSuccess) e = hipMemcpy(dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
-    if (rc == PILOT_OT_OK)
-        rc = pilot_ot_sinkhorn_grid_dev(pl, dP, dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
-                                        f32_floor_ulps, cost_is_symmetric, row_begin, row_end, row_step, dE, dIt, dErr,
-                                        dFl, nullptr);
-    if (rc == PILOT_OT_OK) {
-        e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess) e = hipMemcpy(emd, dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && iters) e = hipMemcpy(iters, dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && err) e = hipMemcpy(err, dErr, sizeof(double) * n_out, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && flags) e = hipMemcpy(flags, dFl, sizeof(int) * n_out, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
-    }
-    if (dP) (void)hipFree(dP);
-    if (dM) (void)hipFree(dM);
-    if (dE) (void)hipFree(dE);
-    if (dErr) (void)hipFree(dErr);
-    if (dIt) (void)hipFree(dIt);
-    if (dFl) (void)hipFree(dFl);
-    pilot_ot_plan_destroy(pl);
-    return rc;
+    HostCtx &h = g_host;
+    hipError_t e = hipMemcpy(h.dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h.dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
+    rc = pilot_ot_sinkhorn_grid_dev(h.plan, h.dP, h.dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
+                                    f32_floor_ulps, cost_is_symmetric, row_begin, row_end, row_step, h.dE,
+                                    iters ? h.dIt : nullptr, err ? h.dErr : nullptr, h.dFl, nullptr);
+    if (rc != PILOT_OT_OK) return rc;
+    e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess) e = hipMemcpy(emd, h.dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && iters) e = hipMemcpy(iters, h.dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && err) e = hipMemcpy(err, h.dErr, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && flags) e = hipMemcpy(flags, h.dFl, sizeof(int) * n_out, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
+    return PILOT_OT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -589,33 +632,21 @@ PILOT_API int pilot_ot_emd_grid(const double *P, int N, int K, const double *M, 
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     const size_t n_out = (size_t)n_rows * N;
     if (n_out == 0) return PILOT_OT_OK;
-    pilot_ot_plan *pl = nullptr;
-    int rc = pilot_ot_plan_create(N, K, &pl);
+    int rc = host_ctx_prepare(N, K, n_out);
     if (rc != PILOT_OT_OK) return rc;
-    double *dP = nullptr, *dM = nullptr, *dE = nullptr;
-    int *dA = nullptr;
-    hipError_t e = hipMalloc(&dP, sizeof(double) * (size_t)N * K);
-    if (e == hipSuccess) e = hipMalloc(&dM, sizeof(double) * (size_t)K * K);
-    if (e == hipSuccess) e = hipMalloc(&dE, sizeof(double) * n_out);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dA), sizeof(int) * n_out);
-    if (e == hipSuccess) e = hipMemcpy(dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(dE, 0, sizeof(double) * n_out);
-    if (e == hipSuccess) e = hipMemset(dA, 0, sizeof(int) * n_out);
-    if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
-    if (rc == PILOT_OT_OK) rc = pilot_ot_emd_grid_dev(pl, dP, dM, mode, row_begin, row_end, row_step, dE, dA, nullptr);
-    if (rc == PILOT_OT_OK) {
-        e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess) e = hipMemcpy(emd, dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_aug) e = hipMemcpy(n_aug, dA, sizeof(int) * n_out, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
-    }
-    if (dP) (void)hipFree(dP);
-    if (dM) (void)hipFree(dM);
-    if (dE) (void)hipFree(dE);
-    if (dA) (void)hipFree(dA);
-    pilot_ot_plan_destroy(pl);
-    return rc;
+    HostCtx &h = g_host;
+    hipError_t e = hipMemcpy(h.dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h.dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(h.dE, 0, sizeof(double) * n_out);
+    if (e == hipSuccess) e = hipMemset(h.dIt, 0, sizeof(int) * n_out);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    rc = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, mode, row_begin, row_end, row_step, h.dE, h.dIt, nullptr);
+    if (rc != PILOT_OT_OK) return rc;
+    e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess) e = hipMemcpy(emd, h.dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_aug) e = hipMemcpy(n_aug, h.dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
+    return PILOT_OT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
