@@ -103,9 +103,9 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int RT, bool SYM, bool TRACK>
+template <class C, int RT, bool SYM, bool TRACK>
 hipError_t launch_one(dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
-    auto kern = pilot::sinkhorn_stream_kernel<T, RT, SYM, TRACK>;
+    auto kern = pilot::sinkhorn_stream_kernel<C, RT, SYM, TRACK>;
     if (lds > 32 * 1024) {  // beyond the default dynamic-LDS window the limit must be raised explicitly
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -115,60 +115,62 @@ hipError_t launch_one(dim3 grid, size_t lds, hipStream_t s, const pilot::GridPar
     return hipGetLastError();
 }
 
-template <typename T, int RT>
+template <class C, int RT>
 hipError_t launch_rt(bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
-    if (sym) return track ? launch_one<T, RT, true, true>(grid, lds, s, p) : launch_one<T, RT, true, false>(grid, lds, s, p);
-    return track ? launch_one<T, RT, false, true>(grid, lds, s, p) : launch_one<T, RT, false, false>(grid, lds, s, p);
+    if (sym) return track ? launch_one<C, RT, true, true>(grid, lds, s, p) : launch_one<C, RT, true, false>(grid, lds, s, p);
+    return track ? launch_one<C, RT, false, true>(grid, lds, s, p) : launch_one<C, RT, false, false>(grid, lds, s, p);
 }
 
-template <typename T>
+template <class C>
 hipError_t launch_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
     switch (RT) {
-    case 1: return launch_rt<T, 1>(sym, track, grid, lds, s, p);
-    case 2: return launch_rt<T, 2>(sym, track, grid, lds, s, p);
-    case 3: return launch_rt<T, 3>(sym, track, grid, lds, s, p);
-    case 4: return launch_rt<T, 4>(sym, track, grid, lds, s, p);
+    case 1: return launch_rt<C, 1>(sym, track, grid, lds, s, p);
+    case 2: return launch_rt<C, 2>(sym, track, grid, lds, s, p);
+    case 3: return launch_rt<C, 3>(sym, track, grid, lds, s, p);
+    case 4: return launch_rt<C, 4>(sym, track, grid, lds, s, p);
     default: break;
     }
-    if constexpr (sizeof(T) == 8) {
+    if constexpr (C::TILE == 16) {
         switch (RT) {
-        case 5: return launch_rt<T, 5>(sym, track, grid, lds, s, p);
-        case 6: return launch_rt<T, 6>(sym, track, grid, lds, s, p);
-        case 7: return launch_rt<T, 7>(sym, track, grid, lds, s, p);
-        case 8: return launch_rt<T, 8>(sym, track, grid, lds, s, p);
+        case 5: return launch_rt<C, 5>(sym, track, grid, lds, s, p);
+        case 6: return launch_rt<C, 6>(sym, track, grid, lds, s, p);
+        case 7: return launch_rt<C, 7>(sym, track, grid, lds, s, p);
+        case 8: return launch_rt<C, 8>(sym, track, grid, lds, s, p);
         default: break;
         }
     }
     return hipErrorInvalidValue;
 }
 
-template <typename T, int RT> hipError_t launch_value_rt(dim3 grid, hipStream_t s, const pilot::GridParams &p) {
-    hipLaunchKernelGGL((pilot::sinkhorn_value_kernel<T, RT>), grid, dim3(pilot::WAVE * pilot::WAVES_PER_WG), 0, s, p);
+template <class C, int RT> hipError_t launch_value_rt(dim3 grid, hipStream_t s, const pilot::GridParams &p) {
+    hipLaunchKernelGGL((pilot::sinkhorn_value_kernel<C, RT>), grid, dim3(pilot::WAVE * pilot::WAVES_PER_WG), 0, s, p);
     return hipGetLastError();
 }
-template <typename T> hipError_t launch_value(int RT, dim3 grid, hipStream_t s, const pilot::GridParams &p) {
+template <class C> hipError_t launch_value(int RT, dim3 grid, hipStream_t s, const pilot::GridParams &p) {
     switch (RT) {
-    case 1: return launch_value_rt<T, 1>(grid, s, p);
-    case 2: return launch_value_rt<T, 2>(grid, s, p);
-    case 3: return launch_value_rt<T, 3>(grid, s, p);
-    case 4: return launch_value_rt<T, 4>(grid, s, p);
+    case 1: return launch_value_rt<C, 1>(grid, s, p);
+    case 2: return launch_value_rt<C, 2>(grid, s, p);
+    case 3: return launch_value_rt<C, 3>(grid, s, p);
+    case 4: return launch_value_rt<C, 4>(grid, s, p);
     default: break;
     }
-    if constexpr (sizeof(T) == 8) {
+    if constexpr (C::TILE == 16) {
         switch (RT) {
-        case 5: return launch_value_rt<T, 5>(grid, s, p);
-        case 6: return launch_value_rt<T, 6>(grid, s, p);
-        case 7: return launch_value_rt<T, 7>(grid, s, p);
-        case 8: return launch_value_rt<T, 8>(grid, s, p);
+        case 5: return launch_value_rt<C, 5>(grid, s, p);
+        case 6: return launch_value_rt<C, 6>(grid, s, p);
+        case 7: return launch_value_rt<C, 7>(grid, s, p);
+        case 8: return launch_value_rt<C, 8>(grid, s, p);
         default: break;
         }
     }
     return hipErrorInvalidValue;
 }
 // workgroups of the persistent stream kernel resident per CU (register file and LDS both bound it)
-template <typename T> int stream_wgs_per_cu(int RT, bool track, size_t lds) {
-    const int regs = (track ? 7 : 5) * RT * pilot::Mfma<T>::NREG * int(sizeof(T) / 4) + 72;
-    int occ = regs <= 256 ? 2 : 1;
+template <class C> int stream_wgs_per_cu(int RT, bool sym, bool track, size_t lds) {
+    const int w = int(sizeof(typename C::T) / 4);
+    const int na = RT * C::NREG * RT * w;
+    const int regs = (track ? 7 : 5) * RT * C::NREG * w + C::NREG * w + 56 + ((sym && na <= 64) ? na : 0);
+    int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));   // mirrors pilot::min_waves_per_simd
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < occ) occ = by_lds;
     return occ < 1 ? 1 : occ;
@@ -369,11 +371,12 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     return PILOT_OT_OK;
 }
 
-template <typename T>
+template <class C>
 int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
              double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
              int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s) {
-    using M = pilot::Mfma<T>;
+    using M = C;
+    using T = typename C::T;
     const int N = pl->N, K = pl->K;
     const int RT = (K + M::TILE - 1) / M::TILE;
     const int KP = RT * M::TILE;
@@ -384,7 +387,7 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, 4 * sizeof(int), s));
     T *img = static_cast<T *>(pl->img);
     T *Pt = static_cast<T *>(pl->p_slot);
-    hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<T>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img, d_P, Pt,
+    hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<C>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img, d_P, Pt,
                        (long)N * KP);
     HIP_TRY(hipGetLastError());
     if (n_rows == 0) return PILOT_OT_OK;
@@ -392,7 +395,7 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     const int n_pairs = n_rows * N;
     // device workspace that scales with the number of pairs: grown on demand (first call at a new size
     // allocates; later calls at the same or a smaller size do not, so they stay graph-capturable)
-    const size_t scr_bytes = (size_t)n_pairs * pilot::scratch_stride<T>(RT) * sizeof(T);
+    const size_t scr_bytes = (size_t)n_pairs * pilot::scratch_stride<C>(RT) * sizeof(T);
     if (scr_bytes > pl->scratch_bytes) {
         if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
     pl->scratch = nullptr; pl->scratch_bytes = 0;
@@ -425,7 +428,9 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     lds += (size_t)KP * sizeof(T);   // first-product table next to the operand image(s)
     const int tiles = (n_pairs + M::TILE - 1) / M::TILE;
     const int wgs_needed = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
-    int wgs = pl->n_cu * stream_wgs_per_cu<T>(RT, false, lds);
+    int occ_main = stream_wgs_per_cu<C>(RT, sym, false, lds);
+    if ((p.debug >> 4) & 7) occ_main = (p.debug >> 4) & 7;   // experiment: override resident workgroups per CU
+    int wgs = pl->n_cu * occ_main;
     if (wgs > wgs_needed) wgs = wgs_needed;
     // longest-first work order (see order_bucket_kernel)
     if (!(p.debug & 2)) {
@@ -441,19 +446,19 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     }
     hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    HIP_TRY((launch_any<T>(RT, sym, false, dim3(wgs), lds, s, p)));
+    HIP_TRY((launch_any<C>(RT, sym, false, dim3(wgs), lds, s, p)));
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
-    int wgs_t = pl->n_cu * stream_wgs_per_cu<T>(RT, true, lds);
+    int wgs_t = pl->n_cu * stream_wgs_per_cu<C>(RT, sym, true, lds);
     if (wgs_t > wgs_needed) wgs_t = wgs_needed;
-    HIP_TRY((launch_any<T>(RT, sym, true, dim3(wgs_t), lds, s, p)));
+    HIP_TRY((launch_any<C>(RT, sym, true, dim3(wgs_t), lds, s, p)));
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
     // third pass: cost <Gamma, M> of every pair from its parked scalings
     p.list = nullptr; p.list_len = nullptr;
     int wgs_v = pl->n_cu * 8;
     if (wgs_v > wgs_needed) wgs_v = wgs_needed;
-    HIP_TRY((launch_value<T>(RT, dim3(wgs_v), s, p)));
+    HIP_TRY((launch_value<C>(RT, dim3(wgs_v), s, p)));
     return PILOT_OT_OK;
 }
 
@@ -472,10 +477,19 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (precision == PILOT_OT_PREC_F32)
-        return run_grid<float>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
+    if (precision == PILOT_OT_PREC_F32) {
+        // 16-pair waves (v_mfma_f32_16x16x4_f32) beat 32-pair waves (v_mfma_f32_32x32x2_f32) at every measured
+        // shape: finer row padding (K=50 -> 64 either way, K=100 -> 112 vs 128), 2-4 waves per SIMD instead of 1-2,
+        // finer work quantum.  The 32-wide form stays selectable for A/B runs (PILOT_OT_DEBUG bit 2).
+        const char *dbg = getenv("PILOT_OT_DEBUG");
+        if (!(dbg && (atoi(dbg) & 4)))
+            return run_grid<pilot::CfgF32x16>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period,
+                                              f32_floor_ulps, cost_is_symmetric != 0, row_begin, n_rows, row_step,
+                                              d_emd, d_iters, d_err, d_flags, s);
+        return run_grid<pilot::CfgF32x32>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
                                cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
-    return run_grid<double>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
+    }
+    return run_grid<pilot::CfgF64x16>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
                             cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
 }
 

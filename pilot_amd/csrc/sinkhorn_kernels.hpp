@@ -11,7 +11,7 @@
 //     the lane and its rows (= cell types) in the accumulator registers, so it is fed back as the "B"
 //     operand of the next product with NO lane movement and NO LDS round trip: k-step (t', r) consumes
 //     accumulator register r of row-tile t'.  Cell types are assigned to accumulator slots so that the
-//     first ceil(K/2) (f32) / ceil(K/4) (f64) k-steps hold all of them (Mfma<T>::lidx) and the rest
+//     first ceil(K/2) (f32) / ceil(K/4) (f64) k-steps hold all of them (Cfg*::lidx) and the rest
 //     are skipped; the LDS image stores G permuted to match;
 //   * element-wise work (v = b / G^T u, u = a / G v, marginal error, tau tracking) happens in that same
 //     register layout; per-pair reductions over cell types are in-register sums plus one or two
@@ -33,20 +33,19 @@ constexpr int WAVES_PER_WG = 4;
 // flag bits, identical to include/pilot_ot.h
 constexpr int FLAG_CONVERGED = 1, FLAG_NAN = 2, FLAG_ABSORB_LAST = 4, FLAG_ABSORBED = 8, FLAG_F64 = 16;
 
-template <typename T> struct Mfma;
+// ---- MFMA configurations: element type + instruction shape -----------------------------------------------
+// TILE  rows per accumulator tile == pairs (columns) per wave;  NREG accumulator registers per tile;
+// NGRP  lane groups (64 / TILE) == k per MFMA.  lidx(t, r, g): cell type held by accumulator register r of
+// row-tile t in lane group g; cell types are dealt to slots in (tile, register, group) order, so k-step
+// (t, r) covers NGRP consecutive cell types and the first ceil(K / NGRP) k-steps hold all of them.
+// lidx_of_row(t, p): cell type of HARDWARE row p of row-tile t (the A operand is addressed by hardware row).
 
-template <> struct Mfma<float> {
-    static constexpr int TILE = 32;  // rows per accumulator tile == pairs per wave
-    static constexpr int NREG = 16;  // accumulator registers per tile
-    static constexpr int NGRP = 2;   // lane groups (64 / TILE) == k per MFMA
+struct CfgF32x32 {   // v_mfma_f32_32x32x2_f32: hardware row of register r in group g = (r&3) + 8*(r>>2) + 4*g
+    using T = float;
+    static constexpr int TILE = 32, NREG = 16, NGRP = 2, VEC = 4;
     using acc_t = float __attribute__((ext_vector_type(16)));
     using vec4_t = float __attribute__((ext_vector_type(4)));
-    static constexpr int VEC = 4;    // elements per 16-byte access
-    // cell type held by accumulator register r of row-tile t in lane group g.  The hardware row of that
-    // slot is (r&3) + 8*(r>>2) + 4*g (cdna guide, 32x32 C/D map); cell types are dealt to slots in
-    // (tile, register, group) order so k-step (t, r) covers cell types 2*(16t+r) and 2*(16t+r)+1.
     __host__ __device__ static constexpr int lidx(int t, int r, int g) { return 2 * (16 * t + r) + g; }
-    // cell type of hardware row p (0..31) of row-tile t (the A operand is addressed by hardware row)
     __host__ __device__ static constexpr int lidx_of_row(int t, int p) {
         return lidx(t, (p & 3) + 4 * (p >> 3), (p >> 2) & 1);
     }
@@ -57,14 +56,25 @@ template <> struct Mfma<float> {
     __device__ static inline float eps() { return 1.1920929e-07f; }
 };
 
-template <> struct Mfma<double> {
-    static constexpr int TILE = 16;
-    static constexpr int NREG = 4;
-    static constexpr int NGRP = 4;
+struct CfgF32x16 {   // v_mfma_f32_16x16x4_f32: hardware row of register r in group g = 4*g + r
+    using T = float;
+    static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 4;
+    using acc_t = float __attribute__((ext_vector_type(4)));
+    using vec4_t = float __attribute__((ext_vector_type(4)));
+    __host__ __device__ static constexpr int lidx(int t, int r, int g) { return 4 * (4 * t + r) + g; }
+    __host__ __device__ static constexpr int lidx_of_row(int t, int p) { return lidx(t, p & 3, p >> 2); }
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    __device__ static inline float eps() { return 1.1920929e-07f; }
+};
+
+struct CfgF64x16 {   // v_mfma_f64_16x16x4_f64 has its own C/D map: hardware row = (lane>>4) + 4*reg (k-step order)
+    using T = double;
+    static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 2;
     using acc_t = double __attribute__((ext_vector_type(4)));
     using vec4_t = double __attribute__((ext_vector_type(2)));
-    static constexpr int VEC = 2;
-    // f64 MFMA has its own C/D map: hardware row = (lane>>4) + 4*reg, which is already k-step order
     __host__ __device__ static constexpr int lidx(int t, int r, int g) { return 16 * t + 4 * r + g; }
     __host__ __device__ static constexpr int lidx_of_row(int t, int p) { return 16 * t + p; }
     __device__ static inline acc_t mfma(double a, double b, acc_t c) {
@@ -75,25 +85,38 @@ template <> struct Mfma<double> {
 };
 
 // index of the LDS/global "A image" element read by `lane` for k-step (tp, r) and output row-tile t
-template <typename T>
+template <class C>
 __host__ __device__ constexpr int img_index(int RT, int tp, int r, int t, int lane) {
-    return (((tp * Mfma<T>::NREG + r) * RT + t) * WAVE) + lane;
+    return (((tp * C::NREG + r) * RT + t) * WAVE) + lane;
 }
 // per-item scratch record: u panel, v panel (KP values each, [tile][group][reg] order), then 4 extras
-template <typename T> __host__ __device__ constexpr int scratch_stride(int RT) { return 2 * RT * Mfma<T>::TILE + 4; }
+template <class C> __host__ __device__ constexpr int scratch_stride(int RT) { return 2 * RT * C::TILE + 4; }
 
-template <typename T> __device__ inline T group_sum(T x) {
+template <class C> __device__ inline typename C::T group_sum(typename C::T x) {
     // sum over the lane groups that hold the same column (lane % TILE)
-    if constexpr (Mfma<T>::NGRP == 4) x += __shfl_xor(x, 16);
+    if constexpr (C::NGRP == 4) x += __shfl_xor(x, 16);
     x += __shfl_xor(x, 32);
     return x;
 }
-template <typename T> __device__ inline T group_max(T x) {
-    if constexpr (Mfma<T>::NGRP == 4) { T y = __shfl_xor(x, 16); x = x > y ? x : y; }
+template <class C> __device__ inline typename C::T group_max(typename C::T x) {
+    using T = typename C::T;
+    if constexpr (C::NGRP == 4) { T y = __shfl_xor(x, 16); x = x > y ? x : y; }
     T y = __shfl_xor(x, 32);
     return x > y ? x : y;
 }
 template <typename T> __device__ inline T abs_t(T x) { return x < T(0) ? -x : x; }
+
+// Where the stationary A operand of a product comes from: the lane-ordered image in LDS / global memory
+// (one ds_read / global load per MFMA), or -- when the whole image fits in <= 64 registers per lane (small K,
+// symmetric cost) -- registers loaded once per wave, which removes every LDS access from the update loop.
+template <class C> struct AFromImage {
+    const typename C::T *img; int lane;
+    __device__ inline typename C::T operator()(int step_tile) const { return img[step_tile * WAVE + lane]; }
+};
+template <class C, int NA> struct AFromRegs {
+    typename C::T a[NA];
+    __device__ inline typename C::T operator()(int step_tile) const { return a[step_tile]; }
+};
 
 // OUT[t] = sum over k of X_img[out row][k] * IN[k]   for the whole K x TILE panel
 // `last_init` seeds the accumulator of the last row-tile (1 in padded slots keeps 0 / OUT finite there).
@@ -102,68 +125,72 @@ template <typename T> __device__ inline T abs_t(T x) { return x < T(0) ? -x : x;
 // The number of k-steps it needs is wave-uniform but only known at run time, so the tail is a jump table
 // over straight-line variants (NLAST = CH, 2*CH, ... registers): no branch sits between an operand's
 // ds_read and its MFMA, and the scheduler sees one block per variant.
-template <typename T, int RT, int NLAST>
-__device__ inline void panel_product_fixed(const T *__restrict__ img, const typename Mfma<T>::acc_t (&IN)[RT],
-                                           typename Mfma<T>::acc_t (&OUT)[RT], int lane,
-                                           const typename Mfma<T>::acc_t &last_init) {
-    using M = Mfma<T>;
+template <class C, int RT, int NLAST, class AOp>
+__device__ inline void panel_product_fixed(const AOp &aop, const typename C::acc_t (&IN)[RT],
+                                           typename C::acc_t (&OUT)[RT],
+                                           const typename C::acc_t &last_init) {
+    using M = C;
+    using T = typename C::T;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) OUT[t][r] = (t == RT - 1) ? last_init[r] : T(0);
+    // k-step outer, output tile inner: RT independent accumulator chains are interleaved, so a wave alone on
+    // its SIMD never waits on the dependent-accumulator latency
 #pragma unroll
-        for (int tp = 0; tp < RT; ++tp)
+    for (int tp = 0; tp < RT; ++tp)
 #pragma unroll
-            for (int r = 0; r < (tp < RT - 1 ? M::NREG : NLAST); ++r)
-                OUT[t] = M::mfma(img[img_index<T>(RT, tp, r, t, lane)], IN[tp][r], OUT[t]);
-    }
+        for (int r = 0; r < (tp < RT - 1 ? M::NREG : NLAST); ++r)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+                OUT[t] = M::mfma(aop((tp * M::NREG + r) * RT + t), IN[tp][r], OUT[t]);
 }
 
-template <typename T, int RT>
-__device__ inline void panel_product(const T *__restrict__ img, const typename Mfma<T>::acc_t (&IN)[RT],
-                                     typename Mfma<T>::acc_t (&OUT)[RT], int K, int lane,
-                                     const typename Mfma<T>::acc_t &last_init) {
-    using M = Mfma<T>;
+template <class C, int RT, class AOp>
+__device__ inline void panel_product(const AOp &aop, const typename C::acc_t (&IN)[RT],
+                                     typename C::acc_t (&OUT)[RT], int K,
+                                     const typename C::acc_t &last_init) {
+    using M = C;
     // registers of the last row-tile that hold a cell type (group 0 holds the smallest index of a register)
     const int n_last = (K - M::lidx(RT - 1, 0, 0) + M::NGRP - 1) / M::NGRP;
     if constexpr (M::NREG == 16) {
         switch ((n_last + 1) / 2) {
-        case 1: panel_product_fixed<T, RT, 2>(img, IN, OUT, lane, last_init); break;
-        case 2: panel_product_fixed<T, RT, 4>(img, IN, OUT, lane, last_init); break;
-        case 3: panel_product_fixed<T, RT, 6>(img, IN, OUT, lane, last_init); break;
-        case 4: panel_product_fixed<T, RT, 8>(img, IN, OUT, lane, last_init); break;
-        case 5: panel_product_fixed<T, RT, 10>(img, IN, OUT, lane, last_init); break;
-        case 6: panel_product_fixed<T, RT, 12>(img, IN, OUT, lane, last_init); break;
-        case 7: panel_product_fixed<T, RT, 14>(img, IN, OUT, lane, last_init); break;
-        default: panel_product_fixed<T, RT, 16>(img, IN, OUT, lane, last_init); break;
+        case 1: panel_product_fixed<C, RT, 2>(aop, IN, OUT, last_init); break;
+        case 2: panel_product_fixed<C, RT, 4>(aop, IN, OUT, last_init); break;
+        case 3: panel_product_fixed<C, RT, 6>(aop, IN, OUT, last_init); break;
+        case 4: panel_product_fixed<C, RT, 8>(aop, IN, OUT, last_init); break;
+        case 5: panel_product_fixed<C, RT, 10>(aop, IN, OUT, last_init); break;
+        case 6: panel_product_fixed<C, RT, 12>(aop, IN, OUT, last_init); break;
+        case 7: panel_product_fixed<C, RT, 14>(aop, IN, OUT, last_init); break;
+        default: panel_product_fixed<C, RT, 16>(aop, IN, OUT, last_init); break;
         }
     } else {
         switch (n_last) {
-        case 1: panel_product_fixed<T, RT, 1>(img, IN, OUT, lane, last_init); break;
-        case 2: panel_product_fixed<T, RT, 2>(img, IN, OUT, lane, last_init); break;
-        case 3: panel_product_fixed<T, RT, 3>(img, IN, OUT, lane, last_init); break;
-        default: panel_product_fixed<T, RT, 4>(img, IN, OUT, lane, last_init); break;
+        case 1: panel_product_fixed<C, RT, 1>(aop, IN, OUT, last_init); break;
+        case 2: panel_product_fixed<C, RT, 2>(aop, IN, OUT, last_init); break;
+        case 3: panel_product_fixed<C, RT, 3>(aop, IN, OUT, last_init); break;
+        default: panel_product_fixed<C, RT, 4>(aop, IN, OUT, last_init); break;
         }
     }
 }
 
-template <typename T> __device__ inline void store_regs(T *dst, const typename Mfma<T>::acc_t &x) {
-    using V = typename Mfma<T>::vec4_t;
+template <class C> __device__ inline void store_regs(typename C::T *dst, const typename C::acc_t &x) {
+    using V = typename C::vec4_t;
 #pragma unroll
-    for (int c = 0; c < Mfma<T>::NREG / Mfma<T>::VEC; ++c) {
+    for (int c = 0; c < C::NREG / C::VEC; ++c) {
         V v;
 #pragma unroll
-        for (int e = 0; e < Mfma<T>::VEC; ++e) v[e] = x[c * Mfma<T>::VEC + e];
-        *reinterpret_cast<V *>(dst + c * Mfma<T>::VEC) = v;
+        for (int e = 0; e < C::VEC; ++e) v[e] = x[c * C::VEC + e];
+        *reinterpret_cast<V *>(dst + c * C::VEC) = v;
     }
 }
-template <typename T> __device__ inline void load_regs(const T *src, typename Mfma<T>::acc_t &x) {
-    using V = typename Mfma<T>::vec4_t;
+template <class C> __device__ inline void load_regs(const typename C::T *src, typename C::acc_t &x) {
+    using V = typename C::vec4_t;
 #pragma unroll
-    for (int c = 0; c < Mfma<T>::NREG / Mfma<T>::VEC; ++c) {
-        const V v = *reinterpret_cast<const V *>(src + c * Mfma<T>::VEC);
+    for (int c = 0; c < C::NREG / C::VEC; ++c) {
+        const V v = *reinterpret_cast<const V *>(src + c * C::VEC);
 #pragma unroll
-        for (int e = 0; e < Mfma<T>::VEC; ++e) x[c * Mfma<T>::VEC + e] = v[e];
+        for (int e = 0; e < C::VEC; ++e) x[c * C::VEC + e] = v[e];
     }
 }
 
@@ -189,8 +216,16 @@ struct GridParams {
 };
 
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
-template <typename T, int RT, bool TRACK> constexpr int min_waves_per_simd() {
-    return ((TRACK ? 7 : 5) * RT * Mfma<T>::NREG * int(sizeof(T) / 4) + 72 <= 256) ? 2 : 1;
+// the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
+template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
+    return SYM && RT * C::NREG * RT * int(sizeof(typename C::T) / 4) <= 64;
+}
+template <class C, int RT, bool SYM, bool TRACK> constexpr int panel_regs() {
+    return (TRACK ? 7 : 5) * RT * C::NREG * int(sizeof(typename C::T) / 4) + C::NREG * int(sizeof(typename C::T) / 4) + 56 +
+           (operands_in_regs<C, RT, SYM>() ? RT * C::NREG * RT * int(sizeof(typename C::T) / 4) : 0);
+}
+template <class C, int RT, bool SYM, bool TRACK> constexpr int min_waves_per_simd() {
+    return panel_regs<C, RT, SYM, TRACK>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK>() <= 256 ? 2 : 1));
 }
 
 // TRACK = false: plain scaling iterations; a pair whose POT residual scaling would exceed tau (i.e. POT
@@ -198,14 +233,15 @@ template <typename T, int RT, bool TRACK> constexpr int min_waves_per_simd() {
 // TRACK = true : additionally carries the reciprocal reference scalings so the iteration at which every
 //                POT absorption happens is known (needed for POT's err-after-absorption and
 //                plan/(K*K)-on-the-final-update behaviour; see oracle/pilot_oracle.c).
-template <typename T, int RT, bool SYM, bool TRACK>
-__global__ void __launch_bounds__(WAVE * WAVES_PER_WG, (min_waves_per_simd<T, RT, TRACK>()))
+template <class C, int RT, bool SYM, bool TRACK>
+__global__ void __launch_bounds__(WAVE * WAVES_PER_WG, (min_waves_per_simd<C, RT, SYM, TRACK>()))
 sinkhorn_stream_kernel(GridParams p) {
-    using M = Mfma<T>;
+    using M = C;
+    using T = typename C::T;
     using acc_t = typename M::acc_t;
     constexpr int TILE = M::TILE, NREG = M::NREG, NGRP = M::NGRP;
     constexpr int KP = RT * TILE;
-    constexpr int SCR = scratch_stride<T>(RT);
+    constexpr int SCR = scratch_stride<C>(RT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *lds = reinterpret_cast<T *>(smem_raw);
 
@@ -223,6 +259,15 @@ sinkhorn_stream_kernel(GridParams p) {
     __syncthreads();
     const T *img_gt = lds;                                         // out = G^T in
     const T *img_g = SYM ? lds : lds + KP * KP;                    // out = G in
+    // small symmetric problems keep the whole operand image in registers (no LDS access in the loop)
+    constexpr int NA = RT * NREG * RT;
+    constexpr bool GREG = operands_in_regs<C, RT, SYM>();
+    AFromRegs<C, GREG ? NA : 1> areg;
+    if constexpr (GREG) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) areg.a[i] = lds[i * WAVE + lane];
+    }
+    const AFromImage<C> a_gt{img_gt, lane}, a_g{img_g, lane};
     const T *acc0 = lds + (SYM ? 1 : 2) * KP * KP;                 // G^T u0, u0 = 1/K (a new pair's first product)
 
     const int col = lane % TILE, grp = lane / TILE;
@@ -232,7 +277,7 @@ sinkhorn_stream_kernel(GridParams p) {
     const T uinit = T(1) / T(K);
     const T tau = T(p.tau);
     const T kk = T(K) * T(K);
-    const unsigned long long colmask = (TILE == 32) ? 0xffffffffull : 0xffffull;  // lanes of group 0
+    const unsigned long long colmask = (1ull << TILE) - 1ull;  // lanes of group 0
 
     acc_t A[RT], B[RT], U[RT], V[RT], ACC[RT];
     acc_t RU[TRACK ? RT : 1], RV[TRACK ? RT : 1];
@@ -295,9 +340,9 @@ sinkhorn_stream_kernel(GridParams p) {
                 T bnorm2 = T(0);
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
-                    load_regs<T>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
-                    load_regs<T>(pb + t * NGRP * NREG, B[t]);
-                    load_regs<T>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
+                    load_regs<C>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
+                    load_regs<C>(pb + t * NGRP * NREG, B[t]);
+                    load_regs<C>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
                         const T ui = (t == RT - 1) ? uinit - uinit * PADC[r] : uinit;   // 0 in padded slots
@@ -335,7 +380,8 @@ sinkhorn_stream_kernel(GridParams p) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) V[t][r] = B[t][r] * M::rcp(ACC[t][r]);
         // ---- u = a / (G v) ----------------------------------------------------------------------------
-        panel_product<T, RT>(img_g, V, ACC, K, lane, PADC);
+        if constexpr (GREG) panel_product<C, RT>(areg, V, ACC, K, PADC);
+        else panel_product<C, RT>(a_g, V, ACC, K, PADC);
         T mx = T(0);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -348,7 +394,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 if constexpr (TRACK) mx = fmax(fmax(mx, un * RU[t][r]), V[t][r] * RV[t][r]);
                 else mx = fmax(fmax(mx, un), V[t][r]);
             }
-        mx = group_max<T>(mx);
+        mx = group_max<C>(mx);
         const bool over = active && mx > tau;   // POT: max|u| > tau or max|v| > tau  ->  absorb
         if constexpr (TRACK) {
             if (over) {
@@ -382,7 +428,8 @@ sinkhorn_stream_kernel(GridParams p) {
         ++ii;   // ii updates of (v, u) are done for this column
 
         // ---- ACC = G^T u: feeds the stopping test of this update and the next v ----------------------
-        panel_product<T, RT>(img_gt, U, ACC, K, lane, PADC);
+        if constexpr (GREG) panel_product<C, RT>(areg, U, ACC, K, PADC);
+        else panel_product<C, RT>(a_gt, U, ACC, K, PADC);
 
         // ---- POT's stopping rule: the error of update ii-1 is evaluated when (ii-1) % period == 0 ---
         const bool pending = active && ii == chk;
@@ -401,7 +448,7 @@ sinkhorn_stream_kernel(GridParams p) {
                     else d = V[t][r] * ACC[t][r] - B[t][r];
                     e2 += d * d;
                 }
-            e2 = group_sum<T>(e2);
+            e2 = group_sum<C>(e2);
             const T e = sqrt(e2);
             bool fin = capped;
             if (pending) {
@@ -419,8 +466,8 @@ sinkhorn_stream_kernel(GridParams p) {
                 T *rec = scratch + (size_t)q * SCR;
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
-                    store_regs<T>(rec + (t * NGRP + grp) * NREG, U[t]);
-                    store_regs<T>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
+                    store_regs<C>(rec + (t * NGRP + grp) * NREG, U[t]);
+                    store_regs<C>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
                 }
                 if (grp == 0) {
                     rec[2 * KP] = scale;
@@ -436,13 +483,14 @@ sinkhorn_stream_kernel(GridParams p) {
 }
 
 // cost <Gamma, M> = u^T (G o M) v for every parked item (ot.sinkhorn2 returns sum(M * Gamma))
-template <typename T, int RT>
+template <class C, int RT>
 __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(GridParams p) {
-    using M = Mfma<T>;
+    using M = C;
+    using T = typename C::T;
     using acc_t = typename M::acc_t;
     constexpr int TILE = M::TILE, NREG = M::NREG, NGRP = M::NGRP;
     constexpr int KP = RT * TILE;
-    constexpr int SCR = scratch_stride<T>(RT);
+    constexpr int SCR = scratch_stride<C>(RT);
     const int n_items = p.n_pairs;
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     const int col = lane % TILE, grp = lane / TILE;
@@ -457,20 +505,20 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(Gri
         acc_t U[RT], V[RT], ACC[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            load_regs<T>(rec + (t * NGRP + grp) * NREG, U[t]);
-            load_regs<T>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
+            load_regs<C>(rec + (t * NGRP + grp) * NREG, U[t]);
+            load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
         }
         const T scale = rec[2 * KP];
         acc_t zero;
 #pragma unroll
         for (int r = 0; r < NREG; ++r) zero[r] = T(0);
-        panel_product<T, RT>(img_gm, V, ACC, p.K, lane, zero);
+        panel_product<C, RT>(AFromImage<C>{img_gm, lane}, V, ACC, p.K, zero);
         T val = T(0);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) val += U[t][r] * ACC[t][r];
-        val = group_sum<T>(val) * scale;
+        val = group_sum<C>(val) * scale;
         if (live && grp == 0) {
             p.emd[item] = double(val);
             if (val != val) p.flags[item] |= FLAG_NAN;
@@ -479,11 +527,12 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(Gri
 }
 
 // One-launch setup: Gibbs kernel images in MFMA operand order, first-product table, P converted to T.
-template <typename T>
+template <class C>
 __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, int RT, double reg,
-                                      T *__restrict__ img, const double *__restrict__ Psrc, T *__restrict__ Pdst,
-                                      long n_p) {
-    using M = Mfma<T>;
+                                      typename C::T *__restrict__ img, const double *__restrict__ Psrc,
+                                      typename C::T *__restrict__ Pdst, long n_p) {
+    using M = C;
+    using T = typename C::T;
     const int KP = RT * M::TILE;
     const int nimg = KP * KP;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
