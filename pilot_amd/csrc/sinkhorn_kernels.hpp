@@ -585,15 +585,24 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
 constexpr int ORDER_NB = 48;
 
 template <typename T>
-__global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int K, int n_items, int row_begin, int row_step,
+__global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int n_items, int row_begin, int row_step,
                                     unsigned char *__restrict__ bucket, int *__restrict__ hist) {
+    // Pt rows are KP long (multiple of 16, zero padded, slot order -- L1 is permutation invariant): 16-byte loads
+    using V = T __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int VE = 16 / sizeof(T);
     __shared__ int lh[ORDER_NB];
     for (int i = threadIdx.x; i < ORDER_NB; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_items; q += gridDim.x * blockDim.x) {
         const int i = row_begin + (q / N) * row_step, j = q % N;
+        const V *pa = reinterpret_cast<const V *>(Pt + (size_t)i * KP);
+        const V *pb = reinterpret_cast<const V *>(Pt + (size_t)j * KP);
         float l1 = 0.f;
-        for (int k = 0; k < K; ++k) l1 += fabsf(float(Pt[(size_t)i * K + k]) - float(Pt[(size_t)j * K + k]));
+        for (int k = 0; k < KP / VE; ++k) {
+            const V a = pa[k], b = pb[k];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) l1 += fabsf(float(a[e]) - float(b[e]));
+        }
         int b = ORDER_NB - 1;
         if (l1 > 0.f) {
             const float v = 4.f * (1.f - log2f(l1));      // l1 = 2 -> 0, halves add 4
