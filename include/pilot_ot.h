@@ -76,6 +76,21 @@ int pilot_ot_memcpy_h2d(void *dst, const void *src, unsigned long long bytes);
 int pilot_ot_memcpy_d2h(void *dst, const void *src, unsigned long long bytes);
 int pilot_ot_stream_sync(void *stream);
 
+/* ---- pre-pass: replaces the pandas loops of Cluster_Representations and cost_matrix ---------- */
+/* cell_code / sample_code: per cell, index of its cell type / sample in FIRST-APPEARANCE order
+ * (what Series.unique() yields, Trajectory.py:402,412); negative codes (missing values) are skipped.
+ * n_total = len(df) (the prior's denominator is n_total - 1, Trajectory.py:407).
+ * P: N x K fp64, bit-identical to the reference's dict values (every fp64 operation in the same order). */
+int pilot_ot_proportions(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
+                         int N, int K, double regulizer, int normalization, double *P);
+/* Per-cell-type column-wise median of the n_cells x D embedding X (Trajectory.py:465-466), exact.
+ * dtype: 0 = float32, 1 = float64 (the median of an even count is averaged in that dtype, like
+ * numpy/pandas, then widened).  centroids: K x D fp64; a cell type without cells yields NaN. */
+#define PILOT_OT_F32 0
+#define PILOT_OT_F64 1
+int pilot_ot_centroid_medians(const void *X, int dtype, long long n_cells, int D, const int *cell_code, int K,
+                              double *centroids);
+
 /* ---- cost matrix: replaces scipy pdist+squareform at Trajectory.py:468-469 ------------------ */
 /* centroids: K x D row-major (per-cell-type medians, Trajectory.py:465-466).  cost: K x K,
  * symmetric, zero diagonal, NOT normalised (the reference stores the raw matrix, :98-99). */

@@ -14,6 +14,7 @@
 #include "../../include/pilot_ot.h"
 #include "sinkhorn_kernels.hpp"
 #include "emd_kernels.hpp"
+#include "prepass_kernels.hpp"
 
 #define PILOT_API extern "C" __attribute__((visibility("default")))
 
@@ -687,4 +688,115 @@ PILOT_API int pilot_ot_plan_kernel_times(pilot_ot_plan *pl, int max_n, float *ma
     }
     *n_out = (int)n;
     return PILOT_OT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pre-pass (host-buffer entry points; the inputs are read once, so they are staged per call)
+namespace {
+struct DevBuf {   // RAII for the temporaries of one host call
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+int grid_for(long n, int block, int n_cu) {
+    long g = (n + block - 1) / block;
+    const long cap = (long)n_cu * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+int current_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+}  // namespace
+
+PILOT_API int pilot_ot_proportions(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
+                                   int N, int K, double regulizer, int normalization, double *P) {
+    if (!cell_code || !sample_code || !P) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (N <= 0 || K <= 0 || n_cells < 0 || n_total < 2)
+        return fail(PILOT_OT_EINVAL, "N=%d K=%d n_cells=%lld n_total=%lld out of range", N, K, n_cells, n_total);
+    if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
+    DevBuf dc, ds, dcnt, dP;
+    hipError_t e = dc.alloc(sizeof(int) * (size_t)n_cells);
+    if (e == hipSuccess) e = ds.alloc(sizeof(int) * (size_t)n_cells);
+    if (e == hipSuccess) e = dcnt.alloc(sizeof(unsigned int) * (size_t)N * K);
+    if (e == hipSuccess) e = dP.alloc(sizeof(double) * (size_t)N * K);
+    if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ds.p, sample_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dcnt.p, 0, sizeof(unsigned int) * (size_t)N * K);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    const int n_cu = current_cu_count();
+    hipLaunchKernelGGL(pilot::count_kernel, dim3(grid_for(n_cells, 256, n_cu)), dim3(256), 0, nullptr, dc.as<int>(),
+                       ds.as<int>(), (long)n_cells, K, dcnt.as<unsigned int>());
+    hipLaunchKernelGGL(pilot::proportions_kernel, dim3(1), dim3(256), sizeof(double) * (K + 1), nullptr,
+                       dcnt.as<unsigned int>(), N, K, (long)n_total, regulizer, normalization, dP.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(P, dP.p, sizeof(double) * (size_t)N * K, hipMemcpyDeviceToHost));
+    return PILOT_OT_OK;
+}
+
+namespace {
+template <typename T>
+int centroid_medians_impl(const void *X, long long C, int D, const int *cell_code, int K, double *centroids) {
+    using U = typename pilot::OrderedKey<T>::U;
+    using State = pilot::SelectState<U>;
+    const size_t lds = sizeof(unsigned int) * (size_t)D * 2 * 256;
+    if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "D=%d embedding dimensions need %zu B of LDS (> %zu)", D, lds, LDS_BYTES);
+    DevBuf dX, dc, dn, doffs, dcur, dperm, dst, dh, dout;
+    hipError_t e = dX.alloc(sizeof(T) * (size_t)C * D);
+    if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
+    if (e == hipSuccess) e = dn.alloc(sizeof(unsigned int) * K);
+    if (e == hipSuccess) e = doffs.alloc(sizeof(unsigned int) * (K + 1));
+    if (e == hipSuccess) e = dcur.alloc(sizeof(unsigned int) * K);
+    if (e == hipSuccess) e = dperm.alloc(sizeof(unsigned int) * (size_t)C);
+    if (e == hipSuccess) e = dst.alloc(sizeof(State) * (size_t)K * D * 2);
+    if (e == hipSuccess) e = dh.alloc(sizeof(unsigned int) * (size_t)K * D * 2 * 256);
+    if (e == hipSuccess) e = dout.alloc(sizeof(double) * (size_t)K * D);
+    if (e == hipSuccess) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dn.p, 0, sizeof(unsigned int) * K);
+    if (e == hipSuccess) e = hipMemset(dcur.p, 0, sizeof(unsigned int) * K);
+    if (e == hipSuccess) e = hipMemset(dh.p, 0, sizeof(unsigned int) * (size_t)K * D * 2 * 256);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    const int n_cu = current_cu_count();
+    const int gc = grid_for(C, 256, n_cu);
+    hipLaunchKernelGGL(pilot::type_count_kernel, dim3(gc), dim3(256), 0, nullptr, dc.as<int>(), (long)C, K, dn.as<unsigned int>());
+    hipLaunchKernelGGL(pilot::type_offsets_kernel, dim3(1), dim3(64), 0, nullptr, dn.as<unsigned int>(), K, doffs.as<unsigned int>());
+    hipLaunchKernelGGL(pilot::type_scatter_kernel, dim3(gc), dim3(256), 0, nullptr, dc.as<int>(), (long)C, K,
+                       doffs.as<unsigned int>(), dcur.as<unsigned int>(), dperm.as<unsigned int>());
+    const int nq = K * D * 2;
+    hipLaunchKernelGGL(pilot::select_init_kernel<T>, dim3((nq + 255) / 256), dim3(256), 0, nullptr, dn.as<unsigned int>(), K, D,
+                       dst.as<State>());
+    // enough workgroups per cell type to fill the chip, at most one per ~2048 rows
+    long splits = (2L * n_cu + K - 1) / K;
+    const long max_splits = (C / K) / 2048 + 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::select_hist_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int shift = pilot::OrderedKey<T>::BITS - 8; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)splits, (unsigned)K), dim3(256), lds, nullptr,
+                           static_cast<const T *>(dX.p), D, dperm.as<unsigned int>(), doffs.as<unsigned int>(), shift,
+                           dst.as<State>(), dh.as<unsigned int>());
+        hipLaunchKernelGGL(pilot::select_pick_kernel<T>, dim3((nq + 255) / 256), dim3(256), 0, nullptr, K, D, shift,
+                           dst.as<State>(), dh.as<unsigned int>());
+    }
+    hipLaunchKernelGGL(pilot::select_finish_kernel<T>, dim3((K * D + 255) / 256), dim3(256), 0, nullptr, dn.as<unsigned int>(), K, D,
+                       dst.as<State>(), dout.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(centroids, dout.p, sizeof(double) * (size_t)K * D, hipMemcpyDeviceToHost));
+    return PILOT_OT_OK;
+}
+}  // namespace
+
+PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_cells, int D, const int *cell_code, int K,
+                                        double *centroids) {
+    if (!X || !cell_code || !centroids) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (n_cells <= 0 || D <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "n_cells=%lld D=%d K=%d must be positive", n_cells, D, K);
+    if (n_cells > 0xffffffffLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", n_cells);
+    if (dtype == PILOT_OT_F32) return centroid_medians_impl<float>(X, n_cells, D, cell_code, K, centroids);
+    if (dtype == PILOT_OT_F64) return centroid_medians_impl<double>(X, n_cells, D, cell_code, K, centroids);
+    return fail(PILOT_OT_EINVAL, "unknown dtype id %d", dtype);
 }

@@ -79,6 +79,42 @@ def pdist_square(centroids, metric="cosine"):
     return out
 
 
+def proportions(cell_code, sample_code, n_samples, n_types, regulizer=0.2, normalization=True, n_total=None):
+    """N x K smoothed cell-type proportions from per-cell integer codes (device histogram; replaces the pandas
+    loops of Cluster_Representations, pilotpy/tools/Trajectory.py:400-430).  Bit-identical to the reference."""
+    cc = np.ascontiguousarray(cell_code, dtype=np.int32)
+    sc = np.ascontiguousarray(sample_code, dtype=np.int32)
+    if cc.shape != sc.shape or cc.ndim != 1:
+        raise ValueError("cell_code and sample_code must be 1-D arrays of equal length")
+    n_total = cc.size if n_total is None else int(n_total)
+    P = np.zeros((n_samples, n_types), dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_proportions(_lib.iptr(cc), _lib.iptr(sc), cc.size, n_total, int(n_samples),
+                                                int(n_types), float(regulizer), int(bool(normalization)), _lib.dptr(P)))
+    return P
+
+
+def centroid_medians(X, cell_code, n_types):
+    """K x D per-cell-type column-wise medians of the C x D embedding (device radix select; replaces
+    ``data[annot.cell_type == k].median(axis=0)``, pilotpy/tools/Trajectory.py:465-466).  float32 / float64 input is
+    processed in its own dtype, like pandas."""
+    X = np.asarray(X)
+    if X.ndim != 2:
+        raise ValueError("X must be 2-D (cells, dims)")
+    if X.dtype == np.float32:
+        dt = 0
+    else:
+        X = X.astype(np.float64, copy=False)
+        dt = 1
+    X = np.ascontiguousarray(X)
+    cc = np.ascontiguousarray(cell_code, dtype=np.int32)
+    if cc.shape != (X.shape[0],):
+        raise ValueError("cell_code must have one entry per row of X")
+    out = np.zeros((int(n_types), X.shape[1]), dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_centroid_medians(ctypes.c_void_p(X.ctypes.data), dt, X.shape[0], X.shape[1],
+                                                     _lib.iptr(cc), int(n_types), _lib.dptr(out)))
+    return out
+
+
 class DevicePlan:
     """Device-resident pair-grid problem: P, M and the outputs live in HBM across calls.
 

@@ -89,45 +89,22 @@ def Cluster_Representations(df, cell_col=0, sample_col=1, regulizer=0.2, normali
     Returns an insertion-ordered dict ``{sampleID: float64[K]}``: samples and cell types in
     first-appearance order (``.unique()``, :402/:412); prior_k = regulizer * n_k / (C - 1)
     (:405-409, note C - 1); with ``normalization`` p = (counts + prior) / (sum counts + sum prior)
-    (:428-430).  One vectorised histogram instead of the reference's per-sample pandas masks.
+    (:428-430).  The host only factorises the two label columns into integer codes; the histogram and
+    the smoothing run on the device (``engine.proportions``) and are bit-identical to the reference.
     """
     cell_col = df.columns[cell_col]
     sample_col = df.columns[sample_col]
     ccodes, cells = _first_appearance_codes(df[cell_col])
     scodes, samples = _first_appearance_codes(df[sample_col])
     K, N = len(cells), len(samples)
-    # the reference counts n_k in the column literally named 'cell_type' (:403-407)
-    n_by_name = df["cell_type"].value_counts(sort=False)
-    prior = np.ones(len(df["cell_type"].unique()))
-    for k, cell in enumerate(cells):
-        prior[k] = int(n_by_name.get(cell, 0)) / (len(df) - 1)
-    prior = prior * regulizer
-    ok = (ccodes >= 0) & (scodes >= 0)
-    counts = np.bincount(scodes[ok].astype(np.int64) * K + ccodes[ok], minlength=N * K)
-    counts = counts.reshape(N, K).astype(np.float64)
-    out = {}
-    if normalization:
-        sum_prior = sum(prior)            # Python sum, left to right, like the reference
-        for n in range(N):
-            out[samples[n]] = (counts[n] + prior) / (sum(counts[n]) + sum_prior)
-    else:
-        for n in range(N):
-            out[samples[n]] = counts[n].copy()
-    return out
-
-
-def _centroid_medians(data, codes, K):
-    """Column-wise median of the rows of each cell type, in the frame's own dtype (:465-466)."""
-    X = data.to_numpy() if isinstance(data, pd.DataFrame) else np.asarray(data)
-    order = np.argsort(codes, kind="stable")
-    sorted_codes = codes[order]
-    starts = np.searchsorted(sorted_codes, np.arange(K), side="left")
-    ends = np.searchsorted(sorted_codes, np.arange(K), side="right")
-    cent = np.empty((K, X.shape[1]), dtype=np.float64)
-    for k in range(K):
-        rows = X[order[starts[k]:ends[k]]]
-        cent[k] = np.median(rows, axis=0) if rows.shape[0] else np.nan
-    return cent
+    if str(cell_col) != "cell_type":
+        # the reference counts n_k in the column literally named 'cell_type' (:403-407); with a different
+        # cell_col the two must at least label the same partition
+        other, _ = _first_appearance_codes(df["cell_type"])
+        if not np.array_equal(other, ccodes):
+            raise NotImplementedError("Cluster_Representations: cell_col differs from the 'cell_type' column")
+    P = engine.proportions(ccodes, scodes, N, K, regulizer=regulizer, normalization=normalization, n_total=len(df))
+    return {samples[n]: P[n].copy() for n in range(N)}
 
 
 def cost_matrix(annot, data, metric="cosine"):
@@ -135,7 +112,8 @@ def cost_matrix(annot, data, metric="cosine"):
     centroids, pairwise ``metric`` distance (device kernel; scipy ``pdist`` names), returned as
     ``(ndarray K x K, DataFrame indexed 'cell_types')``.  NOT normalised (the caller divides by max)."""
     codes, cells = _first_appearance_codes(annot[annot.columns[0]])
-    centroids = _centroid_medians(data, codes, len(cells))
+    X = data.to_numpy() if isinstance(data, pd.DataFrame) else np.asarray(data)
+    centroids = engine.centroid_medians(X, codes, len(cells))
     dis = engine.pdist_square(centroids, metric=metric)
     cost = pd.DataFrame.from_dict(dis).T
     names = annot.cell_type.unique()

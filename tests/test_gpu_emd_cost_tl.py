@@ -67,6 +67,71 @@ def test_emd_golden(name):
     assert np.abs(E - g["emd_unreg"]).max() <= 1e-12
 
 
+# ------------------------------------------------------------------------------- pre-pass (histogram, medians)
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("categorical", [False, True])
+def test_cluster_representations_bit_exact_vs_reference(name, categorical):
+    g = load_golden(name)
+    ad, cell_col = golden_adata(g, categorical=categorical)
+    annot = ad.obs[[cell_col, "sampleID", "status"]].copy()
+    annot.columns = ["cell_type", "sampleID", "status"]
+    rep = tl.Cluster_Representations(annot, regulizer=0.2, normalization=True)
+    assert isinstance(rep, dict) and [str(k) for k in rep.keys()] == list(g["samples"])
+    got = np.stack(list(rep.values()))
+    assert got.dtype == np.float64
+    np.testing.assert_array_equal(got, g["proportions"])           # bit-exact with the reference's output
+    for regulizer in (1.0, 0.05):
+        rep = tl.Cluster_Representations(annot, regulizer=regulizer)
+        ora, _ = O.cluster_representations(annot["cell_type"], annot["sampleID"], regulizer=regulizer)
+        for k in rep:
+            np.testing.assert_array_equal(rep[k], ora[k])
+    raw = tl.Cluster_Representations(annot, normalization=False)
+    ora, _ = O.cluster_representations(annot["cell_type"], annot["sampleID"], normalization=False)
+    for k in raw:
+        np.testing.assert_array_equal(raw[k], ora[k])
+
+
+def test_proportions_kernel_large_and_ragged():
+    rng = np.random.default_rng(0)
+    C, N, K = 300_000, 97, 41
+    cc = rng.integers(0, K, C).astype(np.int32); sc = rng.integers(0, N, C).astype(np.int32)
+    cc[rng.random(C) < 0.01] = -1                                   # missing labels are skipped
+    P = engine.proportions(cc, sc, N, K, regulizer=0.2, n_total=C)
+    ok = cc >= 0
+    counts = np.bincount(sc[ok].astype(np.int64) * K + cc[ok], minlength=N * K).reshape(N, K).astype(np.float64)
+    prior = counts.sum(0) / (C - 1) * 0.2
+    want = np.stack([(counts[n] + prior) / (sum(counts[n]) + sum(prior)) for n in range(N)])
+    np.testing.assert_array_equal(P, want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("C,D,K", [(1, 1, 1), (7, 3, 2), (1000, 30, 50), (4097, 65, 3), (200_000, 30, 50)])
+def test_centroid_medians_exact(dtype, C, D, K):
+    rng = np.random.default_rng(C + D + K)
+    X = (rng.standard_normal((C, D)) * 10).astype(dtype)
+    X[rng.random((C, D)) < 0.05] = 0.0                               # ties, signed zeros
+    X[rng.random((C, D)) < 0.02] *= -0.0
+    cc = rng.integers(0, K, C).astype(np.int32)
+    got = engine.centroid_medians(X, cc, K)
+    for k in range(K):
+        rows = X[cc == k]
+        if len(rows) == 0:
+            assert np.isnan(got[k]).all()
+        else:
+            np.testing.assert_array_equal(got[k], np.median(rows, axis=0).astype(np.float64))   # median in X's dtype
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_centroid_medians_match_the_reference_pandas_medians(name):
+    g = load_golden(name)
+    ad, cell_col = golden_adata(g)
+    codes, cells = tl._first_appearance_codes(ad.obs[cell_col])
+    X = ad.X if str(g["data_type"]) != "scRNA" else ad.obsm["X_pca"]
+    got = engine.centroid_medians(X, codes, len(cells))
+    _, ora_cent, _ = O.cost_matrix(X, ad.obs[cell_col])
+    np.testing.assert_array_equal(got, ora_cent)
+
+
 # ------------------------------------------------------------------------------- cost matrix
 @pytest.mark.parametrize("metric", ["cosine", "euclidean", "sqeuclidean", "cityblock", "chebyshev", "correlation"])
 @pytest.mark.parametrize("K,D", [(2, 3), (50, 30), (100, 50), (130, 7)])
