@@ -92,17 +92,47 @@ __host__ __device__ constexpr int img_index(int RT, int tp, int r, int t, int la
 // per-item scratch record: u panel, v panel (KP values each, [tile][group][reg] order), then 4 extras
 template <class C> __host__ __device__ constexpr int scratch_stride(int RT) { return 2 * RT * C::TILE + 4; }
 
+// Cross-lane exchanges between the lane groups of a column (lanes l, l^16, l^32, l^48) with gfx950's
+// v_permlane32_swap / v_permlane16_swap: VALU-rate, no LDS crossbar round trip (ds_bpermute costs ~100+ cycles of
+// latency per hop, twice per reduction, in the serial part of every update).
+// permlane32_swap(v, v) returns {lower half kept, upper half := v's lower half} and {lower := v's upper half, upper
+// kept}; adding the two gives v[l] + v[l^32] in every lane.  permlane16_swap does the same for odd/even 16-lane rows.
+__device__ inline float sum_xor32(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float sum_xor16(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline double sum_xor32(double x) {
+    union { double d; unsigned int u[2]; } v, a, b;
+    v.d = x;
+    auto lo = __builtin_amdgcn_permlane32_swap(v.u[0], v.u[0], false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(v.u[1], v.u[1], false, false);
+    a.u[0] = lo[0]; a.u[1] = hi[0]; b.u[0] = lo[1]; b.u[1] = hi[1];
+    return a.d + b.d;
+}
+__device__ inline double sum_xor16(double x) {
+    union { double d; unsigned int u[2]; } v, a, b;
+    v.d = x;
+    auto lo = __builtin_amdgcn_permlane16_swap(v.u[0], v.u[0], false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(v.u[1], v.u[1], false, false);
+    a.u[0] = lo[0]; a.u[1] = hi[0]; b.u[0] = lo[1]; b.u[1] = hi[1];
+    return a.d + b.d;
+}
 template <class C> __device__ inline typename C::T group_sum(typename C::T x) {
-    // sum over the lane groups that hold the same column (lane % TILE)
-    if constexpr (C::NGRP == 4) x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
+    // sum over the lane groups that hold the same column (lane % TILE); every lane of the column gets the total
+    x = sum_xor32(x);
+    if constexpr (C::NGRP == 4) x = sum_xor16(x);
     return x;
 }
-template <class C> __device__ inline typename C::T group_max(typename C::T x) {
-    using T = typename C::T;
-    if constexpr (C::NGRP == 4) { T y = __shfl_xor(x, 16); x = x > y ? x : y; }
-    T y = __shfl_xor(x, 32);
-    return x > y ? x : y;
+// "does any lane of my column satisfy pred": one ballot + scalar folds, no cross-lane data movement
+template <class C> __device__ inline unsigned long long column_any_mask(bool pred) {
+    const unsigned long long m = __ballot(pred);
+    unsigned long long f = m | (m >> 32);
+    if constexpr (C::NGRP == 4) f |= f >> 16;
+    return f & ((1ull << C::TILE) - 1ull);
 }
 template <typename T> __device__ inline T abs_t(T x) { return x < T(0) ? -x : x; }
 
@@ -352,8 +382,8 @@ sinkhorn_stream_kernel(GridParams p) {
                         if constexpr (TRACK) { RU[t][r] = T(1); RV[t][r] = T(1); }
                     }
                 }
-                bnorm2 = bnorm2 + __shfl_xor(bnorm2, 32);
-                if constexpr (NGRP == 4) bnorm2 = bnorm2 + __shfl_xor(bnorm2, 16);
+                bnorm2 = sum_xor32(bnorm2);
+                if constexpr (NGRP == 4) bnorm2 = sum_xor16(bnorm2);
                 thr = T(p.stop_thr);
                 if constexpr (sizeof(T) == 4) {
                     const T fl = T(p.floor_ulps) * M::eps() * sqrtf(bnorm2);
@@ -394,8 +424,9 @@ sinkhorn_stream_kernel(GridParams p) {
                 if constexpr (TRACK) mx = fmax(fmax(mx, un * RU[t][r]), V[t][r] * RV[t][r]);
                 else mx = fmax(fmax(mx, un), V[t][r]);
             }
-        mx = group_max<C>(mx);
-        const bool over = active && mx > tau;   // POT: max|u| > tau or max|v| > tau  ->  absorb
+        // POT: max|u| > tau or max|v| > tau  ->  absorb.  "any lane of the column over tau" == "column max over tau"
+        const unsigned long long omask = column_any_mask<C>(active && mx > tau);
+        const bool over = (omask >> col) & 1ull;
         if constexpr (TRACK) {
             if (over) {
                 // POT: alpha += reg log u, beta += reg log v, u = v = 1/K.  In total-scaling terms
@@ -413,7 +444,6 @@ sinkhorn_stream_kernel(GridParams p) {
             }
         } else {
             // hand the pair to the tracking kernel (it restarts the pair from scratch)
-            const unsigned long long omask = __ballot(over) & colmask;
             if (omask) {
                 int base = 0;
                 if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(omask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
