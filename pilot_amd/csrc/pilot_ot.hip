@@ -12,7 +12,7 @@
 #include <new>
 
 #include "../../include/pilot_ot.h"
-#include "sinkhorn_kernels.hpp"
+#include "sinkhorn_launch.hpp"
 #include "emd_kernels.hpp"
 #include "prepass_kernels.hpp"
 
@@ -101,80 +101,6 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
         C[(size_t)i * K + j] = out;
         C[(size_t)j * K + i] = out;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-template <class C, int RT, bool SYM, bool TRACK>
-hipError_t launch_one(dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
-    auto kern = pilot::sinkhorn_stream_kernel<C, RT, SYM, TRACK>;
-    if (lds > 32 * 1024) {  // beyond the default dynamic-LDS window the limit must be raised explicitly
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(pilot::WAVE * pilot::WAVES_PER_WG), lds, s, p);
-    return hipGetLastError();
-}
-
-template <class C, int RT>
-hipError_t launch_rt(bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
-    if (sym) return track ? launch_one<C, RT, true, true>(grid, lds, s, p) : launch_one<C, RT, true, false>(grid, lds, s, p);
-    return track ? launch_one<C, RT, false, true>(grid, lds, s, p) : launch_one<C, RT, false, false>(grid, lds, s, p);
-}
-
-template <class C>
-hipError_t launch_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const pilot::GridParams &p) {
-    switch (RT) {
-    case 1: return launch_rt<C, 1>(sym, track, grid, lds, s, p);
-    case 2: return launch_rt<C, 2>(sym, track, grid, lds, s, p);
-    case 3: return launch_rt<C, 3>(sym, track, grid, lds, s, p);
-    case 4: return launch_rt<C, 4>(sym, track, grid, lds, s, p);
-    default: break;
-    }
-    if constexpr (C::TILE == 16) {
-        switch (RT) {
-        case 5: return launch_rt<C, 5>(sym, track, grid, lds, s, p);
-        case 6: return launch_rt<C, 6>(sym, track, grid, lds, s, p);
-        case 7: return launch_rt<C, 7>(sym, track, grid, lds, s, p);
-        case 8: return launch_rt<C, 8>(sym, track, grid, lds, s, p);
-        default: break;
-        }
-    }
-    return hipErrorInvalidValue;
-}
-
-template <class C, int RT> hipError_t launch_value_rt(dim3 grid, hipStream_t s, const pilot::GridParams &p) {
-    hipLaunchKernelGGL((pilot::sinkhorn_value_kernel<C, RT>), grid, dim3(pilot::WAVE * pilot::WAVES_PER_WG), 0, s, p);
-    return hipGetLastError();
-}
-template <class C> hipError_t launch_value(int RT, dim3 grid, hipStream_t s, const pilot::GridParams &p) {
-    switch (RT) {
-    case 1: return launch_value_rt<C, 1>(grid, s, p);
-    case 2: return launch_value_rt<C, 2>(grid, s, p);
-    case 3: return launch_value_rt<C, 3>(grid, s, p);
-    case 4: return launch_value_rt<C, 4>(grid, s, p);
-    default: break;
-    }
-    if constexpr (C::TILE == 16) {
-        switch (RT) {
-        case 5: return launch_value_rt<C, 5>(grid, s, p);
-        case 6: return launch_value_rt<C, 6>(grid, s, p);
-        case 7: return launch_value_rt<C, 7>(grid, s, p);
-        case 8: return launch_value_rt<C, 8>(grid, s, p);
-        default: break;
-        }
-    }
-    return hipErrorInvalidValue;
-}
-// workgroups of the persistent stream kernel resident per CU (register file and LDS both bound it)
-template <class C> int stream_wgs_per_cu(int RT, bool sym, bool track, size_t lds) {
-    const int w = int(sizeof(typename C::T) / 4);
-    const int na = RT * C::NREG * RT * w;
-    const int regs = (track ? 7 : 5) * RT * C::NREG * w + C::NREG * w + 56 + ((sym && na <= 64) ? na : 0);
-    int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));   // mirrors pilot::min_waves_per_simd
-    const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
-    if (by_lds < occ) occ = by_lds;
-    return occ < 1 ? 1 : occ;
 }
 
 constexpr int MAX_K = 128;
@@ -372,34 +298,45 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     return PILOT_OT_OK;
 }
 
-template <class C>
-int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
+// resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
+int stream_wgs_per_cu(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, size_t lds) {
+    const int na = RT * 4 * RT * w;
+    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + ((sym && na <= 64) ? na : 0);
+    int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
+    const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+    if (by_lds < occ) occ = by_lds;
+    return occ < 1 ? 1 : occ;
+}
+
+// cfg: pilot::CFG_F32 / CFG_F64 (both 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
+int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
              double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
              int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s) {
-    using M = C;
-    using T = typename C::T;
+    const bool f32 = cfg == pilot::CFG_F32;
+    const size_t ts = f32 ? sizeof(float) : sizeof(double);
+    const int w = (int)(ts / 4);
+    constexpr int TILE = 16;
     const int N = pl->N, K = pl->K;
-    const int RT = (K + M::TILE - 1) / M::TILE;
-    const int KP = RT * M::TILE;
-    size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * sizeof(T);
-    if (lds + (size_t)KP * sizeof(T) > LDS_BYTES)
-        return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision",
-                    K, lds + (size_t)KP * sizeof(T), LDS_BYTES);
+    const int RT = (K + TILE - 1) / TILE;
+    const int KP = RT * TILE;
+    size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * ts + (size_t)KP * ts;   // operand image(s) + first-product table
+    if (lds > LDS_BYTES)
+        return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision", K, lds,
+                    LDS_BYTES);
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, 4 * sizeof(int), s));
-    T *img = static_cast<T *>(pl->img);
-    T *Pt = static_cast<T *>(pl->p_slot);
-    hipLaunchKernelGGL(pilot::sinkhorn_setup_kernel<C>, dim3(64), dim3(256), 0, s, d_M, K, RT, reg, img, d_P, Pt,
-                       (long)N * KP);
-    HIP_TRY(hipGetLastError());
+    void *img = pl->img;
+    void *Pt = pl->p_slot;
+    HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, s)
+                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, s));
     if (n_rows == 0) return PILOT_OT_OK;
 
     const int n_pairs = n_rows * N;
     // device workspace that scales with the number of pairs: grown on demand (first call at a new size
     // allocates; later calls at the same or a smaller size do not, so they stay graph-capturable)
-    const size_t scr_bytes = (size_t)n_pairs * pilot::scratch_stride<C>(RT) * sizeof(T);
+    const size_t scr_bytes = (size_t)n_pairs * (2 * KP + 4) * ts;
     if (scr_bytes > pl->scratch_bytes) {
         if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
-    pl->scratch = nullptr; pl->scratch_bytes = 0;
+        pl->scratch = nullptr; pl->scratch_bytes = 0;
         HIP_TRY(hipMalloc(&pl->scratch, scr_bytes));
         pl->scratch_bytes = scr_bytes;
     }
@@ -426,40 +363,48 @@ int run_grid(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
         const char *dbg = getenv("PILOT_OT_DEBUG");
         p.debug = dbg ? atoi(dbg) : 0;
     }
-    lds += (size_t)KP * sizeof(T);   // first-product table next to the operand image(s)
-    const int tiles = (n_pairs + M::TILE - 1) / M::TILE;
-    const int wgs_needed = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
-    int occ_main = stream_wgs_per_cu<C>(RT, sym, false, lds);
-    if ((p.debug >> 4) & 7) occ_main = (p.debug >> 4) & 7;   // experiment: override resident workgroups per CU
-    int wgs = pl->n_cu * occ_main;
-    if (wgs > wgs_needed) wgs = wgs_needed;
+    const int tiles = (n_pairs + TILE - 1) / TILE;
     // longest-first work order (see order_bucket_kernel)
     if (!(p.debug & 2)) {
         HIP_TRY(hipMemsetAsync(pl->order_hist, 0, sizeof(int) * 2 * pilot::ORDER_NB, s));
         int ob = (n_pairs + 255) / 256;
         if (ob > pl->n_cu * 8) ob = pl->n_cu * 8;
-        hipLaunchKernelGGL((pilot::order_bucket_kernel<T>), dim3(ob), dim3(256), 0, s, static_cast<const T *>(Pt), N, KP,
-                           n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist);
-        hipLaunchKernelGGL(pilot::order_scatter_kernel, dim3(ob), dim3(256), 0, s, pl->order_bucket, n_pairs,
-                           pl->order_hist, pl->order_hist + pilot::ORDER_NB, pl->order_list);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(f32 ? pilot::launch_order_f32(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
+                                              pl->order_list, ob, s)
+                    : pilot::launch_order_f64(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
+                                              pl->order_list, ob, s));
         p.list = pl->order_list;
     }
     hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    HIP_TRY((launch_any<C>(RT, sym, false, dim3(wgs), lds, s, p)));
+    // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
+    {
+        int wgs = pl->n_cu * stream_wgs_per_cu(w, RT, sym, false, lds);
+        if ((p.debug >> 4) & 7) wgs = pl->n_cu * ((p.debug >> 4) & 7);   // experiment: resident workgroups per CU
+        const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+        if (wgs > need) wgs = need;
+        HIP_TRY(f32 ? pilot::launch_stream_f32(RT, sym, false, dim3(wgs), lds, s, p)
+                    : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p));
+    }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
-    int wgs_t = pl->n_cu * stream_wgs_per_cu<C>(RT, sym, true, lds);
-    if (wgs_t > wgs_needed) wgs_t = wgs_needed;
-    HIP_TRY((launch_any<C>(RT, sym, true, dim3(wgs_t), lds, s, p)));
+    {
+        int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, lds);
+        const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+        if (wgs_t > need) wgs_t = need;
+        HIP_TRY(f32 ? pilot::launch_stream_f32(RT, sym, true, dim3(wgs_t), lds, s, p)
+                    : pilot::launch_stream_f64(RT, sym, true, dim3(wgs_t), lds, s, p));
+    }
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
     // third pass: cost <Gamma, M> of every pair from its parked scalings
     p.list = nullptr; p.list_len = nullptr;
-    int wgs_v = pl->n_cu * 8;
-    if (wgs_v > wgs_needed) wgs_v = wgs_needed;
-    HIP_TRY((launch_value<C>(RT, dim3(wgs_v), s, p)));
+    {
+        int wgs_v = pl->n_cu * 8;
+        const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+        if (wgs_v > need) wgs_v = need;
+        HIP_TRY(f32 ? pilot::launch_value_f32(RT, dim3(wgs_v), s, p) : pilot::launch_value_f64(RT, dim3(wgs_v), s, p));
+    }
     return PILOT_OT_OK;
 }
 
@@ -478,20 +423,9 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (precision == PILOT_OT_PREC_F32) {
-        // 16-pair waves (v_mfma_f32_16x16x4_f32) beat 32-pair waves (v_mfma_f32_32x32x2_f32) at every measured
-        // shape: finer row padding (K=50 -> 64 either way, K=100 -> 112 vs 128), 2-4 waves per SIMD instead of 1-2,
-        // finer work quantum.  The 32-wide form stays selectable for A/B runs (PILOT_OT_DEBUG bit 2).
-        const char *dbg = getenv("PILOT_OT_DEBUG");
-        if (!(dbg && (atoi(dbg) & 4)))
-            return run_grid<pilot::CfgF32x16>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period,
-                                              f32_floor_ulps, cost_is_symmetric != 0, row_begin, n_rows, row_step,
-                                              d_emd, d_iters, d_err, d_flags, s);
-        return run_grid<pilot::CfgF32x32>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
-                               cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
-    }
-    return run_grid<pilot::CfgF64x16>(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps,
-                            cost_is_symmetric != 0, row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, s);
+    return run_grid(precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : pilot::CFG_F64, pl, d_P, d_M, reg, num_iter_max,
+                    stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0, row_begin, n_rows, row_step,
+                    d_emd, d_iters, d_err, d_flags, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -649,7 +649,7 @@ __global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int
 // Every workgroup owns a contiguous chunk of items: LDS histogram of the chunk, ONE global atomic per
 // (workgroup, bucket) to reserve the range, then LDS cursors -- a handful of hot global addresses would
 // otherwise serialise all N^2 atomics.
-__global__ void order_scatter_kernel(const unsigned char *__restrict__ bucket, int n_items, const int *__restrict__ hist,
+static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bucket, int n_items, const int *__restrict__ hist,
                                      int *__restrict__ cursor, int *__restrict__ list) {
     __shared__ int offs[ORDER_NB], lh[ORDER_NB], lbase[ORDER_NB];
     if (threadIdx.x < ORDER_NB) lh[threadIdx.x] = 0;

@@ -1,0 +1,24 @@
+// Launch entry points of the Sinkhorn kernels.  The template instantiations are spread over several translation
+// units (sk_inst.hip compiled with -DSK_PART=0 for f32, 1 for f64) so that `make -j` builds them in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sinkhorn_kernels.hpp"
+
+namespace pilot {
+
+enum { CFG_F32 = 0, CFG_F64 = 1 };   // CfgF32x16, CfgF64x16
+
+// persistent stream kernel (one tile per wave); track: tau-tracking variant
+hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+// helpers
+hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p);
+hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p);
+hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s);
+hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s);
+hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
+                            int *hist, int *list, int n_blocks, hipStream_t s);
+hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
+                            int *hist, int *list, int n_blocks, hipStream_t s);
+
+}  // namespace pilot

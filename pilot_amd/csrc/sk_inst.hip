@@ -1,0 +1,98 @@
+// Template instantiations of the Sinkhorn kernels, one slice per translation unit (-DSK_PART=0|1: f32 | f64).
+#include "sinkhorn_launch.hpp"
+
+namespace pilot {
+namespace {
+
+template <class C, int RT, bool SYM, bool TRACK>
+hipError_t stream_one(dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    auto kern = sinkhorn_stream_kernel<C, RT, SYM, TRACK>;
+    if (lds > 32 * 1024) {   // beyond the default dynamic-LDS window the limit must be raised explicitly
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVE * WAVES_PER_WG), lds, s, p);
+    return hipGetLastError();
+}
+template <class C, int RT>
+hipError_t stream_rt(bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    if (track) return sym ? stream_one<C, RT, true, true>(grid, lds, s, p) : stream_one<C, RT, false, true>(grid, lds, s, p);
+    return sym ? stream_one<C, RT, true, false>(grid, lds, s, p) : stream_one<C, RT, false, false>(grid, lds, s, p);
+}
+template <class C>
+hipError_t stream_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    switch (RT) {
+    case 1: return stream_rt<C, 1>(sym, track, grid, lds, s, p);
+    case 2: return stream_rt<C, 2>(sym, track, grid, lds, s, p);
+    case 3: return stream_rt<C, 3>(sym, track, grid, lds, s, p);
+    case 4: return stream_rt<C, 4>(sym, track, grid, lds, s, p);
+    case 5: return stream_rt<C, 5>(sym, track, grid, lds, s, p);
+    case 6: return stream_rt<C, 6>(sym, track, grid, lds, s, p);
+    case 7: return stream_rt<C, 7>(sym, track, grid, lds, s, p);
+    case 8: return stream_rt<C, 8>(sym, track, grid, lds, s, p);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <class C, int RT> hipError_t value_rt(dim3 grid, hipStream_t s, const GridParams &p) {
+    hipLaunchKernelGGL((sinkhorn_value_kernel<C, RT>), grid, dim3(WAVE * WAVES_PER_WG), 0, s, p);
+    return hipGetLastError();
+}
+template <class C> hipError_t value_any(int RT, dim3 grid, hipStream_t s, const GridParams &p) {
+    switch (RT) {
+    case 1: return value_rt<C, 1>(grid, s, p);
+    case 2: return value_rt<C, 2>(grid, s, p);
+    case 3: return value_rt<C, 3>(grid, s, p);
+    case 4: return value_rt<C, 4>(grid, s, p);
+    case 5: return value_rt<C, 5>(grid, s, p);
+    case 6: return value_rt<C, 6>(grid, s, p);
+    case 7: return value_rt<C, 7>(grid, s, p);
+    case 8: return value_rt<C, 8>(grid, s, p);
+    default: return hipErrorInvalidValue;
+    }
+}
+template <class C>
+hipError_t setup_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s) {
+    using T = typename C::T;
+    hipLaunchKernelGGL(sinkhorn_setup_kernel<C>, dim3(64), dim3(256), 0, s, M, K, RT, reg, static_cast<T *>(img), P,
+                       static_cast<T *>(Pslot), n_p);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t order_any(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket, int *hist,
+                     int *list, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL((order_bucket_kernel<T>), dim3(n_blocks), dim3(256), 0, s, static_cast<const T *>(Pslot), N, KP, n_items,
+                       row_begin, row_step, bucket, hist);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_items, hist, hist + ORDER_NB, list);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#if SK_PART == 0
+hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<CfgF32x16>(RT, sym, track, grid, lds, s, p);
+}
+hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF32x16>(RT, grid, s, p); }
+hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s) {
+    return setup_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, n_p, s);
+}
+hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
+                            int *hist, int *list, int n_blocks, hipStream_t s) {
+    return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, n_blocks, s);
+}
+#elif SK_PART == 1
+hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<CfgF64x16>(RT, sym, track, grid, lds, s, p);
+}
+hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF64x16>(RT, grid, s, p); }
+hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s) {
+    return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, s);
+}
+hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
+                            int *hist, int *list, int n_blocks, hipStream_t s) {
+    return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, n_blocks, s);
+}
+#endif
+
+}  // namespace pilot

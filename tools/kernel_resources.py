@@ -3,7 +3,7 @@
 -Rpass-analysis=kernel-resource-usage remarks.  Usage: python tools/kernel_resources.py"""
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = subprocess.run(["make", "-C", os.path.join(root, "pilot_amd", "csrc"), "resources"],
+out = subprocess.run(["make", "-s", "-C", os.path.join(root, "pilot_amd", "csrc"), "resources"],
                      capture_output=True, text=True).stdout
 rows, cur = [], None
 for line in out.splitlines():
