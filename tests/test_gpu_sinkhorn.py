@@ -187,3 +187,35 @@ def test_c4_shape_sampled_rows():
     assert np.abs(Eg - Eo).max() <= TOL32
     Eg = engine.sinkhorn_grid(P, M, 0.1, precision="fp64", **rows)
     assert np.abs(Eg - Eo).max() <= TOL64
+
+
+def test_results_do_not_depend_on_work_order_or_occupancy(monkeypatch):
+    """A pair's arithmetic is independent of which wave / column / launch order it lands in: disabling the
+    longest-first ordering or changing the number of resident workgroups must reproduce the same bits."""
+    P, M = make_problem(**CONFIGS["c2"])
+    ref, iref = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", return_info=True)
+    for dbg in ("2", "16", "34"):          # no ordering; 1 workgroup per CU; both
+        monkeypatch.setenv("PILOT_OT_DEBUG", dbg)
+        got, ig = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", return_info=True)
+        np.testing.assert_array_equal(got, ref)
+        np.testing.assert_array_equal(ig["iters"], iref["iters"])
+    monkeypatch.delenv("PILOT_OT_DEBUG")
+
+
+def test_host_workspace_cache_across_shapes_and_shutdown():
+    """The host API caches its device workspace per (N, K); switching shapes, shrinking, growing and an explicit
+    shutdown in between must all give the same answers."""
+    outs = {}
+    for rep in range(2):
+        for (N, K) in ((40, 20), (100, 30), (40, 20), (7, 5)):
+            P, M = make_problem(N, K, 6, seed=N + K, cells_per_patient=300)
+            E = engine.sinkhorn_grid(P, M, 0.2, precision="fp64")
+            X = engine.emd_grid(P, M)
+            if (N, K) in outs:
+                np.testing.assert_array_equal(E, outs[(N, K)][0])
+                np.testing.assert_array_equal(X, outs[(N, K)][1])
+            outs[(N, K)] = (E, X)
+        _lib.check(_lib.load().pilot_ot_shutdown())
+    part = engine.sinkhorn_grid(*make_problem(40, 20, 6, seed=60, cells_per_patient=300), 0.2, precision="fp64",
+                                row_begin=3, row_end=9)
+    np.testing.assert_array_equal(part, outs[(40, 20)][0][3:9])
