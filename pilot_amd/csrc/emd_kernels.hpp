@@ -51,18 +51,52 @@ __device__ inline double uni_f64(double x) {
 }
 __device__ inline int uni_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// wave-wide minimum of a double (all lanes get the result)
+// Wave-wide reductions of a double, every lane gets the result.  Lanes are exchanged with DPP inside a 16-lane row
+// (quad_perm for the xor-1 / xor-2 partners, row_half_mirror and row_mirror to pair quads and octets) and with
+// gfx950's v_permlane16_swap / v_permlane32_swap across rows: ~20 VALU instructions instead of six LDS-crossbar
+// (ds_bpermute) round trips -- the arg-min of every Dijkstra step sits on the critical path of the solver.
+template <int CTRL> __device__ inline double dpp_f64(double x) {
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xf, 0xf, false);
+    return r.d;
+}
+__device__ inline void swap16_f64(double x, double &a, double &b) {
+    union { double d; unsigned int u[2]; } v, p, q;
+    v.d = x;
+    auto lo = __builtin_amdgcn_permlane16_swap(v.u[0], v.u[0], false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(v.u[1], v.u[1], false, false);
+    p.u[0] = lo[0]; p.u[1] = hi[0]; q.u[0] = lo[1]; q.u[1] = hi[1];
+    a = p.d; b = q.d;
+}
+__device__ inline void swap32_f64(double x, double &a, double &b) {
+    union { double d; unsigned int u[2]; } v, p, q;
+    v.d = x;
+    auto lo = __builtin_amdgcn_permlane32_swap(v.u[0], v.u[0], false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(v.u[1], v.u[1], false, false);
+    p.u[0] = lo[0]; p.u[1] = hi[0]; q.u[0] = lo[1]; q.u[1] = hi[1];
+    a = p.d; b = q.d;
+}
 __device__ inline double wave_min_f64(double x) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double y = __shfl_xor(x, off);
-        x = y < x ? y : x;
-    }
+    double y;
+    y = dpp_f64<0xB1>(x); x = y < x ? y : x;     // quad_perm(1,0,3,2): lane ^ 1
+    y = dpp_f64<0x4E>(x); x = y < x ? y : x;     // quad_perm(2,3,0,1): lane ^ 2
+    y = dpp_f64<0x141>(x); x = y < x ? y : x;    // row_half_mirror: the other quad of the octet
+    y = dpp_f64<0x140>(x); x = y < x ? y : x;    // row_mirror: the other octet of the row
+    double a, b;
+    swap16_f64(x, a, b); x = a < b ? a : b;      // the neighbouring row
+    swap32_f64(x, a, b); x = a < b ? a : b;      // the other half of the wave
     return x;
 }
 __device__ inline double wave_sum_f64(double x) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) x += __shfl_xor(x, off);
+    x += dpp_f64<0xB1>(x);
+    x += dpp_f64<0x4E>(x);
+    x += dpp_f64<0x141>(x);
+    x += dpp_f64<0x140>(x);
+    double a, b;
+    swap16_f64(x, a, b); x = a + b;
+    swap32_f64(x, a, b); x = a + b;
     return x;
 }
 
@@ -121,6 +155,22 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
             pu[e] = idx < K ? m : 0.0;
         }
         for (int t = lane; t < K * K; t += 64) FT[t] = 0.0;
+        if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // warm start: wherever the diagonal arc (i, i) has zero reduced cost (always, for a metric-like cost with a
+        // zero diagonal) ship min(a_i, b_i) along it.  Flow only on zero-reduced-cost arcs keeps complementary
+        // slackness, so the augmenting-path phase continues from an optimal partial flow and only has to move the
+        // mass that really differs between the two histograms (about 3x fewer augmentations on PILOT-like inputs).
+#pragma unroll
+        for (int e = 0; e < NK; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < K && Mrd[(size_t)idx * K + idx] - pu[e] == 0.0) {
+                const double f = ra[e] < rb[e] ? ra[e] : rb[e];
+                if (f > 0.0) { FT[(size_t)idx * K + idx] = f; ra[e] -= f; rb[e] -= f; }
+            }
+        }
+        if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
         int n_aug = 0;
         const int aug_guard = 64 * K + 64;   // far above the O(K) augmentations SSP needs; bounds every loop
         bool tripped = false;

@@ -19,7 +19,7 @@ def test_emd_parity(cfg, step):
     Eo = O.emd_grid(P, M, row_step=step, n_threads=16)
     Eg, info = engine.emd_grid(P, M, row_step=step, mode="all", return_info=True)
     assert np.abs(Eg - Eo).max() <= 1e-12
-    assert (info["n_aug"] > 0).all()
+    assert (info["n_aug"] >= 0).all() and info["n_aug"].max() > 0      # >= 0: the warm start already solves a == b
 
 
 def test_emd_modes_and_symmetry():
