@@ -115,7 +115,10 @@ struct pilot_ot_plan {
     void *img;         // 3 operand images, sized for f64 at this K
     void *p_slot;      // N x KP proportions in accumulator-slot order (f32 or f64; sized for f64)
     int *track_list;   // N x N
-    int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch
+    int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch,
+                       // [4..6] split of the ordered list: n_top, (unused copy), queue head of the cooperative launch
+    hipStream_t side;  // the cooperative kernel runs beside the main one
+    hipEvent_t ev_fork, ev_join;
     int *order_list;   // N x N: longest-first work order of the fast launch
     unsigned char *order_bucket;  // N x N
     int *order_hist;   // 2 * ORDER_NB: histogram + scatter cursors
@@ -233,6 +236,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
+    pl->side = nullptr; pl->ev_fork = nullptr; pl->ev_join = nullptr;
     pl->scratch = nullptr; pl->scratch_bytes = 0; pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) pl->ev[i][j] = nullptr;
@@ -246,7 +250,10 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp));
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * (size_t)N * kp);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), 8 * sizeof(int));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_hist), sizeof(int) * 2 * pilot::ORDER_NB);
@@ -268,6 +275,9 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->p_slot) (void)hipFree(pl->p_slot);
     if (pl->track_list) (void)hipFree(pl->track_list);
     if (pl->track_count) (void)hipFree(pl->track_count);
+    if (pl->side) (void)hipStreamDestroy(pl->side);
+    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+    if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     if (pl->order_list) (void)hipFree(pl->order_list);
     if (pl->order_bucket) (void)hipFree(pl->order_bucket);
     if (pl->order_hist) (void)hipFree(pl->order_hist);
@@ -323,7 +333,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if (lds > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision", K, lds,
                     LDS_BYTES);
-    HIP_TRY(hipMemsetAsync(pl->track_count, 0, 4 * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, 8 * sizeof(int), s));
     void *img = pl->img;
     void *Pt = pl->p_slot;
     HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, s)
@@ -364,16 +374,34 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         p.debug = dbg ? atoi(dbg) : 0;
     }
     const int tiles = (n_pairs + TILE - 1) / TILE;
-    // longest-first work order (see order_bucket_kernel)
+    // longest-first work order (see order_bucket_kernel); the head of the list (the slowest pairs) goes to the
+    // cooperative kernel, which runs beside the main kernel on the plan's side stream
+    bool coop = false;
     if (!(p.debug & 2)) {
+        coop = RT >= 2 && !(p.debug & 64);
         HIP_TRY(hipMemsetAsync(pl->order_hist, 0, sizeof(int) * 2 * pilot::ORDER_NB, s));
         int ob = (n_pairs + 255) / 256;
         if (ob > pl->n_cu * 8) ob = pl->n_cu * 8;
+        int *split = pl->track_count + 4;
         HIP_TRY(f32 ? pilot::launch_order_f32(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, ob, s)
+                                              pl->order_list, split, coop ? 1 : 0, ob, s)
                     : pilot::launch_order_f64(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, ob, s));
+                                              pl->order_list, split, coop ? 1 : 0, ob, s));
         p.list = pl->order_list;
+        if (coop) {
+            // the main kernel's queue starts behind the cooperative head: copy n_top into its queue head
+            HIP_TRY(hipMemcpyAsync(pl->track_count + 1, split, sizeof(int), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipEventRecord(pl->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
+            pilot::GridParams pc = p;
+            pc.list_len = split;           // n_items of the cooperative launch = n_top (device side)
+            pc.queue_head = split + 2;
+            int cw = (n_pairs / 256 + 15) / 16 + 1;       // enough workgroups for the capped head, at most one per 2 CUs
+            if (cw > pl->n_cu / 2) cw = pl->n_cu / 2;
+            if (cw < 1) cw = 1;
+            HIP_TRY(f32 ? pilot::launch_coop_f32(RT, sym, cw, pl->side, pc) : pilot::launch_coop_f64(RT, sym, cw, pl->side, pc));
+            HIP_TRY(hipEventRecord(pl->ev_join, pl->side));
+        }
     }
     hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
@@ -387,6 +415,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
                     : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
+    if (coop) HIP_TRY(hipStreamWaitEvent(s, pl->ev_join, 0));
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
     {

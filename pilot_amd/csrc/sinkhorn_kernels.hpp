@@ -469,15 +469,19 @@ sinkhorn_stream_kernel(GridParams p) {
             T e2 = T(0);
             T sc = T(1);
             if constexpr (TRACK) sc = (abs_at == ii - 1) ? T(1) / kk : T(1);  // u, v were just reset to 1/K each
+            // per-tile partial sums added in tile order: the association the cooperative kernel reproduces
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t) {
+                T et = T(0);
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) {
                     T d;
                     if constexpr (TRACK) d = V[t][r] * ACC[t][r] * sc - B[t][r];
                     else d = V[t][r] * ACC[t][r] - B[t][r];
-                    e2 += d * d;
+                    et += d * d;
                 }
+                e2 += et;
+            }
             e2 = group_sum<C>(e2);
             const T e = sqrt(e2);
             bool fin = capped;
@@ -509,6 +513,214 @@ sinkhorn_stream_kernel(GridParams p) {
                 want = true;
             }
         }
+    }
+}
+
+// ---- cooperative kernel for the slowest pairs ----------------------------------------------------------------------
+// A pair's updates are a serial chain, and the pairs at the head of the longest-first list (near-duplicate histograms;
+// the diagonal a == b needs 160-380 updates at reg = 0.1 against a mean of 39) set the minimum duration of a launch --
+// 0.69 ms of the 1.7 ms at 600 patients, and all of it once the grid is sharded over 8 GPUs.  Here a tile of 16 such
+// pairs is iterated by a WORKGROUP of RT waves instead of one wave: wave w owns output row-tile w of both products
+// (ceil(K/4) MFMAs instead of RT*ceil(K/4)) and the element-wise work on those 16 rows; the K x 16 scaling panel is
+// exchanged through LDS twice per update.  Every accumulation chain, every element-wise operation and the order of the
+// partial sums are those of sinkhorn_stream_kernel, so a pair's result is bit-identical whichever kernel solves it.
+template <class C, int RT, bool SYM>
+__global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) {
+    using T = typename C::T;
+    using acc_t = typename C::acc_t;
+    constexpr int TILE = C::TILE, NREG = C::NREG, NGRP = C::NGRP;
+    constexpr int KP = RT * TILE;
+    constexpr int SCR = scratch_stride<C>(RT);
+    constexpr int NSTEP = RT * NREG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *PB = reinterpret_cast<T *>(smem_raw);                 // [2][RT][WAVE][NREG] panel exchange (0: v, 1: u)
+    T *XB = PB + 2 * RT * WAVE * NREG;                         // [2][RT][WAVE] partials (0: squared error, 1: max)
+    int *QB = reinterpret_cast<int *>(XB + 2 * RT * WAVE);     // [1] batch base broadcast
+
+    const int n_items = *p.list_len;
+    if (blockIdx.x * TILE >= n_items) return;
+    const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int col = lane % TILE, grp = lane / TILE;
+    const int K = p.K, N = p.N;
+    const T *Pt = static_cast<const T *>(p.P);
+    const T *img = static_cast<const T *>(p.img);
+    const T *acc0g = img + 3 * KP * KP;
+    T *scratch = static_cast<T *>(p.scratch);
+    const T uinit = T(1) / T(K);
+    const T tau = T(p.tau);
+    const unsigned long long colmask = (1ull << TILE) - 1ull;
+
+    // stationary operands of this wave's output tile (registers): k-step (tp, r) -> image index ((tp*NREG + r)*RT + w)
+    T GT[NSTEP], GG[SYM ? 1 : NSTEP];
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        GT[st] = img[(st * RT + w) * WAVE + lane];
+        if constexpr (!SYM) GG[st] = img[KP * KP + (st * RT + w) * WAVE + lane];
+    }
+    acc_t PADC, UINIT;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const bool pad = C::lidx(w, r, grp) >= K;
+        PADC[r] = pad ? T(1) : T(0);
+        UINIT[r] = pad ? T(0) : uinit;
+    }
+
+    acc_t A, B, U, V, VN, ACC;
+    bool active = false, want = true;
+    int q = 0, ii = 0, chk = 1, flags = 0;
+    T errv = T(1), thr = T(0);
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) { A[r] = B[r] = U[r] = V[r] = VN[r] = T(0); ACC[r] = T(1); }
+    int res_next = 0, res_end = 0;
+    bool exhausted = false;
+
+    // own output tile of  X_img * IN  (IN = the full panel, one acc_t per row-tile); same chain order as panel_product
+    auto product = [&](const T (&G)[NSTEP], const acc_t (&IN)[RT]) {
+        acc_t out = PADC;
+#pragma unroll
+        for (int tp = 0; tp < RT; ++tp)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r)
+                if (tp < RT - 1 || C::lidx(tp, r, 0) < K)          // wave-uniform: skip k-steps that only hold padding
+                    out = C::mfma(G[tp * NREG + r], IN[tp][r], out);
+        return out;
+    };
+
+    for (;;) {
+        // ---- (re)fill: identical decisions in every wave (column state is replicated) -----------------------------
+        const unsigned long long wmask = __ballot(want) & colmask;
+        if (wmask) {
+            if (res_next >= res_end && !exhausted) {
+                if (w == 0 && lane == 0) QB[0] = __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const int base = __builtin_amdgcn_readfirstlane(QB[0]);
+                __syncthreads();
+                exhausted = base >= n_items;
+                res_next = exhausted ? n_items : base;
+                res_end = (base + TILE < n_items) ? base + TILE : n_items;
+                if (exhausted) res_end = n_items;
+            }
+            const int avail = res_end - res_next;
+            const int n_want = (int)__popcll(wmask);
+            const int rank = (int)__popcll(wmask & ((1ull << col) - 1ull));
+            const int item = res_next + rank;
+            const bool take = want && rank < avail;
+            res_next = __builtin_amdgcn_readfirstlane(res_next + (n_want < avail ? n_want : avail));
+            if (want && !take && exhausted) {
+                want = false;
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) { A[r] = B[r] = U[r] = V[r] = T(0); ACC[r] = T(1); }
+            }
+            if (take) {
+                want = false;
+                active = true;
+                q = p.list[item];
+                const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
+                load_regs<C>(Pt + (size_t)i * KP + (w * NGRP + grp) * NREG, A);
+                load_regs<C>(Pt + (size_t)j * KP + (w * NGRP + grp) * NREG, B);
+                acc_t a0;
+                load_regs<C>(acc0g + (w * NGRP + grp) * NREG, a0);
+                T bnorm2 = T(0);          // ||b||^2 over ALL tiles, summed exactly like the stream kernel does
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    acc_t bt;
+                    load_regs<C>(Pt + (size_t)j * KP + (t * NGRP + grp) * NREG, bt);
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) bnorm2 += bt[r] * bt[r];
+                }
+                bnorm2 = sum_xor32(bnorm2);
+                if constexpr (NGRP == 4) bnorm2 = sum_xor16(bnorm2);
+                thr = T(p.stop_thr);
+                if constexpr (sizeof(T) == 4) {
+                    const T fl = T(p.floor_ulps) * C::eps() * sqrtf(bnorm2);
+                    thr = thr > fl ? thr : fl;
+                }
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) { U[r] = UINIT[r]; V[r] = B[r] * C::rcp(a0[r]); }   // first v-update
+                ii = 0; chk = 1; flags = 0; errv = T(1);
+            }
+        }
+        if (__ballot(active || want) == 0ull) break;
+
+        // ---- exchange v; ACC = (G v)[own tile]; u = a / ACC ----------------------------------------------------
+        acc_t IN[RT];
+        store_regs<C>(PB + ((0 * RT + w) * WAVE + lane) * NREG, V);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; ++t) load_regs<C>(PB + ((0 * RT + t) * WAVE + lane) * NREG, IN[t]);
+        if constexpr (SYM) ACC = product(GT, IN); else ACC = product(GG, IN);
+        T mxl = T(0);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const T un = A[r] * C::rcp(ACC[r]);
+            U[r] = un;
+            mxl = fmax(fmax(mxl, un), V[r]);
+        }
+        ++ii;
+        // ---- exchange u (+ the partial max); tau hand-off; ACC = (G^T u)[own tile] --------------------------------
+        store_regs<C>(PB + ((1 * RT + w) * WAVE + lane) * NREG, U);
+        XB[(1 * RT + w) * WAVE + lane] = mxl;
+        __syncthreads();
+        T mx = T(0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            load_regs<C>(PB + ((1 * RT + t) * WAVE + lane) * NREG, IN[t]);
+            mx = fmax(mx, XB[(1 * RT + t) * WAVE + lane]);
+        }
+        {
+            const unsigned long long omask = column_any_mask<C>(active && mx > tau);
+            if (omask) {   // hand the pair to the tracking kernel
+                if (w == 0) {
+                    int base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(omask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (((omask >> col) & 1ull) && grp == 0) p.track_list[base + __popcll(omask & ((1ull << col) - 1ull))] = q;
+                }
+                if ((omask >> col) & 1ull) { active = false; want = true; }
+            }
+        }
+        ACC = product(GT, IN);
+        // ---- stopping test of this update; next v kept aside (a pair that stops parks the v of THIS update) ---------
+        T el = T(0);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const T d = V[r] * ACC[r] - B[r];
+            el += d * d;
+            VN[r] = B[r] * C::rcp(ACC[r]);
+        }
+        const bool pending = active && ii == chk;
+        if (pending) chk += p.period;
+        const bool capped = active && ii >= p.max_iter;
+        if (__ballot(pending || capped)) {
+            XB[(0 * RT + w) * WAVE + lane] = el;
+            __syncthreads();
+            T e2 = T(0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) e2 += XB[(0 * RT + t) * WAVE + lane];     // tile order, like the stream kernel
+            e2 = group_sum<C>(e2);
+            const T e = sqrt(e2);
+            bool fin = capped;
+            if (pending) {
+                errv = e;
+                if (e <= thr) { fin = true; flags |= FLAG_CONVERGED; }
+                else if (e != e) { fin = true; flags |= FLAG_NAN; }
+            }
+            if (fin) {
+                if constexpr (sizeof(T) == 8) flags |= FLAG_F64;
+                T *rec = scratch + (size_t)q * SCR;
+                store_regs<C>(rec + (w * NGRP + grp) * NREG, U);
+                store_regs<C>(rec + KP + (w * NGRP + grp) * NREG, V);
+                if (w == 0 && grp == 0) {
+                    rec[2 * KP] = T(1);
+                    if (p.iters) p.iters[q] = ii;
+                    if (p.err) p.err[q] = double(errv);
+                    p.flags[q] = flags;
+                }
+                active = false;
+                want = true;
+            }
+        }
+        V = VN;
     }
 }
 
@@ -649,8 +861,23 @@ __global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int
 // Every workgroup owns a contiguous chunk of items: LDS histogram of the chunk, ONE global atomic per
 // (workgroup, bucket) to reserve the range, then LDS cursors -- a handful of hot global addresses would
 // otherwise serialise all N^2 atomics.
+// `split` (3 ints, written by workgroup 0): [0] n_top = number of leading list items (the slowest pairs) that go to
+// the cooperative kernel, [1] initial head of the main kernel's queue (= n_top), [2] head of the cooperative queue (0).
 static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bucket, int n_items, const int *__restrict__ hist,
-                                     int *__restrict__ cursor, int *__restrict__ list) {
+                                     int *__restrict__ cursor, int *__restrict__ list, int *__restrict__ split,
+                                     int coop_enabled) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // whole buckets from the top while they fit in 1/256 of the items; the top bucket (duplicates) always
+        int n_top = 0;
+        if (coop_enabled) {
+            const int cap = n_items / 256 > hist[ORDER_NB - 1] ? n_items / 256 : hist[ORDER_NB - 1];
+            for (int b = ORDER_NB - 1; b >= 0; --b) {
+                if (n_top + hist[b] > cap) break;
+                n_top += hist[b];
+            }
+        }
+        split[0] = n_top; split[1] = n_top; split[2] = 0;
+    }
     __shared__ int offs[ORDER_NB], lh[ORDER_NB], lbase[ORDER_NB];
     if (threadIdx.x < ORDER_NB) lh[threadIdx.x] = 0;
     if (threadIdx.x == 0) {

@@ -58,12 +58,34 @@ hipError_t setup_any(const double *M, int K, int RT, double reg, void *img, cons
                        static_cast<T *>(Pslot), n_p);
     return hipGetLastError();
 }
+template <class C, int RT, bool SYM>
+hipError_t coop_one(int n_wgs, hipStream_t s, const GridParams &p) {
+    using T = typename C::T;
+    auto kern = sinkhorn_coop_kernel<C, RT, SYM>;
+    const size_t lds = sizeof(T) * (2 * RT * WAVE * C::NREG + 2 * RT * WAVE) + 16;
+    hipLaunchKernelGGL(kern, dim3(n_wgs), dim3(WAVE * RT), lds, s, p);
+    return hipGetLastError();
+}
+template <class C>
+hipError_t coop_any(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
+    switch (RT) {
+    case 2: return sym ? coop_one<C, 2, true>(n_wgs, s, p) : coop_one<C, 2, false>(n_wgs, s, p);
+    case 3: return sym ? coop_one<C, 3, true>(n_wgs, s, p) : coop_one<C, 3, false>(n_wgs, s, p);
+    case 4: return sym ? coop_one<C, 4, true>(n_wgs, s, p) : coop_one<C, 4, false>(n_wgs, s, p);
+    case 5: return sym ? coop_one<C, 5, true>(n_wgs, s, p) : coop_one<C, 5, false>(n_wgs, s, p);
+    case 6: return sym ? coop_one<C, 6, true>(n_wgs, s, p) : coop_one<C, 6, false>(n_wgs, s, p);
+    case 7: return sym ? coop_one<C, 7, true>(n_wgs, s, p) : coop_one<C, 7, false>(n_wgs, s, p);
+    case 8: return sym ? coop_one<C, 8, true>(n_wgs, s, p) : coop_one<C, 8, false>(n_wgs, s, p);
+    default: return hipErrorInvalidValue;
+    }
+}
 template <typename T>
 hipError_t order_any(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket, int *hist,
-                     int *list, int n_blocks, hipStream_t s) {
+                     int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s) {
     hipLaunchKernelGGL((order_bucket_kernel<T>), dim3(n_blocks), dim3(256), 0, s, static_cast<const T *>(Pslot), N, KP, n_items,
                        row_begin, row_step, bucket, hist);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_items, hist, hist + ORDER_NB, list);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_items, hist, hist + ORDER_NB, list, split,
+                       coop_enabled);
     return hipGetLastError();
 }
 
@@ -78,9 +100,10 @@ hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *im
     return setup_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, n_p, s);
 }
 hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int n_blocks, hipStream_t s) {
-    return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, n_blocks, s);
+                            int *hist, int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s) {
+    return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, coop_enabled, n_blocks, s);
 }
+hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16>(RT, sym, n_wgs, s, p); }
 #elif SK_PART == 1
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<CfgF64x16>(RT, sym, track, grid, lds, s, p);
@@ -90,9 +113,10 @@ hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *im
     return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, s);
 }
 hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int n_blocks, hipStream_t s) {
-    return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, n_blocks, s);
+                            int *hist, int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s) {
+    return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, coop_enabled, n_blocks, s);
 }
+hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF64x16>(RT, sym, n_wgs, s, p); }
 #endif
 
 }  // namespace pilot
