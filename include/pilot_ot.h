@@ -148,6 +148,18 @@ int pilot_ot_emd_grid_dev(pilot_ot_plan *plan, const double *d_P, const double *
                           int row_begin, int row_end, int row_step, double *d_emd, int *d_n_aug,
                           void *stream);
 
+/* ---- cell-level W2 pair grid (EXTENSION: not in the reference; BASELINE config 5) ------ */
+/* Compares patients by their raw cell clouds instead of cell-type proportions.  X: n_cells x D float32 embedding
+ * with the cells of patient i stored contiguously at rows offsets[i] .. offsets[i+1] (offsets: N + 1 entries).
+ * Pair (i, j): uniform weights 1/n_i, 1/n_j, cost C = |x - y|^2 / scale, entropic OT solved in the log domain with
+ * the control flow of POT's ot.bregman.sinkhorn_log (v-update then u-update; marginal error every check_period
+ * updates; stop on err < stop_thr, floored in f32 like the proportion-level kernel, or after num_iter_max updates);
+ * the value is <Gamma, C>.  The n_i x n_j cost matrix is never materialised.  D <= 64; patients up to ~13 000 cells.
+ * w2 / iters / err: n_rows x N (iters, err nullable). */
+int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D, double scale, double reg,
+                          int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
+                          int row_begin, int row_end, int row_step, double *w2, int *iters, double *err);
+
 /* precision actually selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (1 or 2) */
 int pilot_ot_auto_precision(double max_cost_over_reg);
 

@@ -244,3 +244,38 @@ def wasserstein_d(clu_rep, cost, regularized="unreg", reg=0.1, n_threads=1):
     emd["sampleID"] = samples_id
     emd = emd.set_index("sampleID")
     return EMD, emd
+
+
+def cell_w2(X, Y, scale, reg, numItermax=1000, stopThr=1e-9, check_period=10, return_info=False):
+    """fp64 oracle of the cell-level extension (pilot_ot_cell_w2_grid; NOT in the reference): POT 0.9.x
+    ``ot.bregman.sinkhorn_log`` control flow on uniform weights and cost |x - y|^2 / scale; returns <Gamma, C>."""
+    from scipy.special import logsumexp
+    from scipy.spatial.distance import cdist
+    X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    n, m = len(X), len(Y)
+    M = cdist(X, Y, "sqeuclidean") / scale
+    Mr = -M / reg
+    loga, logb = np.full(n, -np.log(n)), np.full(m, -np.log(m))
+    b = np.full(m, 1.0 / m)
+    u, v = np.zeros(n), np.zeros(m)
+    err, iters = 1.0, 0
+    for ii in range(numItermax):
+        v = logb - logsumexp(Mr + u[:, None], axis=0)
+        u = loga - logsumexp(Mr + v[None, :], axis=1)
+        iters = ii + 1
+        if ii % check_period == 0:
+            err = float(np.linalg.norm(np.exp(Mr + u[:, None] + v[None, :]).sum(0) - b))
+            if err < stopThr:
+                break
+    val = float(np.sum(np.exp(Mr + u[:, None] + v[None, :]) * M))
+    return (val, dict(iters=iters, err=err)) if return_info else val
+
+
+def cell_w2_grid(X, offsets, scale, reg, row_begin=0, row_end=None, row_step=1, **kw):
+    N = len(offsets) - 1
+    rows = range(row_begin, N if row_end is None else row_end, row_step)
+    out = np.zeros((len(rows), N))
+    for r, i in enumerate(rows):
+        for j in range(N):
+            out[r, j] = cell_w2(X[offsets[i]:offsets[i + 1]], X[offsets[j]:offsets[j + 1]], scale, reg, **kw)
+    return out

@@ -28,7 +28,7 @@ SYMBOLS = [
     "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_shutdown",
-    "pilot_ot_proportions", "pilot_ot_centroid_medians",
+    "pilot_ot_proportions", "pilot_ot_centroid_medians", "pilot_ot_cell_w2_grid",
 ]
 
 _lib = None
@@ -74,6 +74,8 @@ def load() -> ctypes.CDLL:
                                              ctypes.POINTER(ctypes.c_float), ip]
     L.pilot_ot_proportions.argtypes = [ip, ip, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int, c_dbl, c_int, dp]
     L.pilot_ot_centroid_medians.argtypes = [c_vp, c_int, ctypes.c_longlong, c_int, ip, c_int, dp]
+    L.pilot_ot_cell_w2_grid.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, c_int, c_int, c_int,
+                                        dp, ip, dp]
     L.pilot_ot_emd_grid.argtypes = [dp, c_int, c_int, dp, c_int, c_int, c_int, c_int, dp, ip]
     L.pilot_ot_emd_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]
     for name in SYMBOLS:

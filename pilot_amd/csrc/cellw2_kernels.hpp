@@ -1,0 +1,284 @@
+// Cell-level W2 pair grid (BASELINE config 5).  NOT in the reference: PILOT only ever solves
+// K x K problems on cell-type proportions; this extension compares two patients by their raw cell clouds.
+//
+// Pair (p, q): a = 1/n_p, b = 1/n_q, C_ij = |x_i - y_j|^2 / scale, entropic OT in the log domain with the control
+// flow of POT's ot.bregman.sinkhorn_log (v-update, then u-update, marginal error every `period` updates, strict <):
+//     v = log b - LSE_i(-C_ij/eps + u_i);   u = log a - LSE_j(-C_ij/eps + v_j);   value = sum(exp(logT) * C)
+// With alpha = 1/(scale*eps) and the shifted potentials hu_i = u_i - alpha|x_i|^2, hv_j = v_j - alpha|y_j|^2 both
+// updates are the same "flash" pass   out_r = LSE_c( 2 alpha <A_r, B_c> + h_c ):   hv = log b - out(A=Y, B=X, h=hu),
+// hu = log a - out(A=X, B=Y, h=hv).  The n_p x n_q cost matrix (100 MB at 5000 cells) is never materialised: 16 x 16
+// tiles of dot products come from v_mfma_f32_16x16x4_f32 (points pre-arranged in operand order), the log-sum-exp is
+// kept online per lane (running max + rescaled sum, base 2 so v_exp_f32 / v_log_f32 are used directly) and reduced
+// across the 16 lanes of a row with DPP at the end of a row block.  One workgroup (4 waves) per pair; the potentials
+// of the pair live in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pilot {
+
+constexpr float CELL_NEG_BIG = -1.0e30f;
+constexpr int CELL_WG = 1024;   // 16 waves share one pair: the self-pairs converge slowly and set the critical path
+constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
+
+struct CellParams {
+    const float *Xs;        // C x (4*DS) points in MFMA operand order: Xs[c][g*DS + s] = X[c][4*s + g], zero padded
+    const float *nrm;       // C: |x_c|^2
+    const long long *offs;  // N + 1: first cell of every patient
+    int N;
+    int n_rows, row_begin, row_step;
+    float two_alpha2;       // 2 * alpha * log2(e)
+    float alpha;            // 1 / (scale * eps)
+    float inv_scale;        // 1 / scale
+    int max_iter, period;
+    float stop_thr, floor_ulps;
+    int max_n;              // largest patient (LDS layout: hu[max_n], hv[max_n], hvn[max_n])
+    double *w2;             // n_rows x N
+    int *iters;
+    double *err;
+    int *queue;             // dynamic pair queue
+};
+
+// one pre-pass over the cells: operand-ordered copy + squared norms
+__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int DS, float *__restrict__ Xs,
+                                  float *__restrict__ nrm) {
+    const int W = 4 * DS;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * W; idx += (long)gridDim.x * blockDim.x) {
+        const long c = idx / W;
+        const int o = (int)(idx % W), g = o / DS, s = o % DS, d = 4 * s + g;
+        Xs[idx] = d < D ? X[c * D + d] : 0.f;
+    }
+    for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += X[c * D + d] * X[c * D + d];
+        nrm[c] = s;
+    }
+}
+
+template <int CTRL> __device__ inline float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// combine the online (max, sum) pairs of the 16 lanes of a row group; every lane of the group gets the result
+__device__ inline void row16_lse_combine(float &m, float &l) {
+#define PILOT_LSE_STEP(CTRL)                                                       \
+    {                                                                              \
+        const float mo = dpp_f32<CTRL>(m), lo = dpp_f32<CTRL>(l);                  \
+        const float mn = fmaxf(m, mo);                                             \
+        l = l * __builtin_amdgcn_exp2f(m - mn) + lo * __builtin_amdgcn_exp2f(mo - mn); \
+        m = mn;                                                                    \
+    }
+    PILOT_LSE_STEP(0xB1)    // lane ^ 1
+    PILOT_LSE_STEP(0x4E)    // lane ^ 2
+    PILOT_LSE_STEP(0x141)   // the other quad of the octet
+    PILOT_LSE_STEP(0x140)   // the other octet of the row
+#undef PILOT_LSE_STEP
+}
+__device__ inline float row16_sum(float x) {
+    x += dpp_f32<0xB1>(x); x += dpp_f32<0x4E>(x); x += dpp_f32<0x141>(x); x += dpp_f32<0x140>(x);
+    return x;
+}
+
+// out2[r] = log2 sum_c 2^( two_alpha2 * <A_r, B_c> + h2[c] )  for every row r of the A side  (base-2 LSE)
+// FN(row, lse2) is called by one lane per row with the result.
+template <int DS, class FN>
+__device__ inline void lse_pass(const float *__restrict__ As, int na, const float *__restrict__ Bs, int nb,
+                                const float *h2 /* LDS, nb */, float two_alpha2, int wave, int n_waves, int lane, FN &&fn) {
+    using f4 = float __attribute__((ext_vector_type(4)));
+    const int col = lane & 15, g = lane >> 4;
+    constexpr int TB = DS >= 16 ? 2 : 4;
+    for (int blk = wave; blk * 16 < na; blk += n_waves) {
+        int arow = blk * 16 + col;                        // A operand: lane holds row (lane & 15), k-slots of group g
+        if (arow >= na) arow = na - 1;
+        float a[DS];
+        const float *ap = As + (size_t)arow * (4 * DS) + g * DS;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) a[s] = ap[s];
+        float m[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m[r] = CELL_NEG_BIG; l[r] = 0.f; }
+        // TB column tiles per step: one running-max rescale per row and step instead of one per element
+        for (int tb = 0; tb * 16 < nb; tb += TB) {
+            f4 acc[TB];
+            float h[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                int bcol = (tb + u) * 16 + col;
+                const bool okc = bcol < nb;
+                if (!okc) bcol = nb - 1;
+                const float *bp = Bs + (size_t)bcol * (4 * DS) + g * DS;
+                float b[DS];
+#pragma unroll
+                for (int s = 0; s < DS; ++s) b[s] = bp[s];
+                h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
+                acc[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < DS; ++s) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                 // acc[u][r] = <A_{4g+r}, B_col(u)>
+                float t[TB], mn = m[r];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) { t[u] = fmaf(acc[u][r], two_alpha2, h[u]); mn = fmaxf(mn, t[u]); }
+                float add = 0.f;
+#pragma unroll
+                for (int u = 0; u < TB; ++u) add += __builtin_amdgcn_exp2f(t[u] - mn);
+                l[r] = fmaf(l[r], __builtin_amdgcn_exp2f(m[r] - mn), add);
+                m[r] = mn;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            row16_lse_combine(m[r], l[r]);
+            const int row = blk * 16 + 4 * g + r;
+            if (col == 0 && row < na) fn(row, m[r] + __builtin_amdgcn_logf(l[r]));   // v_log_f32 is log2
+        }
+    }
+}
+
+// sum_ij 2^(two_alpha2 <x_i, y_j> + hu2_i + hv2_j) * C_ij  for the rows handled by this wave (lane-local partial)
+template <int DS>
+__device__ inline float value_pass(const float *__restrict__ As, const float *__restrict__ na2, int na,
+                                   const float *__restrict__ Bs, const float *__restrict__ nb2, int nb,
+                                   const float *hA2, const float *hB2, float two_alpha2, float inv_scale, int wave,
+                                   int n_waves, int lane) {
+    using f4 = float __attribute__((ext_vector_type(4)));
+    const int col = lane & 15, g = lane >> 4;
+    float total = 0.f;
+    for (int blk = wave; blk * 16 < na; blk += n_waves) {
+        int arow = blk * 16 + col;
+        if (arow >= na) arow = na - 1;
+        float a[DS];
+        const float *ap = As + (size_t)arow * (4 * DS) + g * DS;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) a[s] = ap[s];
+        float hr[4], nr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = blk * 16 + 4 * g + r;
+            const bool ok = row < na;
+            hr[r] = ok ? hA2[row] : CELL_NEG_BIG;
+            nr[r] = ok ? na2[row] : 0.f;
+        }
+        for (int tb = 0; tb * 16 < nb; ++tb) {
+            int bcol = tb * 16 + col;
+            const bool okc = bcol < nb;
+            if (!okc) bcol = nb - 1;
+            const float *bp = Bs + (size_t)bcol * (4 * DS) + g * DS;
+            float b[DS];
+#pragma unroll
+            for (int s = 0; s < DS; ++s) b[s] = bp[s];
+            const float h = okc ? hB2[bcol] : CELL_NEG_BIG;
+            const float nc = nb2[bcol];
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < DS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float wgt = __builtin_amdgcn_exp2f(fmaf(acc[r], two_alpha2, h) + hr[r]);   // Gamma_ij
+                const float c = fmaxf(fmaf(-2.f, acc[r], nr[r] + nc), 0.f) * inv_scale;          // C_ij >= 0
+                total = fmaf(wgt, c, total);
+            }
+        }
+    }
+    return total;
+}
+
+template <int DS>
+__global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *hu = reinterpret_cast<float *>(smem_raw);        // [max_n] shifted potentials of the row patient (base 2)
+    float *hv = hu + p.max_n;                                // [max_n] ... of the column patient
+    float *hvn = hv + p.max_n;                               // [max_n] spare buffer of the v-update
+    float *red = hvn + p.max_n;                              // [32] per-wave partial sums
+    int *qslot = reinterpret_cast<int *>(red + 32);
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, n_waves = blockDim.x / 64;
+    const long total = (long)p.n_rows * p.N;
+
+    for (;;) {
+        if (threadIdx.x == 0) qslot[0] = atomicAdd(p.queue, 1);
+        __syncthreads();
+        const long q = qslot[0];
+        __syncthreads();
+        if (q >= total) break;
+        // self-pairs first (slowest to converge), then the rest row by row
+        int r_idx, j;
+        if (q < p.n_rows) { r_idx = (int)q; j = p.row_begin + r_idx * p.row_step; }
+        else {
+            const long qq = q - p.n_rows;
+            r_idx = (int)(qq / (p.N - 1));
+            j = (int)(qq % (p.N - 1));
+            j += j >= p.row_begin + r_idx * p.row_step;
+        }
+        const int i = p.row_begin + r_idx * p.row_step;
+        const long out = (long)r_idx * p.N + j;
+        const long o_p = p.offs[i], o_q = p.offs[j];
+        const int np = (int)(p.offs[i + 1] - o_p), nq = (int)(p.offs[j + 1] - o_q);
+        const float *Xp = p.Xs + (size_t)o_p * (4 * DS), *Yq = p.Xs + (size_t)o_q * (4 * DS);
+        const float *nxp = p.nrm + o_p, *nyq = p.nrm + o_q;
+        const float loga2 = -__builtin_amdgcn_logf((float)np), logb2 = -__builtin_amdgcn_logf((float)nq);
+        const float bval = 1.f / (float)nq;
+        const float a2l = p.alpha * LOG2E_F;
+        // u = v = 0  ->  hu2_i = -alpha |x_i|^2 log2 e
+        for (int t = threadIdx.x; t < np; t += blockDim.x) hu[t] = -a2l * nxp[t];
+        for (int t = threadIdx.x; t < nq; t += blockDim.x) hv[t] = -a2l * nyq[t];
+        __syncthreads();
+        // f32 floor of the stop threshold (|b|_2 = 1/sqrt(nq)), as in the proportion-level kernel
+        float thr = p.stop_thr;
+        {
+            const float fl = p.floor_ulps * 1.1920929e-07f * __builtin_amdgcn_rsqf((float)nq);
+            thr = thr > fl ? thr : fl;
+        }
+        int iters = 0;
+        float err = 1.f;
+        float *hv_cur = hv, *hv_new = hvn;
+        for (int ii = 0; ii < p.max_iter; ++ii) {
+            // ---- v-update:  hv_j = log b - LSE_i(2 alpha <y_j, x_i> + hu_i), written to the spare buffer.  The column
+            //      sums of the plan BEFORE this update are 2^(hv_old_j + out_j), so the marginal error POT evaluates
+            //      after update ii-1 comes for free; if it stops the pair, (hu, hv_old) is exactly the plan POT returns.
+            const bool check = ii > 0 && ((ii - 1) % p.period == 0);
+            float e2 = 0.f;
+            lse_pass<DS>(Yq, nq, Xp, np, hu, p.two_alpha2, wave, n_waves, lane, [&](int row, float lse2) {
+                if (check) {
+                    const float d = __builtin_amdgcn_exp2f(hv_cur[row] + lse2) - bval;
+                    e2 = fmaf(d, d, e2);
+                }
+                hv_new[row] = logb2 - lse2;
+            });
+            if (check) {   // wave-uniform
+                float s = e2;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) red[wave] = s;
+            }
+            __syncthreads();
+            if (check) {
+                float e = 0.f;
+                for (int w = 0; w < n_waves; ++w) e += red[w];   // fixed order: results do not depend on scheduling
+                err = sqrtf(e);
+                __syncthreads();
+                if (err < thr || err != err) break;          // POT: `if err < stopThr: break` (strict)
+            }
+            { float *t = hv_cur; hv_cur = hv_new; hv_new = t; }
+            // ---- u-update:  hu_i = log a - LSE_j(2 alpha <x_i, y_j> + hv_j) -------------------------------------------
+            lse_pass<DS>(Xp, np, Yq, nq, hv_cur, p.two_alpha2, wave, n_waves, lane,
+                         [&](int row, float lse2) { hu[row] = loga2 - lse2; });
+            __syncthreads();
+            iters = ii + 1;
+        }
+        // ---- value <Gamma, C> ---------------------------------------------------------------------------------------
+        float part = value_pass<DS>(Xp, nxp, np, Yq, nyq, nq, hu, hv_cur, p.two_alpha2, p.inv_scale, wave, n_waves, lane);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) red[16 + wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < n_waves; ++w) tot += red[16 + w];
+            p.w2[out] = (double)tot;
+            if (p.iters) p.iters[out] = iters;
+            if (p.err) p.err[out] = (double)err;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace pilot

@@ -15,6 +15,7 @@
 #include "sinkhorn_launch.hpp"
 #include "emd_kernels.hpp"
 #include "prepass_kernels.hpp"
+#include "cellw2_kernels.hpp"
 
 #define PILOT_API extern "C" __attribute__((visibility("default")))
 
@@ -762,4 +763,82 @@ PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_ce
     if (dtype == PILOT_OT_F32) return centroid_medians_impl<float>(X, n_cells, D, cell_code, K, centroids);
     if (dtype == PILOT_OT_F64) return centroid_medians_impl<double>(X, n_cells, D, cell_code, K, centroids);
     return fail(PILOT_OT_EINVAL, "unknown dtype id %d", dtype);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cell-level W2 (extension)
+PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D, double scale, double reg,
+                                    int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
+                                    int row_begin, int row_end, int row_step, double *w2, int *iters, double *err) {
+    if (!X || !offsets || !w2) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (N <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "N=%d D=%d must be positive", N, D);
+    if (D > 64) return fail(PILOT_OT_ENOTSUP, "D=%d > 64 embedding dimensions", D);
+    if (!(scale > 0.0) || !(reg > 0.0)) return fail(PILOT_OT_EINVAL, "scale=%g reg=%g must be positive", scale, reg);
+    if (num_iter_max < 1 || check_period < 1) return fail(PILOT_OT_EINVAL, "num_iter_max / check_period must be >= 1");
+    if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
+        return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
+    long long max_n = 0;
+    for (int i = 0; i < N; ++i) {
+        const long long n = offsets[i + 1] - offsets[i];
+        if (n <= 0) return fail(PILOT_OT_EINVAL, "patient %d has %lld cells", i, n);
+        if (n > max_n) max_n = n;
+    }
+    const size_t lds = sizeof(float) * (3 * (size_t)max_n + 48);
+    if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "a patient with %lld cells needs %zu B of LDS (> %zu)", max_n, lds, LDS_BYTES);
+    const long long C = offsets[N];
+    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
+    const size_t n_out = (size_t)n_rows * N;
+    if (n_out == 0) return PILOT_OT_OK;
+    const int DS = D <= 16 ? 4 : (D <= 32 ? 8 : 16);
+    if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
+
+    DevBuf dX, dXs, dnrm, doffs, dW, dIt, dErr, dQ;
+    hipError_t e = dX.alloc(sizeof(float) * (size_t)C * D);
+    if (e == hipSuccess) e = dXs.alloc(sizeof(float) * (size_t)C * 4 * DS);
+    if (e == hipSuccess) e = dnrm.alloc(sizeof(float) * (size_t)C);
+    if (e == hipSuccess) e = doffs.alloc(sizeof(long long) * (size_t)(N + 1));
+    if (e == hipSuccess) e = dW.alloc(sizeof(double) * n_out);
+    if (e == hipSuccess) e = dIt.alloc(sizeof(int) * n_out);
+    if (e == hipSuccess) e = dErr.alloc(sizeof(double) * n_out);
+    if (e == hipSuccess) e = dQ.alloc(sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dX.p, X, sizeof(float) * (size_t)C * D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(doffs.p, offsets, sizeof(long long) * (size_t)(N + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dQ.p, 0, sizeof(int));
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    const int n_cu = current_cu_count();
+    hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(C * 4 * DS, 256, n_cu)), dim3(256), 0, nullptr, dX.as<float>(), (long)C, D,
+                       DS, dXs.as<float>(), dnrm.as<float>());
+    pilot::CellParams p;
+    p.Xs = dXs.as<float>(); p.nrm = dnrm.as<float>(); p.offs = doffs.as<long long>(); p.N = N;
+    p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
+    const double alpha = 1.0 / (scale * reg);
+    p.alpha = (float)alpha;
+    p.two_alpha2 = (float)(2.0 * alpha * 1.4426950408889634);
+    p.inv_scale = (float)(1.0 / scale);
+    p.max_iter = num_iter_max; p.period = check_period;
+    p.stop_thr = (float)stop_thr; p.floor_ulps = (float)f32_floor_ulps;
+    p.max_n = (int)max_n;
+    p.w2 = dW.as<double>(); p.iters = dIt.as<int>(); p.err = dErr.as<double>(); p.queue = dQ.as<int>();
+    long wgs = (long)n_out;
+    long per_cu = (long)(LDS_BYTES / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    if (wgs > n_cu * per_cu) wgs = n_cu * per_cu;
+    hipError_t le = hipSuccess;
+#define PILOT_CELL_LAUNCH(DSV)                                                                                     \
+    do {                                                                                                           \
+        le = hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::cell_w2_kernel<DSV>),                       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (le == hipSuccess) hipLaunchKernelGGL(pilot::cell_w2_kernel<DSV>, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, nullptr, p); \
+    } while (0)
+    if (DS == 4) PILOT_CELL_LAUNCH(4);
+    else if (DS == 8) PILOT_CELL_LAUNCH(8);
+    else PILOT_CELL_LAUNCH(16);
+#undef PILOT_CELL_LAUNCH
+    HIP_TRY(le);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(w2, dW.p, sizeof(double) * n_out, hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(hipMemcpy(iters, dIt.p, sizeof(int) * n_out, hipMemcpyDeviceToHost));
+    if (err) HIP_TRY(hipMemcpy(err, dErr.p, sizeof(double) * n_out, hipMemcpyDeviceToHost));
+    return PILOT_OT_OK;
 }

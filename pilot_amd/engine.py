@@ -115,6 +115,34 @@ def centroid_medians(X, cell_code, n_types):
     return out
 
 
+def cell_w2_grid(X, offsets, scale, reg, num_iter_max=1000, stop_thr=1e-9, check_period=10, f32_floor_ulps=0.0,
+                 row_begin=0, row_end=None, row_step=1, return_info=False):
+    """EXTENSION (not in the reference; BASELINE config 5): entropic W2 cost between patients' raw cell clouds.
+
+    X: (C, D) float32 embedding with every patient's cells contiguous; offsets: (N + 1,) row ranges.  Pair (i, j):
+    uniform weights, cost |x - y|^2 / scale, log-domain Sinkhorn with POT ``sinkhorn_log`` control flow; returns the
+    (n_rows, N) matrix of <Gamma, C>."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    if X.ndim != 2 or offsets.ndim != 1 or offsets.size < 2 or offsets[0] != 0 or offsets[-1] != X.shape[0]:
+        raise ValueError("X must be (C, D) and offsets (N + 1,) with offsets[0] = 0, offsets[-1] = C")
+    if not np.all(np.isfinite(X)):
+        raise ValueError("X contains NaN or inf")
+    N = offsets.size - 1
+    row_end = N if row_end is None else int(row_end)
+    n_rows = n_rows_of(N, row_begin, row_end, row_step)
+    w2 = np.zeros((n_rows, N), dtype=np.float64)
+    iters = np.zeros((n_rows, N), dtype=np.int32)
+    err = np.zeros((n_rows, N), dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_cell_w2_grid(
+        ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(offsets.ctypes.data), N, X.shape[1], float(scale), float(reg),
+        int(num_iter_max), float(stop_thr), int(check_period), float(f32_floor_ulps), int(row_begin), row_end, int(row_step),
+        _lib.dptr(w2), _lib.iptr(iters), _lib.dptr(err)))
+    if return_info:
+        return w2, dict(iters=iters, err=err)
+    return w2
+
+
 class DevicePlan:
     """Device-resident pair-grid problem: P, M and the outputs live in HBM across calls.
 

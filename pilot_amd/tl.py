@@ -216,3 +216,39 @@ def Precomputed_distance(adata, distances, cost_df, features_matrix, emb_matrix=
     adata.uns["cost"] = cost_df
     adata.uns["EMD"] = distances
     adata.uns["real_labels"] = return_real_labels(annot)
+
+
+def cell_level_wasserstein(adata, emb_matrix="X_PCA", sample_col="sampleID", status="status", reg=0.1, scale=None,
+                           num_iter_max=1000, stop_thr=1e-9):
+    """EXTENSION -- not part of pilotpy (BASELINE config 5): Wasserstein-2 distance between
+    samples computed on their raw cell clouds instead of on cell-type proportions.
+
+    Every sample is the uniform measure on its cells in ``adata.obsm[emb_matrix]``; the ground cost is the squared
+    Euclidean distance divided by ``scale`` (default: twice the mean squared distance of the cells to the global
+    centroid, i.e. the expected squared distance between two random cells); entropic OT with regularisation ``reg`` is
+    solved in the log domain on the device for all ordered sample pairs.  Writes ``adata.uns['EMD_cell']`` (ndarray
+    N x N of transport costs), ``adata.uns['EMD_cell_df']`` and ``adata.uns['real_labels']``; returns nothing, like
+    ``wasserstein_distance``.
+    """
+    X = np.asarray(adata.obsm[emb_matrix], dtype=np.float32)
+    obs = adata.obs[[sample_col, status]].copy()
+    obs.columns = ["sampleID", "status"]
+    obs = obs.reset_index(drop=True)
+    scodes, samples = _first_appearance_codes(obs["sampleID"])
+    if (scodes < 0).any():
+        raise ValueError("cells without a sample id")
+    order = np.argsort(scodes, kind="stable")                 # group the cells of a sample, keep their order
+    counts = np.bincount(scodes, minlength=len(samples))
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    Xg = np.ascontiguousarray(X[order])
+    if scale is None:
+        mu = Xg.mean(axis=0, dtype=np.float64)
+        scale = 2.0 * float(((Xg.astype(np.float64) - mu) ** 2).sum(axis=1).mean())
+    W = engine.cell_w2_grid(Xg, offsets, scale, reg, num_iter_max=num_iter_max, stop_thr=stop_thr)
+    df = pd.DataFrame(W.T, columns=list(samples))
+    df["sampleID"] = list(samples)
+    df = df.set_index("sampleID")
+    adata.uns["EMD_cell"] = W
+    adata.uns["EMD_cell_df"] = df
+    adata.uns["EMD_cell_scale"] = scale
+    adata.uns["real_labels"] = return_real_labels(pd.DataFrame({"cell_type": 0, "sampleID": obs["sampleID"], "status": obs["status"]}))

@@ -1,0 +1,56 @@
+"""Cell-level W2 extension (not in the reference): device kernel vs the fp64 oracle
+(oracle.cell_w2: POT sinkhorn_log control flow).  Tolerance: 1e-4 absolute on costs of order 0.1-1 (f32 log-domain)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pilot_amd import engine, tl
+from pilot_amd.synthetic import make_cells
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def cohort(n_patients, cells, D, seed):
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(max(1, cells // 2), cells + 1, n_patients)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    centres = rng.standard_normal((n_patients, D)) * 0.5
+    X = np.concatenate([centres[p] + rng.standard_normal((sizes[p], D)) for p in range(n_patients)]).astype(np.float32)
+    mu = X.mean(0, dtype=np.float64)
+    scale = 2.0 * float(((X - mu) ** 2).sum(1).mean())
+    return X, offs, scale
+
+
+@pytest.mark.parametrize("n_patients,cells,D", [(4, 40, 5), (5, 150, 30), (3, 333, 17), (3, 97, 50)])
+@pytest.mark.parametrize("reg", [0.5, 0.1])
+def test_cell_w2_parity(n_patients, cells, D, reg):
+    X, offs, scale = cohort(n_patients, cells, D, seed=cells + D)
+    Wo = O.cell_w2_grid(X, offs, scale, reg)
+    Wg, info = engine.cell_w2_grid(X, offs, scale, reg, return_info=True)
+    assert Wg.shape == (n_patients, n_patients) and np.isfinite(Wg).all()
+    assert np.abs(Wg - Wo).max() <= TOL
+    it = info["iters"]
+    assert ((it % 10 == 1) | (it == 1000)).all()              # err is tested every 10 updates; 1000 = the cap
+
+
+def test_cell_w2_iteration_cap_and_rows():
+    X, offs, scale = cohort(5, 80, 8, seed=3)
+    Wo = O.cell_w2_grid(X, offs, scale, 0.05, numItermax=7)
+    Wg, info = engine.cell_w2_grid(X, offs, scale, 0.05, num_iter_max=7, return_info=True)
+    assert (info["iters"] == 7).all()
+    assert np.abs(Wg - Wo).max() <= TOL
+    part = engine.cell_w2_grid(X, offs, scale, 0.05, num_iter_max=7, row_begin=1, row_step=2)
+    np.testing.assert_array_equal(part, Wg[1::2])
+
+
+def test_cell_w2_properties_and_tl_surface(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    ad = make_cells(8, 6, 10, seed=5, cells_per_patient=300)
+    tl.cell_level_wasserstein(ad, emb_matrix="X_pca", reg=0.2)
+    W = ad.uns["EMD_cell"]
+    assert W.shape == (8, 8) and len(ad.uns["real_labels"]) == 8
+    assert np.abs(W - W.T).max() < 1e-4                       # converged entropic costs are symmetric
+    assert (np.diag(W) > 0).all() and (np.diag(W) < W.max()).all()
+    assert list(ad.uns["EMD_cell_df"].index) == list(ad.uns["EMD_cell_df"].columns)
+    np.testing.assert_array_equal(ad.uns["EMD_cell_df"].to_numpy(), W.T)
