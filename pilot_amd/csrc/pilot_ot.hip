@@ -251,13 +251,12 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp));
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * (size_t)N * kp);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), 8 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (8 + 2 * pilot::ORDER_NB) * sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_hist), sizeof(int) * 2 * pilot::ORDER_NB);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
     if (e == hipSuccess && K > 64)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
@@ -281,7 +280,6 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     if (pl->order_list) (void)hipFree(pl->order_list);
     if (pl->order_bucket) (void)hipFree(pl->order_bucket);
-    if (pl->order_hist) (void)hipFree(pl->order_hist);
     if (pl->scratch) (void)hipFree(pl->scratch);
     if (pl->flags_ws) (void)hipFree(pl->flags_ws);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
@@ -310,9 +308,9 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 }
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
-int stream_wgs_per_cu(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, size_t lds) {
+int stream_wgs_per_cu(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, size_t lds) {
     const int na = RT * 4 * RT * w;
-    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + ((sym && na <= 64) ? na : 0);
+    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + ((sym && na <= 64) ? na + 2 * tv * ((RT - 1) * 4 + 1) : 0);
     int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < occ) occ = by_lds;
@@ -331,14 +329,23 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     const int RT = (K + TILE - 1) / TILE;
     const int KP = RT * TILE;
     size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * ts + (size_t)KP * ts;   // operand image(s) + first-product table
+    // f32, K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
+    int tv = 0;
+    {
+        const char *dbg = getenv("PILOT_OT_DEBUG");
+        const int n_tail = K - (RT - 1) * TILE;
+        if (f32 && RT >= 2 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
+        if (tv) lds += (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * sizeof(float);
+    }
     if (lds > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision", K, lds,
                     LDS_BYTES);
-    HIP_TRY(hipMemsetAsync(pl->track_count, 0, 8 * sizeof(int), s));
+    pl->order_hist = pl->track_count + 8;     // one control block, one memset per call
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, (8 + 2 * pilot::ORDER_NB) * sizeof(int), s));
     void *img = pl->img;
     void *Pt = pl->p_slot;
-    HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, s)
-                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, s));
+    HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, tv ? 1 : 0, s)
+                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, 0, s));
     if (n_rows == 0) return PILOT_OT_OK;
 
     const int n_pairs = n_rows * N;
@@ -379,19 +386,20 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     // cooperative kernel, which runs beside the main kernel on the plan's side stream
     bool coop = false;
     if (!(p.debug & 2)) {
-        coop = RT >= 2 && !(p.debug & 64);
-        HIP_TRY(hipMemsetAsync(pl->order_hist, 0, sizeof(int) * 2 * pilot::ORDER_NB, s));
-        int ob = (n_pairs + 255) / 256;
-        if (ob > pl->n_cu * 8) ob = pl->n_cu * 8;
+        // the cooperative kernel pays (two cross-stream event hops, shared CUs) only when the launch is bounded by the
+        // serial chains of its slowest pairs, i.e. when the grid refills the resident waves just a few times
+        const long in_flight = (long)pl->n_cu * 2 * pilot::WAVES_PER_WG * TILE;
+        coop = RT >= 2 && !(p.debug & 64) && ((long)n_pairs <= 3 * in_flight || (p.debug & 128));
+        int ob = (n_pairs + 1023) / 1024;
+        if (ob > pl->n_cu) ob = pl->n_cu;
         int *split = pl->track_count + 4;
         HIP_TRY(f32 ? pilot::launch_order_f32(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, split, coop ? 1 : 0, ob, s)
+                                              pl->order_list, split, pl->track_count + 1, coop ? 1 : 0, ob, s)
                     : pilot::launch_order_f64(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, split, coop ? 1 : 0, ob, s));
+                                              pl->order_list, split, pl->track_count + 1, coop ? 1 : 0, ob, s));
         p.list = pl->order_list;
         if (coop) {
-            // the main kernel's queue starts behind the cooperative head: copy n_top into its queue head
-            HIP_TRY(hipMemcpyAsync(pl->track_count + 1, split, sizeof(int), hipMemcpyDeviceToDevice, s));
+            // (the main kernel's queue starts behind the cooperative head: order_scatter_kernel wrote n_top into it)
             HIP_TRY(hipEventRecord(pl->ev_fork, s));
             HIP_TRY(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
             pilot::GridParams pc = p;
@@ -400,7 +408,8 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
             int cw = (n_pairs / 256 + 15) / 16 + 1;       // enough workgroups for the capped head, at most one per 2 CUs
             if (cw > pl->n_cu / 2) cw = pl->n_cu / 2;
             if (cw < 1) cw = 1;
-            HIP_TRY(f32 ? pilot::launch_coop_f32(RT, sym, cw, pl->side, pc) : pilot::launch_coop_f64(RT, sym, cw, pl->side, pc));
+            HIP_TRY(tv ? pilot::launch_coop_f32_tv(tv, RT, sym, cw, pl->side, pc)
+                       : (f32 ? pilot::launch_coop_f32(RT, sym, cw, pl->side, pc) : pilot::launch_coop_f64(RT, sym, cw, pl->side, pc)));
             HIP_TRY(hipEventRecord(pl->ev_join, pl->side));
         }
     }
@@ -408,23 +417,25 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
     {
-        int wgs = pl->n_cu * stream_wgs_per_cu(w, RT, sym, false, lds);
+        int wgs = pl->n_cu * stream_wgs_per_cu(w, RT, sym, false, tv, lds);
         if ((p.debug >> 4) & 7) wgs = pl->n_cu * ((p.debug >> 4) & 7);   // experiment: resident workgroups per CU
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs > need) wgs = need;
-        HIP_TRY(f32 ? pilot::launch_stream_f32(RT, sym, false, dim3(wgs), lds, s, p)
-                    : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p));
+        HIP_TRY(tv ? pilot::launch_stream_f32_tv(tv, RT, sym, false, dim3(wgs), lds, s, p)
+                   : (f32 ? pilot::launch_stream_f32(RT, sym, false, dim3(wgs), lds, s, p)
+                          : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p)));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     if (coop) HIP_TRY(hipStreamWaitEvent(s, pl->ev_join, 0));
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
     {
-        int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, lds);
+        int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, tv, lds);
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs_t > need) wgs_t = need;
-        HIP_TRY(f32 ? pilot::launch_stream_f32(RT, sym, true, dim3(wgs_t), lds, s, p)
-                    : pilot::launch_stream_f64(RT, sym, true, dim3(wgs_t), lds, s, p));
+        HIP_TRY(tv ? pilot::launch_stream_f32_tv(tv, RT, sym, true, dim3(wgs_t), lds, s, p)
+                   : (f32 ? pilot::launch_stream_f32(RT, sym, true, dim3(wgs_t), lds, s, p)
+                          : pilot::launch_stream_f64(RT, sym, true, dim3(wgs_t), lds, s, p)));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
     // third pass: cost <Gamma, M> of every pair from its parked scalings

@@ -204,6 +204,79 @@ __device__ inline void panel_product(const AOp &aop, const typename C::acc_t (&I
     }
 }
 
+// ---- VALU tail rows (f32 16x16x4 only) --------------------------------------------------------------------------------
+// When K mod 16 is 1..4 the last row-tile holds at most four cell types (accumulator register 0 of the four lane groups)
+// and a product spends ceil(K/4) MFMAs (32 matrix-pipe cycles each) on 16 rows of which 12+ are padding.  With
+// TV = 1 (<= 2 live rows) or 2 (<= 4) those rows are computed on the VALU instead: every lane multiplies the
+// ceil(K/4) panel values it already holds (its lane group's share of the contraction index) with the matching
+// weights of TWO rows at once (v_pk_fma_f32, ~8 pipe cycles), and the four lane-group partials of a column are
+// added with the permlane swaps.  13 pk-FMAs + one reduction replace 13 MFMAs at K = 50.  The element-wise loops skip
+// the three all-padding registers of that tile as well.  Every kernel variant (stream, tracking, cooperative) uses
+// this one function, so a pair's bits still do not depend on which kernel solves it.
+using f2_t = float __attribute__((ext_vector_type(2)));
+template <int RT> __host__ __device__ constexpr int tail_steps() { return (RT - 1) * 4 + 1; }   // k-steps when only register 0 of the last tile is live
+// global tail image (f32, written by sinkhorn_setup_kernel behind the first-product table): [form 0: G^T-form, 1: G-form]
+// [chain 0..1][k-step][lane] pairs (X[row 2c][k], X[row 2c+1][k]), row h = cell type 16 (RT-1) + h, k = lidx(step, lane / 16)
+template <int RT> __host__ __device__ constexpr int tail_form_stride() { return 2 * tail_steps<RT>() * WAVE; }  // in f2_t
+
+template <int RT> struct TailFromImage {
+    const f2_t *w; int lane;
+    __device__ inline f2_t operator()(int c, int st) const { return w[(c * tail_steps<RT>() + st) * WAVE + lane]; }
+};
+template <int RT, int TV> struct TailFromRegs {
+    f2_t a[(TV > 0 ? TV : 1) * tail_steps<RT>()];
+    __device__ inline f2_t operator()(int c, int st) const { return a[c * tail_steps<RT>() + st]; }
+};
+struct TailNone {};
+
+template <class C, int RT, int TV, class WOp>
+__device__ inline float tail_rows(const WOp &w, const typename C::acc_t (&IN)[RT], float init0, int grp) {
+    static_assert(C::NGRP == 4 && C::NREG == 4 && sizeof(typename C::T) == 4, "VALU tail rows: f32 16x16x4 layout only");
+    f2_t acc[TV];
+#pragma unroll
+    for (int c = 0; c < TV; ++c) acc[c] = f2_t{0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < RT; ++tp)
+#pragma unroll
+        for (int r = 0; r < (tp < RT - 1 ? 4 : 1); ++r) {
+            const f2_t x = {IN[tp][r], IN[tp][r]};
+#pragma unroll
+            for (int c = 0; c < TV; ++c) acc[c] = __builtin_elementwise_fma(w(c, tp * 4 + r), x, acc[c]);
+        }
+#pragma unroll
+    for (int c = 0; c < TV; ++c) {
+        acc[c][0] = sum_xor16(sum_xor32(acc[c][0]));
+        acc[c][1] = sum_xor16(sum_xor32(acc[c][1]));
+    }
+    float val = (grp & 1) ? acc[0][1] : acc[0][0];
+    if constexpr (TV == 2) {
+        const float hi = (grp & 1) ? acc[1][1] : acc[1][0];
+        val = grp < 2 ? val : hi;
+    }
+    return init0 + val;    // init0 = 1 in padded slots (their weights are 0), 0 in live ones
+}
+
+// panel product with the last row-tile on the VALU (TV > 0): MFMA chains for row-tiles 0 .. RT-2 only
+template <class C, int RT, int TV, class AOp, class WOp>
+__device__ inline void panel_product_tail(const AOp &aop, const WOp &wop, const typename C::acc_t (&IN)[RT],
+                                          typename C::acc_t (&OUT)[RT], const typename C::acc_t &last_init, int grp) {
+    using M = C;
+    using T = typename C::T;
+#pragma unroll
+    for (int t = 0; t < RT - 1; ++t)
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) OUT[t][r] = T(0);
+#pragma unroll
+    for (int tp = 0; tp < RT; ++tp)
+#pragma unroll
+        for (int r = 0; r < (tp < RT - 1 ? M::NREG : 1); ++r)
+#pragma unroll
+            for (int t = 0; t < RT - 1; ++t)
+                OUT[t] = M::mfma(aop((tp * M::NREG + r) * RT + t), IN[tp][r], OUT[t]);
+    OUT[RT - 1] = last_init;
+    OUT[RT - 1][0] = tail_rows<C, RT, TV>(wop, IN, last_init[0], grp);
+}
+
 template <class C> __device__ inline void store_regs(typename C::T *dst, const typename C::acc_t &x) {
     using V = typename C::vec4_t;
 #pragma unroll
@@ -250,12 +323,12 @@ struct GridParams {
 template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
     return SYM && RT * C::NREG * RT * int(sizeof(typename C::T) / 4) <= 64;
 }
-template <class C, int RT, bool SYM, bool TRACK> constexpr int panel_regs() {
+template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel_regs() {
     return (TRACK ? 7 : 5) * RT * C::NREG * int(sizeof(typename C::T) / 4) + C::NREG * int(sizeof(typename C::T) / 4) + 56 +
-           (operands_in_regs<C, RT, SYM>() ? RT * C::NREG * RT * int(sizeof(typename C::T) / 4) : 0);
+           (operands_in_regs<C, RT, SYM>() ? RT * C::NREG * RT * int(sizeof(typename C::T) / 4) + 2 * TV * tail_steps<RT>() : 0);
 }
-template <class C, int RT, bool SYM, bool TRACK> constexpr int min_waves_per_simd() {
-    return panel_regs<C, RT, SYM, TRACK>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK>() <= 256 ? 2 : 1));
+template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
+    return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
 }
 
 // TRACK = false: plain scaling iterations; a pair whose POT residual scaling would exceed tau (i.e. POT
@@ -263,8 +336,8 @@ template <class C, int RT, bool SYM, bool TRACK> constexpr int min_waves_per_sim
 // TRACK = true : additionally carries the reciprocal reference scalings so the iteration at which every
 //                POT absorption happens is known (needed for POT's err-after-absorption and
 //                plan/(K*K)-on-the-final-update behaviour; see oracle/pilot_oracle.c).
-template <class C, int RT, bool SYM, bool TRACK>
-__global__ void __launch_bounds__(WAVE * WAVES_PER_WG, (min_waves_per_simd<C, RT, SYM, TRACK>()))
+template <class C, int RT, bool SYM, bool TRACK, int TV = 0>
+__global__ void __launch_bounds__(WAVE * WAVES_PER_WG, (min_waves_per_simd<C, RT, SYM, TRACK, TV>()))
 sinkhorn_stream_kernel(GridParams p) {
     using M = C;
     using T = typename C::T;
@@ -285,6 +358,14 @@ sinkhorn_stream_kernel(GridParams p) {
         constexpr int n_img = (SYM ? 1 : 2) * KP * KP;
         for (int i = threadIdx.x; i < n_img; i += WAVE * WAVES_PER_WG) lds[i] = g[i];
         for (int i = threadIdx.x; i < KP; i += WAVE * WAVES_PER_WG) lds[n_img + i] = g[3 * KP * KP + i];
+        if constexpr (TV > 0) {   // tail-row weights (chains 0 .. TV-1 of form 0, and of form 1 unless symmetric)
+            constexpr int n_form = TV * tail_steps<RT>() * WAVE * 2;           // floats per form actually used
+            const T *tg = g + 3 * KP * KP + KP;
+            for (int i = threadIdx.x; i < n_form; i += WAVE * WAVES_PER_WG) {
+                lds[n_img + KP + i] = tg[i];
+                if constexpr (!SYM) lds[n_img + KP + n_form + i] = tg[2 * tail_form_stride<RT>() + i];
+            }
+        }
     }
     __syncthreads();
     const T *img_gt = lds;                                         // out = G^T in
@@ -299,8 +380,29 @@ sinkhorn_stream_kernel(GridParams p) {
     }
     const AFromImage<C> a_gt{img_gt, lane}, a_g{img_g, lane};
     const T *acc0 = lds + (SYM ? 1 : 2) * KP * KP;                 // G^T u0, u0 = 1/K (a new pair's first product)
-
     const int col = lane % TILE, grp = lane / TILE;
+    // tail-row weights: LDS images, or registers next to the register-resident operand image
+    constexpr int NTF = (TV > 0 ? TV : 1) * tail_steps<RT>() * WAVE;            // f2_t per form in LDS
+    const f2_t *tl_base = reinterpret_cast<const f2_t *>(acc0 + KP);
+    const TailFromImage<RT> w_gt{tl_base, lane}, w_g{SYM ? tl_base : tl_base + NTF, lane};
+    TailFromRegs<RT, (GREG && TV > 0) ? TV : 0> wreg;
+    if constexpr (GREG && TV > 0) {
+#pragma unroll
+        for (int i = 0; i < TV * tail_steps<RT>(); ++i) wreg.a[i] = tl_base[i * WAVE + lane];
+    }
+    // all-padding registers of the last row-tile (TV > 0: only register 0 is live) are skipped by the element-wise loops
+    auto dead = [](int t, int r) { return TV > 0 && t == RT - 1 && r > 0; };
+    auto product = [&](const AFromImage<C> &a_img, const TailFromImage<RT> &w_img, const acc_t (&IN)[RT], acc_t (&OUT)[RT],
+                       const acc_t &init) {
+        if constexpr (TV > 0) {
+            if constexpr (GREG) panel_product_tail<C, RT, TV>(areg, wreg, IN, OUT, init, grp);
+            else panel_product_tail<C, RT, TV>(a_img, w_img, IN, OUT, init, grp);
+        } else {
+            if constexpr (GREG) panel_product<C, RT>(areg, IN, OUT, p.K, init);
+            else panel_product<C, RT>(a_img, IN, OUT, p.K, init);
+        }
+    };
+
     const int K = p.K, N = p.N;
     const T *Pt = static_cast<const T *>(p.P);
     T *scratch = static_cast<T *>(p.scratch);
@@ -408,15 +510,18 @@ sinkhorn_stream_kernel(GridParams p) {
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int r = 0; r < NREG; ++r) V[t][r] = B[t][r] * M::rcp(ACC[t][r]);
+            for (int r = 0; r < NREG; ++r) {
+                if (dead(t, r)) continue;
+                V[t][r] = B[t][r] * M::rcp(ACC[t][r]);
+            }
         // ---- u = a / (G v) ----------------------------------------------------------------------------
-        if constexpr (GREG) panel_product<C, RT>(areg, V, ACC, K, PADC);
-        else panel_product<C, RT>(a_g, V, ACC, K, PADC);
+        product(a_g, w_g, V, ACC, PADC);
         T mx = T(0);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
+                if (dead(t, r)) continue;
                 const T un = A[t][r] * M::rcp(ACC[t][r]);
                 U[t][r] = un;
                 // scalings are positive, so max|.| needs no abs; NaN operands drop out of max (as in POT,
@@ -458,8 +563,7 @@ sinkhorn_stream_kernel(GridParams p) {
         ++ii;   // ii updates of (v, u) are done for this column
 
         // ---- ACC = G^T u: feeds the stopping test of this update and the next v ----------------------
-        if constexpr (GREG) panel_product<C, RT>(areg, U, ACC, K, PADC);
-        else panel_product<C, RT>(a_gt, U, ACC, K, PADC);
+        product(a_gt, w_gt, U, ACC, PADC);
 
         // ---- POT's stopping rule: the error of update ii-1 is evaluated when (ii-1) % period == 0 ---
         const bool pending = active && ii == chk;
@@ -475,6 +579,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 T et = T(0);
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) {
+                    if (dead(t, r)) continue;      // (adds exactly 0 otherwise)
                     T d;
                     if constexpr (TRACK) d = V[t][r] * ACC[t][r] * sc - B[t][r];
                     else d = V[t][r] * ACC[t][r] - B[t][r];
@@ -524,7 +629,7 @@ sinkhorn_stream_kernel(GridParams p) {
 // (ceil(K/4) MFMAs instead of RT*ceil(K/4)) and the element-wise work on those 16 rows; the K x 16 scaling panel is
 // exchanged through LDS twice per update.  Every accumulation chain, every element-wise operation and the order of the
 // partial sums are those of sinkhorn_stream_kernel, so a pair's result is bit-identical whichever kernel solves it.
-template <class C, int RT, bool SYM>
+template <class C, int RT, bool SYM, int TV = 0>
 __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) {
     using T = typename C::T;
     using acc_t = typename C::acc_t;
@@ -557,6 +662,16 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
         GT[st] = img[(st * RT + w) * WAVE + lane];
         if constexpr (!SYM) GG[st] = img[KP * KP + (st * RT + w) * WAVE + lane];
     }
+    // TV > 0: the wave that owns the last row-tile computes it on the VALU (tail_rows, as the stream kernel does)
+    TailFromRegs<RT, TV> WT, WG;
+    if constexpr (TV > 0) {
+        const f2_t *tg = reinterpret_cast<const f2_t *>(img + 3 * KP * KP + KP);
+#pragma unroll
+        for (int i = 0; i < TV * tail_steps<RT>(); ++i) {
+            WT.a[i] = tg[i * WAVE + lane];
+            WG.a[i] = SYM ? WT.a[i] : tg[tail_form_stride<RT>() + i * WAVE + lane];
+        }
+    }
     acc_t PADC, UINIT;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
@@ -575,8 +690,14 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
     bool exhausted = false;
 
     // own output tile of  X_img * IN  (IN = the full panel, one acc_t per row-tile); same chain order as panel_product
-    auto product = [&](const T (&G)[NSTEP], const acc_t (&IN)[RT]) {
+    auto product = [&](const T (&G)[NSTEP], const TailFromRegs<RT, TV> &W, const acc_t (&IN)[RT]) {
         acc_t out = PADC;
+        if constexpr (TV > 0) {
+            if (w == RT - 1) {       // wave-uniform
+                out[0] = tail_rows<C, RT, TV>(W, IN, PADC[0], grp);
+                return out;
+            }
+        }
 #pragma unroll
         for (int tp = 0; tp < RT; ++tp)
 #pragma unroll
@@ -648,7 +769,7 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < RT; ++t) load_regs<C>(PB + ((0 * RT + t) * WAVE + lane) * NREG, IN[t]);
-        if constexpr (SYM) ACC = product(GT, IN); else ACC = product(GG, IN);
+        if constexpr (SYM) ACC = product(GT, WT, IN); else ACC = product(GG, WG, IN);
         T mxl = T(0);
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
@@ -679,7 +800,7 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
                 if ((omask >> col) & 1ull) { active = false; want = true; }
             }
         }
-        ACC = product(GT, IN);
+        ACC = product(GT, WT, IN);
         // ---- stopping test of this update; next v kept aside (a pair that stops parks the v of THIS update) ---------
         T el = T(0);
 #pragma unroll
@@ -772,7 +893,7 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(Gri
 template <class C>
 __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, int RT, double reg,
                                       typename C::T *__restrict__ img, const double *__restrict__ Psrc,
-                                      typename C::T *__restrict__ Pdst, long n_p) {
+                                      typename C::T *__restrict__ Pdst, long n_p, int write_tail) {
     using M = C;
     using T = typename C::T;
     const int KP = RT * M::TILE;
@@ -808,6 +929,23 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
             for (int k = 0; k < K; ++k) s += exp(-Msrc[(size_t)k * K + j] / reg);
         img[3 * nimg + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
     }
+    // tail-row weights for the VALU variant (see tail_rows): [form][chain][k-step][lane] pairs behind the table
+    if (write_tail) {
+        const int nst = (RT - 1) * 4 + 1;
+        T *tail = img + 3 * nimg + KP;
+        for (int idx = tid; idx < 2 * 2 * nst * WAVE * 2; idx += nthr) {
+            const int h = idx & 1;
+            int rest = idx >> 1;
+            const int lane = rest % WAVE; rest /= WAVE;
+            const int st = rest % nst; rest /= nst;
+            const int c = rest & 1, form = rest >> 1;
+            const int row = M::lidx(RT - 1, 0, 2 * c + h);
+            const int k = M::lidx(st / M::NREG, st % M::NREG, lane / M::TILE);
+            double v = 0.0;
+            if (row < K && k < K) v = form == 0 ? exp(-Msrc[(size_t)k * K + row] / reg) : exp(-Msrc[(size_t)row * K + k] / reg);
+            tail[idx] = T(v);
+        }
+    }
     // proportions: N rows of KP values in slot order, zero in padding (n_p = N * KP)
     for (long idx = tid; idx < n_p; idx += nthr) {
         const long row = idx / KP;
@@ -826,32 +964,79 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
 // launches: bucket ids + histogram, (prefix is folded into) scatter.
 constexpr int ORDER_NB = 48;
 
+// wave-aggregated LDS counter: lanes with equal `b` share one atomic; returns the lane's slot (base + rank among equals)
+__device__ inline int lds_count_aggregated(int *counters, int b, bool valid) {
+    int slot = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int b0 = __builtin_amdgcn_readlane(b, leader);
+        const unsigned long long same = __ballot(valid && b == b0);
+        const int lane = threadIdx.x % WAVE;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counters[b0], (int)__popcll(same));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (valid && b == b0) slot = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+// Tile of ORDER_RI selected rows x ORDER_JW columns per workgroup: the column histograms are staged transposed in LDS
+// (coalesced global reads, conflict-free LDS reads), the row histograms are LDS broadcasts; 2 VALU per |a_k - b_k|.
+constexpr int ORDER_JW = 128, ORDER_RI = 8;
+
 template <typename T>
-__global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int n_items, int row_begin, int row_step,
-                                    unsigned char *__restrict__ bucket, int *__restrict__ hist) {
-    // Pt rows are KP long (multiple of 16, zero padded, slot order -- L1 is permutation invariant): 16-byte loads
-    using V = T __attribute__((ext_vector_type(16 / sizeof(T))));
-    constexpr int VE = 16 / sizeof(T);
-    __shared__ int lh[ORDER_NB];
-    for (int i = threadIdx.x; i < ORDER_NB; i += blockDim.x) lh[i] = 0;
+__global__ void __launch_bounds__(256) order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int n_rows, int row_begin,
+                                                           int row_step, unsigned char *__restrict__ bucket,
+                                                           int *__restrict__ hist) {
+    // Pt rows are KP long (zero padded, slot order -- L1 is permutation invariant and the padding adds 0)
+    extern __shared__ __attribute__((aligned(16))) unsigned char order_smem[];
+    float *Bt = reinterpret_cast<float *>(order_smem);           // [KP][ORDER_JW + 1]
+    float *Ar = Bt + (size_t)KP * (ORDER_JW + 1);                // [ORDER_RI][KP]
+    int *lh = reinterpret_cast<int *>(Ar + ORDER_RI * KP);       // [ORDER_NB]
+    const int n_jb = (N + ORDER_JW - 1) / ORDER_JW;
+    const int jb = (blockIdx.x % n_jb) * ORDER_JW, rb = (blockIdx.x / n_jb) * ORDER_RI;
+    const int nj = N - jb < ORDER_JW ? N - jb : ORDER_JW;
+    const int nr = n_rows - rb < ORDER_RI ? n_rows - rb : ORDER_RI;
+    for (int e = threadIdx.x; e < ORDER_NB; e += blockDim.x) lh[e] = 0;
+    for (int e = threadIdx.x; e < nj * KP; e += blockDim.x) {
+        const int row = e / KP, k = e % KP;
+        Bt[k * (ORDER_JW + 1) + row] = float(Pt[(size_t)jb * KP + e]);
+    }
+    for (int e = threadIdx.x; e < ORDER_RI * KP; e += blockDim.x) {
+        const int r = e / KP, k = e % KP;
+        Ar[e] = r < nr ? float(Pt[(size_t)(row_begin + (rb + r) * row_step) * KP + k]) : 0.f;
+    }
     __syncthreads();
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_items; q += gridDim.x * blockDim.x) {
-        const int i = row_begin + (q / N) * row_step, j = q % N;
-        const V *pa = reinterpret_cast<const V *>(Pt + (size_t)i * KP);
-        const V *pb = reinterpret_cast<const V *>(Pt + (size_t)j * KP);
-        float l1 = 0.f;
-        for (int k = 0; k < KP / VE; ++k) {
-            const V a = pa[k], b = pb[k];
+    constexpr int R = ORDER_RI / 2;                               // rows per thread: the two halves of the block split the rows
+    const int jl = threadIdx.x % ORDER_JW, half = threadIdx.x / ORDER_JW;
+    float l1[R];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) l1 += fabsf(float(a[e]) - float(b[e]));
+    for (int r = 0; r < R; ++r) l1[r] = 0.f;
+    using f4 = float __attribute__((ext_vector_type(4)));
+    for (int k = 0; k < KP; k += 4) {
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = Bt[(k + e) * (ORDER_JW + 1) + jl];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const f4 av = *reinterpret_cast<const f4 *>(Ar + (half * R + r) * KP + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) l1[r] += fabsf(av[e] - bv[e]);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int rr = rb + half * R + r;
+        const bool valid = jl < nj && half * R + r < nr;
         int b = ORDER_NB - 1;
-        if (l1 > 0.f) {
-            const float v = 4.f * (1.f - log2f(l1));      // l1 = 2 -> 0, halves add 4
+        if (l1[r] > 0.f) {
+            const float v = 4.f * (1.f - log2f(l1[r]));      // l1 = 2 -> 0, halves add 4
             b = v < 0.f ? 0 : (v > float(ORDER_NB - 2) ? ORDER_NB - 2 : int(v));
         }
-        bucket[q] = (unsigned char)b;
-        atomicAdd(&lh[b], 1);
+        if (valid) bucket[(size_t)rr * N + jb + jl] = (unsigned char)b;
+        (void)lds_count_aggregated(lh, b, valid);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ORDER_NB; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
@@ -865,29 +1050,37 @@ __global__ void order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int
 // the cooperative kernel, [1] initial head of the main kernel's queue (= n_top), [2] head of the cooperative queue (0).
 static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bucket, int n_items, const int *__restrict__ hist,
                                      int *__restrict__ cursor, int *__restrict__ list, int *__restrict__ split,
-                                     int coop_enabled) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+                                     int *__restrict__ main_queue_head, int coop_enabled) {
+    __shared__ int offs[ORDER_NB], lh[ORDER_NB], lbase[ORDER_NB], gh[ORDER_NB];
+    if (threadIdx.x < ORDER_NB) { lh[threadIdx.x] = 0; gh[threadIdx.x] = hist[threadIdx.x]; }
+    __syncthreads();
+    if (threadIdx.x < ORDER_NB) {          // items in higher buckets come first
+        int run = 0;
+        for (int b = ORDER_NB - 1; b > (int)threadIdx.x; --b) run += gh[b];
+        offs[threadIdx.x] = run;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 64) {
         // whole buckets from the top while they fit in 1/256 of the items; the top bucket (duplicates) always
         int n_top = 0;
         if (coop_enabled) {
-            const int cap = n_items / 256 > hist[ORDER_NB - 1] ? n_items / 256 : hist[ORDER_NB - 1];
+            const int cap = n_items / 256 > gh[ORDER_NB - 1] ? n_items / 256 : gh[ORDER_NB - 1];
             for (int b = ORDER_NB - 1; b >= 0; --b) {
-                if (n_top + hist[b] > cap) break;
-                n_top += hist[b];
+                if (n_top + gh[b] > cap) break;
+                n_top += gh[b];
             }
         }
         split[0] = n_top; split[1] = n_top; split[2] = 0;
-    }
-    __shared__ int offs[ORDER_NB], lh[ORDER_NB], lbase[ORDER_NB];
-    if (threadIdx.x < ORDER_NB) lh[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int b = ORDER_NB - 1; b >= 0; --b) { offs[b] = run; run += hist[b]; }
+        *main_queue_head = n_top;          // the main kernel's queue starts behind the cooperative head
     }
     __syncthreads();
     const int chunk = (n_items + gridDim.x - 1) / gridDim.x;
     const int q0 = blockIdx.x * chunk, q1 = (q0 + chunk < n_items) ? q0 + chunk : n_items;
-    for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) atomicAdd(&lh[bucket[q]], 1);
+    const int n_it = (q1 - q0 + (int)blockDim.x - 1) / (int)blockDim.x;      // whole waves stay in the loop: ballots inside
+    for (int it = 0; it < n_it; ++it) {
+        const int q = q0 + it * blockDim.x + threadIdx.x;
+        const bool valid = q < q1;
+        (void)lds_count_aggregated(lh, valid ? bucket[q] : 0, valid);
+    }
     __syncthreads();
     if (threadIdx.x < ORDER_NB) {
         const int c = lh[threadIdx.x];
@@ -895,9 +1088,12 @@ static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bu
         lh[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
-        const int b = bucket[q];
-        list[lbase[b] + atomicAdd(&lh[b], 1)] = q;
+    for (int it = 0; it < n_it; ++it) {
+        const int q = q0 + it * blockDim.x + threadIdx.x;
+        const bool valid = q < q1;
+        const int b = valid ? bucket[q] : 0;
+        const int slot = lds_count_aggregated(lh, b, valid);
+        if (valid) list[lbase[b] + slot] = q;
     }
 }
 

@@ -1,5 +1,5 @@
 // Launch entry points of the Sinkhorn kernels.  The template instantiations are spread over several translation
-// units (sk_inst.hip compiled with -DSK_PART=0 for f32, 1 for f64) so that `make -j` builds them in parallel.
+// units (sk_inst.hip compiled with -DSK_PART=0 for f32, 1 for f64, 2 / 3 for the f32 VALU-tail variants) so that `make -j` builds them in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sinkhorn_kernels.hpp"
@@ -11,17 +11,20 @@ enum { CFG_F32 = 0, CFG_F64 = 1 };   // CfgF32x16, CfgF64x16
 // persistent stream kernel (one tile per wave); track: tau-tracking variant
 hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+// f32 variants with the last row-tile on the VALU (tv = 1: <= 2 live rows, 2: <= 4; see tail_rows); RT >= 2
+hipError_t launch_stream_f32_tv(int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_coop_f32_tv(int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
 // cooperative kernel for the head of the longest-first list (one workgroup of RT waves per tile)
 hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
 hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
 // helpers
 hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p);
 hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p);
-hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s);
-hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s);
+hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s);
+hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s);
 hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s);
+                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s);
 hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s);
+                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s);
 
 }  // namespace pilot

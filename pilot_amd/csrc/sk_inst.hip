@@ -4,9 +4,9 @@
 namespace pilot {
 namespace {
 
-template <class C, int RT, bool SYM, bool TRACK>
+template <class C, int RT, bool SYM, bool TRACK, int TV = 0>
 hipError_t stream_one(dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
-    auto kern = sinkhorn_stream_kernel<C, RT, SYM, TRACK>;
+    auto kern = sinkhorn_stream_kernel<C, RT, SYM, TRACK, TV>;
     if (lds > 32 * 1024) {   // beyond the default dynamic-LDS window the limit must be raised explicitly
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -14,22 +14,22 @@ hipError_t stream_one(dim3 grid, size_t lds, hipStream_t s, const GridParams &p)
     hipLaunchKernelGGL(kern, grid, dim3(WAVE * WAVES_PER_WG), lds, s, p);
     return hipGetLastError();
 }
-template <class C, int RT>
+template <class C, int RT, int TV = 0>
 hipError_t stream_rt(bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
-    if (track) return sym ? stream_one<C, RT, true, true>(grid, lds, s, p) : stream_one<C, RT, false, true>(grid, lds, s, p);
-    return sym ? stream_one<C, RT, true, false>(grid, lds, s, p) : stream_one<C, RT, false, false>(grid, lds, s, p);
+    if (track) return sym ? stream_one<C, RT, true, true, TV>(grid, lds, s, p) : stream_one<C, RT, false, true, TV>(grid, lds, s, p);
+    return sym ? stream_one<C, RT, true, false, TV>(grid, lds, s, p) : stream_one<C, RT, false, false, TV>(grid, lds, s, p);
 }
-template <class C>
+template <class C, int TV = 0>
 hipError_t stream_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     switch (RT) {
-    case 1: return stream_rt<C, 1>(sym, track, grid, lds, s, p);
-    case 2: return stream_rt<C, 2>(sym, track, grid, lds, s, p);
-    case 3: return stream_rt<C, 3>(sym, track, grid, lds, s, p);
-    case 4: return stream_rt<C, 4>(sym, track, grid, lds, s, p);
-    case 5: return stream_rt<C, 5>(sym, track, grid, lds, s, p);
-    case 6: return stream_rt<C, 6>(sym, track, grid, lds, s, p);
-    case 7: return stream_rt<C, 7>(sym, track, grid, lds, s, p);
-    case 8: return stream_rt<C, 8>(sym, track, grid, lds, s, p);
+    case 1: if constexpr (TV == 0) return stream_rt<C, 1, TV>(sym, track, grid, lds, s, p); else return hipErrorInvalidValue;
+    case 2: return stream_rt<C, 2, TV>(sym, track, grid, lds, s, p);
+    case 3: return stream_rt<C, 3, TV>(sym, track, grid, lds, s, p);
+    case 4: return stream_rt<C, 4, TV>(sym, track, grid, lds, s, p);
+    case 5: return stream_rt<C, 5, TV>(sym, track, grid, lds, s, p);
+    case 6: return stream_rt<C, 6, TV>(sym, track, grid, lds, s, p);
+    case 7: return stream_rt<C, 7, TV>(sym, track, grid, lds, s, p);
+    case 8: return stream_rt<C, 8, TV>(sym, track, grid, lds, s, p);
     default: return hipErrorInvalidValue;
     }
 }
@@ -52,40 +52,51 @@ template <class C> hipError_t value_any(int RT, dim3 grid, hipStream_t s, const 
     }
 }
 template <class C>
-hipError_t setup_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s) {
+hipError_t setup_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail,
+                     hipStream_t s) {
     using T = typename C::T;
     hipLaunchKernelGGL(sinkhorn_setup_kernel<C>, dim3(64), dim3(256), 0, s, M, K, RT, reg, static_cast<T *>(img), P,
-                       static_cast<T *>(Pslot), n_p);
+                       static_cast<T *>(Pslot), n_p, write_tail);
     return hipGetLastError();
 }
-template <class C, int RT, bool SYM>
+template <class C, int RT, bool SYM, int TV = 0>
 hipError_t coop_one(int n_wgs, hipStream_t s, const GridParams &p) {
     using T = typename C::T;
-    auto kern = sinkhorn_coop_kernel<C, RT, SYM>;
+    auto kern = sinkhorn_coop_kernel<C, RT, SYM, TV>;
     const size_t lds = sizeof(T) * (2 * RT * WAVE * C::NREG + 2 * RT * WAVE) + 16;
     hipLaunchKernelGGL(kern, dim3(n_wgs), dim3(WAVE * RT), lds, s, p);
     return hipGetLastError();
 }
-template <class C>
+template <class C, int TV = 0>
 hipError_t coop_any(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
     switch (RT) {
-    case 2: return sym ? coop_one<C, 2, true>(n_wgs, s, p) : coop_one<C, 2, false>(n_wgs, s, p);
-    case 3: return sym ? coop_one<C, 3, true>(n_wgs, s, p) : coop_one<C, 3, false>(n_wgs, s, p);
-    case 4: return sym ? coop_one<C, 4, true>(n_wgs, s, p) : coop_one<C, 4, false>(n_wgs, s, p);
-    case 5: return sym ? coop_one<C, 5, true>(n_wgs, s, p) : coop_one<C, 5, false>(n_wgs, s, p);
-    case 6: return sym ? coop_one<C, 6, true>(n_wgs, s, p) : coop_one<C, 6, false>(n_wgs, s, p);
-    case 7: return sym ? coop_one<C, 7, true>(n_wgs, s, p) : coop_one<C, 7, false>(n_wgs, s, p);
-    case 8: return sym ? coop_one<C, 8, true>(n_wgs, s, p) : coop_one<C, 8, false>(n_wgs, s, p);
+    case 2: return sym ? coop_one<C, 2, true, TV>(n_wgs, s, p) : coop_one<C, 2, false, TV>(n_wgs, s, p);
+    case 3: return sym ? coop_one<C, 3, true, TV>(n_wgs, s, p) : coop_one<C, 3, false, TV>(n_wgs, s, p);
+    case 4: return sym ? coop_one<C, 4, true, TV>(n_wgs, s, p) : coop_one<C, 4, false, TV>(n_wgs, s, p);
+    case 5: return sym ? coop_one<C, 5, true, TV>(n_wgs, s, p) : coop_one<C, 5, false, TV>(n_wgs, s, p);
+    case 6: return sym ? coop_one<C, 6, true, TV>(n_wgs, s, p) : coop_one<C, 6, false, TV>(n_wgs, s, p);
+    case 7: return sym ? coop_one<C, 7, true, TV>(n_wgs, s, p) : coop_one<C, 7, false, TV>(n_wgs, s, p);
+    case 8: return sym ? coop_one<C, 8, true, TV>(n_wgs, s, p) : coop_one<C, 8, false, TV>(n_wgs, s, p);
     default: return hipErrorInvalidValue;
     }
 }
 template <typename T>
 hipError_t order_any(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket, int *hist,
-                     int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s) {
-    hipLaunchKernelGGL((order_bucket_kernel<T>), dim3(n_blocks), dim3(256), 0, s, static_cast<const T *>(Pslot), N, KP, n_items,
+                     int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
+    const int n_rows = n_items / N;
+    const int tiles = ((N + ORDER_JW - 1) / ORDER_JW) * ((n_rows + ORDER_RI - 1) / ORDER_RI);
+    const size_t lds = sizeof(float) * ((size_t)KP * (ORDER_JW + 1) + (size_t)ORDER_RI * KP) + sizeof(int) * ORDER_NB;
+    static bool attr_set = false;     // more than 64 KB of dynamic LDS (K > 112) needs the opt-in; once per process
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(order_bucket_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((order_bucket_kernel<T>), dim3(tiles), dim3(256), lds, s, static_cast<const T *>(Pslot), N, KP, n_rows,
                        row_begin, row_step, bucket, hist);
     hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_items, hist, hist + ORDER_NB, list, split,
-                       coop_enabled);
+                       main_queue_head, coop_enabled);
     return hipGetLastError();
 }
 
@@ -96,27 +107,49 @@ hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds
     return stream_any<CfgF32x16>(RT, sym, track, grid, lds, s, p);
 }
 hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF32x16>(RT, grid, s, p); }
-hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s) {
-    return setup_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, n_p, s);
+hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s) {
+    return setup_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, n_p, write_tail, s);
 }
 hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s) {
-    return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, coop_enabled, n_blocks, s);
+                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
+    return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, main_queue_head, coop_enabled, n_blocks, s);
 }
 hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16>(RT, sym, n_wgs, s, p); }
+hipError_t launch_stream_f32_tv1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_stream_f32_tv2(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_coop_f32_tv1(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
+hipError_t launch_coop_f32_tv2(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
+hipError_t launch_stream_f32_tv(int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return tv == 1 ? launch_stream_f32_tv1(RT, sym, track, grid, lds, s, p) : launch_stream_f32_tv2(RT, sym, track, grid, lds, s, p);
+}
+hipError_t launch_coop_f32_tv(int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
+    return tv == 1 ? launch_coop_f32_tv1(RT, sym, n_wgs, s, p) : launch_coop_f32_tv2(RT, sym, n_wgs, s, p);
+}
 #elif SK_PART == 1
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<CfgF64x16>(RT, sym, track, grid, lds, s, p);
 }
 hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF64x16>(RT, grid, s, p); }
-hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, hipStream_t s) {
-    return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, s);
+hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s) {
+    return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, 0, s);
 }
 hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int coop_enabled, int n_blocks, hipStream_t s) {
-    return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, coop_enabled, n_blocks, s);
+                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
+    return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, main_queue_head, coop_enabled, n_blocks, s);
 }
 hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF64x16>(RT, sym, n_wgs, s, p); }
+#elif SK_PART == 2 || SK_PART == 3
+#if SK_PART == 2
+hipError_t launch_stream_f32_tv1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<CfgF32x16, 1>(RT, sym, track, grid, lds, s, p);
+}
+hipError_t launch_coop_f32_tv1(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16, 1>(RT, sym, n_wgs, s, p); }
+#else
+hipError_t launch_stream_f32_tv2(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<CfgF32x16, 2>(RT, sym, track, grid, lds, s, p);
+}
+hipError_t launch_coop_f32_tv2(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16, 2>(RT, sym, n_wgs, s, p); }
+#endif
 #endif
 
 }  // namespace pilot

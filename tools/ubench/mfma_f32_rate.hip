@@ -23,6 +23,25 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed) {
             } else if (MODE == 3) {   // 8 independent-ish VALU
                 v0 = fmaf(v0, v1, v2); v1 = fmaf(v1, v2, v3); v2 = fmaf(v2, v3, v0); v3 = fmaf(v3, v0, v1);
                 v0 = __builtin_amdgcn_rcpf(v0) * v2; v1 = __builtin_amdgcn_rcpf(v1) * v3;
+            } else if (MODE == 4 || MODE == 6) {   // 4 (8) v_pk_fma_f32
+                using f2 = float __attribute__((ext_vector_type(2)));
+                f2 p0 = {v0, v1}, p1 = {v2, v3};
+                p0 = __builtin_elementwise_fma(p0, p1, p0); p1 = __builtin_elementwise_fma(p1, p0, p1);
+                p0 = __builtin_elementwise_fma(p0, p1, p0); p1 = __builtin_elementwise_fma(p1, p0, p1);
+                if (MODE == 6) {
+                    p0 = __builtin_elementwise_fma(p0, p1, p0); p1 = __builtin_elementwise_fma(p1, p0, p1);
+                    p0 = __builtin_elementwise_fma(p0, p1, p0); p1 = __builtin_elementwise_fma(p1, p0, p1);
+                }
+                v0 = p0[0]; v1 = p0[1]; v2 = p1[0]; v3 = p1[1];
+            } else if (MODE == 5) {   // 2 permlane32_swap + 2 permlane16_swap + 4 add
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v0), false, false);
+                v0 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v0), false, false);
+                v0 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
+                v1 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
+                v1 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -110,6 +129,9 @@ int main() {
         run<4, 2>("4 acc + 4 fma per 4 MFMA", w);
         run<4, 3>("4 acc + 4 fma + 2 rcp + 2 mul per 4 MFMA", w);
         run<7, 3>("7 acc + 4 fma + 2 rcp + 2 mul per 7 MFMA", w);
+        run<4, 4>("4 acc + 4 pk_fma per 4 MFMA", w);
+        run<4, 6>("4 acc + 8 pk_fma per 4 MFMA", w);
+        run<4, 5>("4 acc + 4 permlane swap + 4 add per 4 MFMA", w);
     }
     return 0;
 }
