@@ -248,7 +248,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
             pl->n_cu = n_cu;
     }
     const int kp = ((K + 31) / 32) * 32;
-    if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp));
+    if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp + 2 * 2 * (size_t)(kp / 4) * 64 * 2));   // + tail-row weights
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * (size_t)N * kp);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (8 + 2 * pilot::ORDER_NB) * sizeof(int));
@@ -310,7 +310,7 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
 int stream_wgs_per_cu(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, size_t lds) {
     const int na = RT * 4 * RT * w;
-    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + ((sym && na <= 64) ? na + 2 * tv * ((RT - 1) * 4 + 1) : 0);
+    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + ((sym && na <= 64) ? na + 2 * tv * ((RT - 1) * 4 + 1) * w : 0);
     int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < occ) occ = by_lds;
@@ -329,13 +329,13 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     const int RT = (K + TILE - 1) / TILE;
     const int KP = RT * TILE;
     size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * ts + (size_t)KP * ts;   // operand image(s) + first-product table
-    // f32, K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
+    // K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
     int tv = 0;
     {
         const char *dbg = getenv("PILOT_OT_DEBUG");
         const int n_tail = K - (RT - 1) * TILE;
-        if (f32 && RT >= 2 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
-        if (tv) lds += (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * sizeof(float);
+        if (RT >= 2 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
+        if (tv) lds += (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * ts;
     }
     if (lds > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision", K, lds,
@@ -345,7 +345,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     void *img = pl->img;
     void *Pt = pl->p_slot;
     HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, tv ? 1 : 0, s)
-                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, 0, s));
+                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, tv ? 1 : 0, s));
     if (n_rows == 0) return PILOT_OT_OK;
 
     const int n_pairs = n_rows * N;
@@ -408,7 +408,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
             int cw = (n_pairs / 256 + 15) / 16 + 1;       // enough workgroups for the capped head, at most one per 2 CUs
             if (cw > pl->n_cu / 2) cw = pl->n_cu / 2;
             if (cw < 1) cw = 1;
-            HIP_TRY(tv ? pilot::launch_coop_f32_tv(tv, RT, sym, cw, pl->side, pc)
+            HIP_TRY(tv ? pilot::launch_coop_tv(cfg, tv, RT, sym, cw, pl->side, pc)
                        : (f32 ? pilot::launch_coop_f32(RT, sym, cw, pl->side, pc) : pilot::launch_coop_f64(RT, sym, cw, pl->side, pc)));
             HIP_TRY(hipEventRecord(pl->ev_join, pl->side));
         }
@@ -421,7 +421,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         if ((p.debug >> 4) & 7) wgs = pl->n_cu * ((p.debug >> 4) & 7);   // experiment: resident workgroups per CU
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs > need) wgs = need;
-        HIP_TRY(tv ? pilot::launch_stream_f32_tv(tv, RT, sym, false, dim3(wgs), lds, s, p)
+        HIP_TRY(tv ? pilot::launch_stream_tv(cfg, tv, RT, sym, false, dim3(wgs), lds, s, p)
                    : (f32 ? pilot::launch_stream_f32(RT, sym, false, dim3(wgs), lds, s, p)
                           : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p)));
     }
@@ -433,7 +433,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, tv, lds);
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs_t > need) wgs_t = need;
-        HIP_TRY(tv ? pilot::launch_stream_f32_tv(tv, RT, sym, true, dim3(wgs_t), lds, s, p)
+        HIP_TRY(tv ? pilot::launch_stream_tv(cfg, tv, RT, sym, true, dim3(wgs_t), lds, s, p)
                    : (f32 ? pilot::launch_stream_f32(RT, sym, true, dim3(wgs_t), lds, s, p)
                           : pilot::launch_stream_f64(RT, sym, true, dim3(wgs_t), lds, s, p)));
     }

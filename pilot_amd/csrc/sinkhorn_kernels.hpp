@@ -204,41 +204,44 @@ __device__ inline void panel_product(const AOp &aop, const typename C::acc_t (&I
     }
 }
 
-// ---- VALU tail rows (f32 16x16x4 only) --------------------------------------------------------------------------------
+// ---- VALU tail rows (16x16x4 configurations) --------------------------------------------------------------------------------
 // When K mod 16 is 1..4 the last row-tile holds at most four cell types (accumulator register 0 of the four lane groups)
 // and a product spends ceil(K/4) MFMAs (32 matrix-pipe cycles each) on 16 rows of which 12+ are padding.  With
 // TV = 1 (<= 2 live rows) or 2 (<= 4) those rows are computed on the VALU instead: every lane multiplies the
 // ceil(K/4) panel values it already holds (its lane group's share of the contraction index) with the matching
-// weights of TWO rows at once (v_pk_fma_f32, ~8 pipe cycles), and the four lane-group partials of a column are
+// weights of TWO rows at once (f32: v_pk_fma_f32, ~8 pipe cycles; f64: two v_fma_f64), and the four lane-group partials of a column are
 // added with the permlane swaps.  13 pk-FMAs + one reduction replace 13 MFMAs at K = 50.  The element-wise loops skip
 // the three all-padding registers of that tile as well.  Every kernel variant (stream, tracking, cooperative) uses
 // this one function, so a pair's bits still do not depend on which kernel solves it.
-using f2_t = float __attribute__((ext_vector_type(2)));
+template <typename T> using pair_of = T __attribute__((ext_vector_type(2)));
 template <int RT> __host__ __device__ constexpr int tail_steps() { return (RT - 1) * 4 + 1; }   // k-steps when only register 0 of the last tile is live
 // global tail image (f32, written by sinkhorn_setup_kernel behind the first-product table): [form 0: G^T-form, 1: G-form]
 // [chain 0..1][k-step][lane] pairs (X[row 2c][k], X[row 2c+1][k]), row h = cell type 16 (RT-1) + h, k = lidx(step, lane / 16)
-template <int RT> __host__ __device__ constexpr int tail_form_stride() { return 2 * tail_steps<RT>() * WAVE; }  // in f2_t
+template <int RT> __host__ __device__ constexpr int tail_form_stride() { return 2 * tail_steps<RT>() * WAVE; }  // in pairs
 
-template <int RT> struct TailFromImage {
-    const f2_t *w; int lane;
-    __device__ inline f2_t operator()(int c, int st) const { return w[(c * tail_steps<RT>() + st) * WAVE + lane]; }
+template <typename T, int RT> struct TailFromImage {
+    const pair_of<T> *w; int lane;
+    __device__ inline pair_of<T> operator()(int c, int st) const { return w[(c * tail_steps<RT>() + st) * WAVE + lane]; }
 };
-template <int RT, int TV> struct TailFromRegs {
-    f2_t a[(TV > 0 ? TV : 1) * tail_steps<RT>()];
-    __device__ inline f2_t operator()(int c, int st) const { return a[c * tail_steps<RT>() + st]; }
+template <typename T, int RT, int TV> struct TailFromRegs {
+    pair_of<T> a[(TV > 0 ? TV : 1) * tail_steps<RT>()];
+    __device__ inline pair_of<T> operator()(int c, int st) const { return a[c * tail_steps<RT>() + st]; }
 };
 struct TailNone {};
 
 template <class C, int RT, int TV, class WOp>
-__device__ inline float tail_rows(const WOp &w, const typename C::acc_t (&IN)[RT], float init0, int grp) {
-    static_assert(C::NGRP == 4 && C::NREG == 4 && sizeof(typename C::T) == 4, "VALU tail rows: f32 16x16x4 layout only");
+__device__ inline typename C::T tail_rows(const WOp &w, const typename C::acc_t (&IN)[RT], typename C::T init0, int grp) {
+    static_assert(C::NGRP == 4 && C::NREG == 4 && C::lidx(1, 0, 1) == 17, "VALU tail rows: 16x16x4 layouts with lidx = 16t + 4r + g");
+    using T = typename C::T;
+    using f2_t = pair_of<T>;
     f2_t acc[TV];
 #pragma unroll
-    for (int c = 0; c < TV; ++c) acc[c] = f2_t{0.f, 0.f};
+    for (int c = 0; c < TV; ++c) acc[c] = f2_t{T(0), T(0)};
 #pragma unroll
     for (int tp = 0; tp < RT; ++tp)
 #pragma unroll
         for (int r = 0; r < (tp < RT - 1 ? 4 : 1); ++r) {
+            // (forcing v_pk_fma_f32 with inline asm where the compiler splits it into two v_fma_f32 was measured: no gain)
             const f2_t x = {IN[tp][r], IN[tp][r]};
 #pragma unroll
             for (int c = 0; c < TV; ++c) acc[c] = __builtin_elementwise_fma(w(c, tp * 4 + r), x, acc[c]);
@@ -248,9 +251,9 @@ __device__ inline float tail_rows(const WOp &w, const typename C::acc_t (&IN)[RT
         acc[c][0] = sum_xor16(sum_xor32(acc[c][0]));
         acc[c][1] = sum_xor16(sum_xor32(acc[c][1]));
     }
-    float val = (grp & 1) ? acc[0][1] : acc[0][0];
+    T val = (grp & 1) ? acc[0][1] : acc[0][0];
     if constexpr (TV == 2) {
-        const float hi = (grp & 1) ? acc[1][1] : acc[1][0];
+        const T hi = (grp & 1) ? acc[1][1] : acc[1][0];
         val = grp < 2 ? val : hi;
     }
     return init0 + val;    // init0 = 1 in padded slots (their weights are 0), 0 in live ones
@@ -325,7 +328,7 @@ template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel_regs() {
     return (TRACK ? 7 : 5) * RT * C::NREG * int(sizeof(typename C::T) / 4) + C::NREG * int(sizeof(typename C::T) / 4) + 56 +
-           (operands_in_regs<C, RT, SYM>() ? RT * C::NREG * RT * int(sizeof(typename C::T) / 4) + 2 * TV * tail_steps<RT>() : 0);
+           (operands_in_regs<C, RT, SYM>() ? (RT * C::NREG * RT + 2 * TV * tail_steps<RT>()) * int(sizeof(typename C::T) / 4) : 0);
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
     return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
@@ -382,17 +385,17 @@ sinkhorn_stream_kernel(GridParams p) {
     const T *acc0 = lds + (SYM ? 1 : 2) * KP * KP;                 // G^T u0, u0 = 1/K (a new pair's first product)
     const int col = lane % TILE, grp = lane / TILE;
     // tail-row weights: LDS images, or registers next to the register-resident operand image
-    constexpr int NTF = (TV > 0 ? TV : 1) * tail_steps<RT>() * WAVE;            // f2_t per form in LDS
-    const f2_t *tl_base = reinterpret_cast<const f2_t *>(acc0 + KP);
-    const TailFromImage<RT> w_gt{tl_base, lane}, w_g{SYM ? tl_base : tl_base + NTF, lane};
-    TailFromRegs<RT, (GREG && TV > 0) ? TV : 0> wreg;
+    constexpr int NTF = (TV > 0 ? TV : 1) * tail_steps<RT>() * WAVE;            // pairs per form in LDS
+    const pair_of<T> *tl_base = reinterpret_cast<const pair_of<T> *>(acc0 + KP);
+    const TailFromImage<T, RT> w_gt{tl_base, lane}, w_g{SYM ? tl_base : tl_base + NTF, lane};
+    TailFromRegs<T, RT, (GREG && TV > 0) ? TV : 0> wreg;
     if constexpr (GREG && TV > 0) {
 #pragma unroll
         for (int i = 0; i < TV * tail_steps<RT>(); ++i) wreg.a[i] = tl_base[i * WAVE + lane];
     }
     // all-padding registers of the last row-tile (TV > 0: only register 0 is live) are skipped by the element-wise loops
     auto dead = [](int t, int r) { return TV > 0 && t == RT - 1 && r > 0; };
-    auto product = [&](const AFromImage<C> &a_img, const TailFromImage<RT> &w_img, const acc_t (&IN)[RT], acc_t (&OUT)[RT],
+    auto product = [&](const AFromImage<C> &a_img, const TailFromImage<T, RT> &w_img, const acc_t (&IN)[RT], acc_t (&OUT)[RT],
                        const acc_t &init) {
         if constexpr (TV > 0) {
             if constexpr (GREG) panel_product_tail<C, RT, TV>(areg, wreg, IN, OUT, init, grp);
@@ -663,9 +666,9 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
         if constexpr (!SYM) GG[st] = img[KP * KP + (st * RT + w) * WAVE + lane];
     }
     // TV > 0: the wave that owns the last row-tile computes it on the VALU (tail_rows, as the stream kernel does)
-    TailFromRegs<RT, TV> WT, WG;
+    TailFromRegs<T, RT, TV> WT, WG;
     if constexpr (TV > 0) {
-        const f2_t *tg = reinterpret_cast<const f2_t *>(img + 3 * KP * KP + KP);
+        const pair_of<T> *tg = reinterpret_cast<const pair_of<T> *>(img + 3 * KP * KP + KP);
 #pragma unroll
         for (int i = 0; i < TV * tail_steps<RT>(); ++i) {
             WT.a[i] = tg[i * WAVE + lane];
@@ -690,7 +693,7 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
     bool exhausted = false;
 
     // own output tile of  X_img * IN  (IN = the full panel, one acc_t per row-tile); same chain order as panel_product
-    auto product = [&](const T (&G)[NSTEP], const TailFromRegs<RT, TV> &W, const acc_t (&IN)[RT]) {
+    auto product = [&](const T (&G)[NSTEP], const TailFromRegs<T, RT, TV> &W, const acc_t (&IN)[RT]) {
         acc_t out = PADC;
         if constexpr (TV > 0) {
             if (w == RT - 1) {       // wave-uniform

@@ -1,5 +1,5 @@
 // Launch entry points of the Sinkhorn kernels.  The template instantiations are spread over several translation
-// units (sk_inst.hip compiled with -DSK_PART=0 for f32, 1 for f64, 2 / 3 for the f32 VALU-tail variants) so that `make -j` builds them in parallel.
+// units (sk_inst.hip compiled with -DSK_PART=0 for f32, 1 for f64, 2..5 for the VALU-tail variants: f32 tv1, f32 tv2, f64 tv1, f64 tv2) so that `make -j` builds them in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sinkhorn_kernels.hpp"
@@ -11,9 +11,9 @@ enum { CFG_F32 = 0, CFG_F64 = 1 };   // CfgF32x16, CfgF64x16
 // persistent stream kernel (one tile per wave); track: tau-tracking variant
 hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
-// f32 variants with the last row-tile on the VALU (tv = 1: <= 2 live rows, 2: <= 4; see tail_rows); RT >= 2
-hipError_t launch_stream_f32_tv(int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
-hipError_t launch_coop_f32_tv(int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
+// variants with the last row-tile on the VALU (tv = 1: <= 2 live rows, 2: <= 4; see tail_rows); RT >= 2
+hipError_t launch_stream_tv(int cfg, int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_coop_tv(int cfg, int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
 // cooperative kernel for the head of the longest-first list (one workgroup of RT waves per tile)
 hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
 hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);

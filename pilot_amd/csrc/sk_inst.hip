@@ -115,15 +115,18 @@ hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int r
     return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, main_queue_head, coop_enabled, n_blocks, s);
 }
 hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16>(RT, sym, n_wgs, s, p); }
-hipError_t launch_stream_f32_tv1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
-hipError_t launch_stream_f32_tv2(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
-hipError_t launch_coop_f32_tv1(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
-hipError_t launch_coop_f32_tv2(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
-hipError_t launch_stream_f32_tv(int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
-    return tv == 1 ? launch_stream_f32_tv1(RT, sym, track, grid, lds, s, p) : launch_stream_f32_tv2(RT, sym, track, grid, lds, s, p);
+#define PILOT_TV_DECL(NAME) \
+    hipError_t launch_stream_##NAME(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p); \
+    hipError_t launch_coop_##NAME(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
+PILOT_TV_DECL(f32_tv1) PILOT_TV_DECL(f32_tv2) PILOT_TV_DECL(f64_tv1) PILOT_TV_DECL(f64_tv2)
+#undef PILOT_TV_DECL
+hipError_t launch_stream_tv(int cfg, int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    if (cfg == CFG_F32) return tv == 1 ? launch_stream_f32_tv1(RT, sym, track, grid, lds, s, p) : launch_stream_f32_tv2(RT, sym, track, grid, lds, s, p);
+    return tv == 1 ? launch_stream_f64_tv1(RT, sym, track, grid, lds, s, p) : launch_stream_f64_tv2(RT, sym, track, grid, lds, s, p);
 }
-hipError_t launch_coop_f32_tv(int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
-    return tv == 1 ? launch_coop_f32_tv1(RT, sym, n_wgs, s, p) : launch_coop_f32_tv2(RT, sym, n_wgs, s, p);
+hipError_t launch_coop_tv(int cfg, int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
+    if (cfg == CFG_F32) return tv == 1 ? launch_coop_f32_tv1(RT, sym, n_wgs, s, p) : launch_coop_f32_tv2(RT, sym, n_wgs, s, p);
+    return tv == 1 ? launch_coop_f64_tv1(RT, sym, n_wgs, s, p) : launch_coop_f64_tv2(RT, sym, n_wgs, s, p);
 }
 #elif SK_PART == 1
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
@@ -131,25 +134,37 @@ hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds
 }
 hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF64x16>(RT, grid, s, p); }
 hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s) {
-    return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, 0, s);
+    return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, write_tail, s);
 }
 hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
                             int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
     return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, main_queue_head, coop_enabled, n_blocks, s);
 }
 hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF64x16>(RT, sym, n_wgs, s, p); }
-#elif SK_PART == 2 || SK_PART == 3
-#if SK_PART == 2
-hipError_t launch_stream_f32_tv1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
-    return stream_any<CfgF32x16, 1>(RT, sym, track, grid, lds, s, p);
-}
-hipError_t launch_coop_f32_tv1(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16, 1>(RT, sym, n_wgs, s, p); }
 #else
-hipError_t launch_stream_f32_tv2(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
-    return stream_any<CfgF32x16, 2>(RT, sym, track, grid, lds, s, p);
-}
-hipError_t launch_coop_f32_tv2(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16, 2>(RT, sym, n_wgs, s, p); }
+#if SK_PART == 2
+#define PILOT_TV_CFG CfgF32x16
+#define PILOT_TV_N 1
+#define PILOT_TV_NAME(x) x##f32_tv1
+#elif SK_PART == 3
+#define PILOT_TV_CFG CfgF32x16
+#define PILOT_TV_N 2
+#define PILOT_TV_NAME(x) x##f32_tv2
+#elif SK_PART == 4
+#define PILOT_TV_CFG CfgF64x16
+#define PILOT_TV_N 1
+#define PILOT_TV_NAME(x) x##f64_tv1
+#else
+#define PILOT_TV_CFG CfgF64x16
+#define PILOT_TV_N 2
+#define PILOT_TV_NAME(x) x##f64_tv2
 #endif
+hipError_t PILOT_TV_NAME(launch_stream_)(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<PILOT_TV_CFG, PILOT_TV_N>(RT, sym, track, grid, lds, s, p);
+}
+hipError_t PILOT_TV_NAME(launch_coop_)(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
+    return coop_any<PILOT_TV_CFG, PILOT_TV_N>(RT, sym, n_wgs, s, p);
+}
 #endif
 
 }  // namespace pilot
