@@ -117,7 +117,8 @@ struct pilot_ot_plan {
     void *p_slot;      // N x KP proportions in accumulator-slot order (f32 or f64; sized for f64)
     int *track_list;   // N x N
     int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch,
-                       // [4..6] split of the ordered list: n_top, (unused copy), queue head of the cooperative launch
+                       // [3] queue head of the solo waves, [4..7] split of the ordered list: n_top, (unused copy), queue head of
+                       // the cooperative tiles (= n_dup), n_dup = number of leading exact-duplicate pairs
     hipStream_t side;  // the cooperative kernel runs beside the main one
     hipEvent_t ev_fork, ev_join;
     int *order_list;   // N x N: longest-first work order of the fast launch
@@ -248,7 +249,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
             pl->n_cu = n_cu;
     }
     const int kp = ((K + 31) / 32) * 32;
-    if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp + 2 * 2 * (size_t)(kp / 4) * 64 * 2));   // + tail-row weights
+    if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp + 2 * 2 * (size_t)(kp / 4) * 64 * 2 + 2 * 64 * 64));   // + tail-row weights + plain tables
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * (size_t)N * kp);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (8 + 2 * pilot::ORDER_NB) * sizeof(int));
@@ -308,10 +309,20 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 }
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
-int stream_wgs_per_cu(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, size_t lds) {
+int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv) {
     const int na = RT * 4 * RT * w;
-    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + ((sym && na <= 64) ? na + 2 * tv * ((RT - 1) * 4 + 1) * w : 0);
-    int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
+    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) +
+                     ((sym && na <= 64) ? na + 2 * tv * ((RT - 1) * 4 + 1) * w : 0);
+    return regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
+}
+// mirrors pilot::solo_in_stream: does the fast launch of this configuration carry the one-wave-per-pair path?
+bool stream_has_solo(int w, int RT, bool sym, int tv) {
+    const int mw = stream_min_waves(w, RT, sym, false, tv);
+    const int budget = mw >= 4 ? 128 : (mw == 3 ? 168 : 256);
+    return sym && RT <= 4 && (64 + 45) * w <= budget;
+}
+int stream_wgs_per_cu(int w, int RT, bool sym, bool track, int tv, size_t lds) {
+    int occ = stream_min_waves(w, RT, sym, track, tv);
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < occ) occ = by_lds;
     return occ < 1 ? 1 : occ;
@@ -334,7 +345,8 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     {
         const char *dbg = getenv("PILOT_OT_DEBUG");
         const int n_tail = K - (RT - 1) * TILE;
-        if (RT >= 2 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
+        // (RT = 8 variants spill: left on the MFMA path)
+        if (RT >= 2 && RT <= 7 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
         if (tv) lds += (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * ts;
     }
     if (lds > LDS_BYTES)
@@ -344,8 +356,8 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, (8 + 2 * pilot::ORDER_NB) * sizeof(int), s));
     void *img = pl->img;
     void *Pt = pl->p_slot;
-    HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, tv ? 1 : 0, s)
-                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, tv ? 1 : 0, s));
+    HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, (tv ? 1 : 0) | 2, s)
+                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, (tv ? 1 : 0) | 2, s));
     if (n_rows == 0) return PILOT_OT_OK;
 
     const int n_pairs = n_rows * N;
@@ -372,6 +384,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.P = Pt; p.img = img; p.scratch = pl->scratch; p.N = N; p.K = K;
     p.n_pairs = n_pairs;
     p.list = nullptr; p.list_len = nullptr;
+    p.solo_len = nullptr; p.solo_head = nullptr; p.solo_blocks = 0;
     p.row_begin = row_begin; p.row_step = row_step;
     p.max_iter = num_iter_max; p.period = check_period;
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
@@ -385,26 +398,37 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     // longest-first work order (see order_bucket_kernel); the head of the list (the slowest pairs) goes to the
     // cooperative kernel, which runs beside the main kernel on the plan's side stream
     bool coop = false;
-    if (!(p.debug & 2)) {
+    // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
+    const bool solo = stream_has_solo(w, RT, sym, tv) && !(p.debug & 512);
+    int solo_blocks = 0;
+    {
         // the cooperative kernel pays (two cross-stream event hops, shared CUs) only when the launch is bounded by the
         // serial chains of its slowest pairs, i.e. when the grid refills the resident waves just a few times
         const long in_flight = (long)pl->n_cu * 2 * pilot::WAVES_PER_WG * TILE;
-        coop = RT >= 2 && !(p.debug & 64) && ((long)n_pairs <= 3 * in_flight || (p.debug & 128));
+        coop = RT >= 2 && !(p.debug & (64 | 2)) && ((long)n_pairs <= 3 * in_flight || (p.debug & 128));
+        if (tv && !f32 && RT > 4) coop = false;     // f64 tail weights + panels do not fit the cooperative kernel's registers
         int ob = (n_pairs + 1023) / 1024;
         if (ob > pl->n_cu) ob = pl->n_cu;
         int *split = pl->track_count + 4;
+        const int mode = (coop ? 1 : 0) | (solo ? 2 : 0) | ((p.debug & 2) ? 4 : 0);   // bit 2: natural order (experiment)
         HIP_TRY(f32 ? pilot::launch_order_f32(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, split, pl->track_count + 1, coop ? 1 : 0, ob, s)
+                                              pl->order_list, split, pl->track_count + 1, mode, ob, s)
                     : pilot::launch_order_f64(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, split, pl->track_count + 1, coop ? 1 : 0, ob, s));
+                                              pl->order_list, split, pl->track_count + 1, mode, ob, s));
         p.list = pl->order_list;
+        if (solo) {
+            solo_blocks = (n_rows + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;     // the diagonal; more duplicates queue up
+            if (solo_blocks > pl->n_cu) solo_blocks = pl->n_cu;
+            p.solo_len = split + 3; p.solo_head = pl->track_count + 3; p.solo_blocks = solo_blocks;
+        }
         if (coop) {
             // (the main kernel's queue starts behind the cooperative head: order_scatter_kernel wrote n_top into it)
             HIP_TRY(hipEventRecord(pl->ev_fork, s));
             HIP_TRY(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
             pilot::GridParams pc = p;
             pc.list_len = split;           // n_items of the cooperative launch = n_top (device side)
-            pc.queue_head = split + 2;
+            pc.queue_head = split + 2;     // starts behind the duplicates
+            pc.solo_blocks = 0;
             int cw = (n_pairs / 256 + 15) / 16 + 1;       // enough workgroups for the capped head, at most one per 2 CUs
             if (cw > pl->n_cu / 2) cw = pl->n_cu / 2;
             if (cw < 1) cw = 1;
@@ -421,6 +445,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         if ((p.debug >> 4) & 7) wgs = pl->n_cu * ((p.debug >> 4) & 7);   // experiment: resident workgroups per CU
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs > need) wgs = need;
+        wgs += solo_blocks;
         HIP_TRY(tv ? pilot::launch_stream_tv(cfg, tv, RT, sym, false, dim3(wgs), lds, s, p)
                    : (f32 ? pilot::launch_stream_f32(RT, sym, false, dim3(wgs), lds, s, p)
                           : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p)));
@@ -429,11 +454,14 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if (coop) HIP_TRY(hipStreamWaitEvent(s, pl->ev_join, 0));
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
+    p.solo_blocks = 0;
     {
-        int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, tv, lds);
+        // (the tracking kernel's result need not match the fast kernels' bits: a pair is always solved by one of them)
+        const int tv_t = RT <= 4 ? tv : 0;          // larger tracking variants spill with the tail rows
+        int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, tv_t, lds);
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs_t > need) wgs_t = need;
-        HIP_TRY(tv ? pilot::launch_stream_tv(cfg, tv, RT, sym, true, dim3(wgs_t), lds, s, p)
+        HIP_TRY(tv_t ? pilot::launch_stream_tv(cfg, tv_t, RT, sym, true, dim3(wgs_t), lds, s, p)
                    : (f32 ? pilot::launch_stream_f32(RT, sym, true, dim3(wgs_t), lds, s, p)
                           : pilot::launch_stream_f64(RT, sym, true, dim3(wgs_t), lds, s, p)));
     }

@@ -318,8 +318,124 @@ struct GridParams {
     int *track_list;      // fast kernel appends pairs that need POT absorption tracking
     int *track_count;
     int *queue_head;      // dynamic work queue of this launch (zeroed by the host before the launch)
+    const int *solo_len;  // fast launch: device-side number of leading list items (exact duplicates a == b) for solo_pairs
+    int *solo_head;       //   their queue head
+    int solo_blocks;      //   leading workgroups of the launch that run solo_pairs (they start first); 0: none
     int debug;            // experiment switches (PILOT_OT_DEBUG): bit0 no priority, bit1 no longest-first order
 };
+
+// ---- one wave per pair: the exact duplicates ---------------------------------------------------------------------------
+// Pairs with a == b (the diagonal of the grid, duplicate patients) need the most updates by far (161 .. 381 at c3 against
+// a mean of 39) and a pair's updates are a serial chain, so on a small or sharded grid they ARE the run time.  A 16-pair
+// MFMA tile spends 2 x (ceil(K/4) dependent MFMAs + an LDS panel exchange) per update on them; here one wavefront owns
+// one pair instead: lane i holds row i of G (and of G^T) in registers, the scaling vector lives one element per lane and
+// is broadcast k by k through v_readlane into an SGPR operand of v_fmac -- no LDS, no barrier, ~2.5x shorter update.
+// Selection is by value (a == b bit for bit: top bucket of the order key), never by load, so which kernel solves a pair
+// does not depend on the row subset or on the launch size; K <= 64.
+template <typename T> __device__ inline T readlane_t(T x, int k);
+template <> __device__ inline float readlane_t<float>(float x, int k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
+}
+template <> __device__ inline double readlane_t<double>(double x, int k) {
+    union { double d; int u[2]; } v;
+    v.d = x;
+    v.u[0] = __builtin_amdgcn_readlane(v.u[0], k);
+    v.u[1] = __builtin_amdgcn_readlane(v.u[1], k);
+    return v.d;
+}
+template <typename T> __device__ inline T wave_sum(T x) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) x += __shfl_xor(x, off);
+    return sum_xor32(sum_xor16(x));
+}
+// elements of the plain tables behind the tail-row weights: [table 0: G[lane][k], 1: G[k][lane]][k < 64][lane < 64]
+__host__ __device__ constexpr int plain_offset(int KP, int RT) { return 3 * KP * KP + KP + 2 * 2 * ((RT - 1) * 4 + 1) * WAVE * 2; }
+
+template <class C, bool SYM>
+__device__ inline void solo_pairs(const GridParams &p, int KP, int RT) {
+    using T = typename C::T;
+    const int lane = threadIdx.x % WAVE;
+    const int K = p.K, N = p.N;
+    const T *img = static_cast<const T *>(p.img);
+    const T *plain = img + plain_offset(KP, RT);
+    const T *Pt = static_cast<const T *>(p.P);
+    T *scratch = static_cast<T *>(p.scratch);
+    const int SCR = 2 * KP + 4;
+    T g1[64], g2[SYM ? 1 : 64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        g1[k] = plain[k * WAVE + lane];
+        if constexpr (!SYM) g2[k] = plain[64 * WAVE + k * WAVE + lane];
+    }
+    auto matvec = [&](const T (&g)[64], T x) {
+        T acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int k0 = 0; k0 < 64; k0 += 8)
+            if (k0 < K) {        // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e & 3] = fma(g[k0 + e], readlane_t<T>(x, k0 + e), acc[e & 3]);
+            }
+        return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    };
+    const bool live = lane < K;
+    const int pos = ((lane / 16) * 4 + (lane % 4)) * 4 + (lane % 16) / 4;     // accumulator slot of cell type `lane`
+    const bool inrec = lane < KP;
+    const T acc0 = inrec ? img[3 * KP * KP + pos] : T(1);
+    const T tau = T(p.tau);
+    const int n_items = *p.solo_len;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = __hip_atomic_fetch_add(p.solo_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const int q = p.list[item];
+        const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
+        const T a = inrec ? Pt[(size_t)i * KP + pos] : T(0), b = inrec ? Pt[(size_t)j * KP + pos] : T(0);
+        T thr = T(p.stop_thr);
+        if constexpr (sizeof(T) == 4) {
+            const T fl = T(p.floor_ulps) * C::eps() * sqrtf(wave_sum(b * b));
+            thr = thr > fl ? thr : fl;
+        }
+        T u = live ? T(1) / T(K) : T(0), v = u, ACC = acc0, errv = T(1);
+        int ii = 0, chk = 1, flags = sizeof(T) == 8 ? FLAG_F64 : 0;
+        for (;;) {
+            v = b * C::rcp(ACC);
+            T r1 = SYM ? matvec(g1, v) : matvec(g1, v);
+            r1 = live ? r1 : T(1);
+            u = a * C::rcp(r1);
+            if (__ballot(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
+                if (lane == 0) p.track_list[__hip_atomic_fetch_add(p.track_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
+                break;
+            }
+            ++ii;
+            if constexpr (SYM) ACC = matvec(g1, u); else ACC = matvec(g2, u);
+            ACC = live ? ACC : T(1);
+            const bool pending = ii == chk, capped = ii >= p.max_iter;
+            if (pending) chk += p.period;
+            if (pending || capped) {                              // wave-uniform
+                const T d = v * ACC - b;
+                const T e = sqrt(wave_sum(d * d));
+                bool fin = capped;
+                if (pending) {
+                    errv = e;
+                    if (e <= thr) { fin = true; flags |= FLAG_CONVERGED; }
+                    else if (e != e) { fin = true; flags |= FLAG_NAN; }
+                }
+                if (fin) {
+                    T *rec = scratch + (size_t)q * SCR;
+                    if (inrec) { rec[pos] = u; rec[KP + pos] = v; }
+                    if (lane == 0) {
+                        rec[2 * KP] = T(1);
+                        if (p.iters) p.iters[q] = ii;
+                        if (p.err) p.err[q] = double(errv);
+                        p.flags[q] = flags;
+                    }
+                    break;
+                }
+            }
+        }
+    }
+}
 
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
@@ -328,10 +444,18 @@ template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel_regs() {
     return (TRACK ? 7 : 5) * RT * C::NREG * int(sizeof(typename C::T) / 4) + C::NREG * int(sizeof(typename C::T) / 4) + 56 +
+           (TV > 0 ? 24 * int(sizeof(typename C::T) / 4) : 0) +     // tail accumulators, broadcast pairs, weights in flight
            (operands_in_regs<C, RT, SYM>() ? (RT * C::NREG * RT + 2 * TV * tail_steps<RT>()) * int(sizeof(typename C::T) / 4) : 0);
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
     return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
+}
+
+// solo_pairs (64 + ~45 registers of T per lane) rides in the fast launch when the cost is symmetric (PILOT's always is),
+// K <= 64, and the launch's register budget holds it without spilling
+template <class C, int RT, bool SYM, bool TRACK, int TV> constexpr bool solo_in_stream() {
+    constexpr int budget = min_waves_per_simd<C, RT, SYM, TRACK, TV>() >= 4 ? 128 : (min_waves_per_simd<C, RT, SYM, TRACK, TV>() == 3 ? 168 : 256);
+    return !TRACK && SYM && RT <= 4 && (64 + 45) * int(sizeof(typename C::T) / 4) <= budget;
 }
 
 // TRACK = false: plain scaling iterations; a pair whose POT residual scaling would exceed tau (i.e. POT
@@ -351,9 +475,15 @@ sinkhorn_stream_kernel(GridParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *lds = reinterpret_cast<T *>(smem_raw);
 
+    int block = blockIdx.x;
+    if constexpr (solo_in_stream<C, RT, SYM, TRACK, TV>()) {
+        // the leading workgroups of the fast launch run the exact-duplicate pairs, one per wave (they start first)
+        if (block < p.solo_blocks) { solo_pairs<C, SYM>(p, KP, RT); return; }
+        block -= p.solo_blocks;
+    }
     const int n_items = p.list_len ? *p.list_len : p.n_pairs;
     const int lane = threadIdx.x % WAVE;
-    if (blockIdx.x * WAVES_PER_WG * TILE >= n_items) return;  // more workgroups than work (tracking launch)
+    if (block * WAVES_PER_WG * TILE >= n_items) return;  // more workgroups than work (tracking launch)
 
     // stage the stationary operand: image 0 (and image 1 unless G is symmetric) + first-product table
     {
@@ -933,7 +1063,16 @@ __global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, in
         img[3 * nimg + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
     }
     // tail-row weights for the VALU variant (see tail_rows): [form][chain][k-step][lane] pairs behind the table
-    if (write_tail) {
+    if (write_tail & 2) {     // plain tables of solo_pairs
+        T *plain = img + plain_offset(KP, RT);
+        for (int idx = tid; idx < 2 * 64 * WAVE; idx += nthr) {
+            const int lane = idx % WAVE, k = (idx / WAVE) % 64, tbl = idx / (64 * WAVE);
+            double v = 0.0;
+            if (k < K && lane < K) v = tbl == 0 ? exp(-Msrc[(size_t)lane * K + k] / reg) : exp(-Msrc[(size_t)k * K + lane] / reg);
+            plain[idx] = T(v);
+        }
+    }
+    if (write_tail & 1) {
         const int nst = (RT - 1) * 4 + 1;
         T *tail = img + 3 * nimg + KP;
         for (int idx = tid; idx < 2 * 2 * nst * WAVE * 2; idx += nthr) {
@@ -992,7 +1131,7 @@ constexpr int ORDER_JW = 128, ORDER_RI = 8;
 template <typename T>
 __global__ void __launch_bounds__(256) order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int n_rows, int row_begin,
                                                            int row_step, unsigned char *__restrict__ bucket,
-                                                           int *__restrict__ hist) {
+                                                           int *__restrict__ hist, int collapse) {
     // Pt rows are KP long (zero padded, slot order -- L1 is permutation invariant and the padding adds 0)
     extern __shared__ __attribute__((aligned(16))) unsigned char order_smem[];
     float *Bt = reinterpret_cast<float *>(order_smem);           // [KP][ORDER_JW + 1]
@@ -1037,6 +1176,7 @@ __global__ void __launch_bounds__(256) order_bucket_kernel(const T *__restrict__
         if (l1[r] > 0.f) {
             const float v = 4.f * (1.f - log2f(l1[r]));      // l1 = 2 -> 0, halves add 4
             b = v < 0.f ? 0 : (v > float(ORDER_NB - 2) ? ORDER_NB - 2 : int(v));
+            if (collapse) b = 0;       // experiment switch: natural order, only the duplicates are told apart
         }
         if (valid) bucket[(size_t)rr * N + jb + jl] = (unsigned char)b;
         (void)lds_count_aggregated(lh, b, valid);
@@ -1065,14 +1205,17 @@ static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bu
     if (blockIdx.x == 0 && threadIdx.x == 64) {
         // whole buckets from the top while they fit in 1/256 of the items; the top bucket (duplicates) always
         int n_top = 0;
-        if (coop_enabled) {
+        if (coop_enabled & 1) {
             const int cap = n_items / 256 > gh[ORDER_NB - 1] ? n_items / 256 : gh[ORDER_NB - 1];
             for (int b = ORDER_NB - 1; b >= 0; --b) {
                 if (n_top + gh[b] > cap) break;
                 n_top += gh[b];
             }
         }
-        split[0] = n_top; split[1] = n_top; split[2] = 0;
+        // coop_enabled bit 1: the exact duplicates (top bucket, first in the list) go to solo_pairs, tiles start behind them
+        const int n_dup = (coop_enabled & 2) ? gh[ORDER_NB - 1] : 0;
+        if (n_top < n_dup) n_top = n_dup;      // no cooperative launch: the main queue starts behind the duplicates
+        split[0] = n_top; split[1] = n_top; split[2] = n_dup; split[3] = n_dup;
         *main_queue_head = n_top;          // the main kernel's queue starts behind the cooperative head
     }
     __syncthreads();

@@ -83,6 +83,7 @@ hipError_t coop_any(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams
 template <typename T>
 hipError_t order_any(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket, int *hist,
                      int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
+    const int collapse = (coop_enabled >> 2) & 1;    // bit 2: no longest-first order (experiment switch)
     const int n_rows = n_items / N;
     const int tiles = ((N + ORDER_JW - 1) / ORDER_JW) * ((n_rows + ORDER_RI - 1) / ORDER_RI);
     const size_t lds = sizeof(float) * ((size_t)KP * (ORDER_JW + 1) + (size_t)ORDER_RI * KP) + sizeof(int) * ORDER_NB;
@@ -94,9 +95,9 @@ hipError_t order_any(const void *Pslot, int N, int KP, int n_items, int row_begi
         attr_set = true;
     }
     hipLaunchKernelGGL((order_bucket_kernel<T>), dim3(tiles), dim3(256), lds, s, static_cast<const T *>(Pslot), N, KP, n_rows,
-                       row_begin, row_step, bucket, hist);
+                       row_begin, row_step, bucket, hist, collapse);
     hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_items, hist, hist + ORDER_NB, list, split,
-                       main_queue_head, coop_enabled);
+                       main_queue_head, coop_enabled & 3);
     return hipGetLastError();
 }
 
