@@ -407,6 +407,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         const long in_flight = (long)pl->n_cu * 2 * pilot::WAVES_PER_WG * TILE;
         coop = RT >= 2 && !(p.debug & (64 | 2)) && ((long)n_pairs <= 3 * in_flight || (p.debug & 128));
         if (tv && !f32 && RT > 4) coop = false;     // f64 tail weights + panels do not fit the cooperative kernel's registers
+        if (solo && !(p.debug & 128)) coop = false; // with the duplicates on their own waves the tile version gains nothing (measured)
         int ob = (n_pairs + 1023) / 1024;
         if (ob > pl->n_cu) ob = pl->n_cu;
         int *split = pl->track_count + 4;

@@ -352,7 +352,7 @@ template <typename T> __device__ inline T wave_sum(T x) {
 __host__ __device__ constexpr int plain_offset(int KP, int RT) { return 3 * KP * KP + KP + 2 * 2 * ((RT - 1) * 4 + 1) * WAVE * 2; }
 
 template <class C, bool SYM>
-__device__ inline void solo_pairs(const GridParams &p, int KP, int RT) {
+__device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned char *solo_smem) {
     using T = typename C::T;
     const int lane = threadIdx.x % WAVE;
     const int K = p.K, N = p.N;
@@ -367,13 +367,23 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT) {
         g1[k] = plain[k * WAVE + lane];
         if constexpr (!SYM) g2[k] = plain[64 * WAVE + k * WAVE + lane];
     }
+    // y_lane = sum_k g[k] * x_k: x goes through a wave-private LDS line and comes back as broadcast 16-byte reads (half the
+    // instructions of a v_readlane per element; the wave is issue-bound)
+    T *xline = reinterpret_cast<T *>(solo_smem) + (threadIdx.x / WAVE) * WAVE;
+    using V4 = T __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int VE = 16 / sizeof(T);
     auto matvec = [&](const T (&g)[64], T x) {
+        xline[lane] = x;
         T acc[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int k0 = 0; k0 < 64; k0 += 8)
+        for (int k0 = 0; k0 < 64; k0 += 16)
             if (k0 < K) {        // wave-uniform
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e & 3] = fma(g[k0 + e], readlane_t<T>(x, k0 + e), acc[e & 3]);
+                for (int c = 0; c < 16 / VE; ++c) {
+                    const V4 xv = *reinterpret_cast<const V4 *>(xline + k0 + c * VE);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[e & 3] = fma(g[k0 + c * VE + e], xv[e], acc[e & 3]);
+                }
             }
         return (acc[0] + acc[1]) + (acc[2] + acc[3]);
     };
@@ -478,7 +488,7 @@ sinkhorn_stream_kernel(GridParams p) {
     int block = blockIdx.x;
     if constexpr (solo_in_stream<C, RT, SYM, TRACK, TV>()) {
         // the leading workgroups of the fast launch run the exact-duplicate pairs, one per wave (they start first)
-        if (block < p.solo_blocks) { solo_pairs<C, SYM>(p, KP, RT); return; }
+        if (block < p.solo_blocks) { solo_pairs<C, SYM>(p, KP, RT, smem_raw); return; }
         block -= p.solo_blocks;
     }
     const int n_items = p.list_len ? *p.list_len : p.n_pairs;
