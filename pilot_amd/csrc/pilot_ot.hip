@@ -356,8 +356,6 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, (8 + 2 * pilot::ORDER_NB) * sizeof(int), s));
     void *img = pl->img;
     void *Pt = pl->p_slot;
-    HIP_TRY(f32 ? pilot::launch_setup_f32(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, (tv ? 1 : 0) | 2, s)
-                : pilot::launch_setup_f64(d_M, K, RT, reg, img, d_P, Pt, (long)N * KP, (tv ? 1 : 0) | 2, s));
     if (n_rows == 0) return PILOT_OT_OK;
 
     const int n_pairs = n_rows * N;
@@ -412,10 +410,10 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         if (ob > pl->n_cu) ob = pl->n_cu;
         int *split = pl->track_count + 4;
         const int mode = (coop ? 1 : 0) | (solo ? 2 : 0) | ((p.debug & 2) ? 4 : 0);   // bit 2: natural order (experiment)
-        HIP_TRY(f32 ? pilot::launch_order_f32(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, split, pl->track_count + 1, mode, ob, s)
-                    : pilot::launch_order_f64(Pt, N, KP, n_pairs, row_begin, row_step, pl->order_bucket, pl->order_hist,
-                                              pl->order_list, split, pl->track_count + 1, mode, ob, s));
+        HIP_TRY(f32 ? pilot::launch_prep_f32(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, n_rows, row_begin, row_step,
+                                             pl->order_bucket, pl->order_hist, pl->order_list, split, pl->track_count + 1, mode, ob, s)
+                    : pilot::launch_prep_f64(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, n_rows, row_begin, row_step,
+                                             pl->order_bucket, pl->order_hist, pl->order_list, split, pl->track_count + 1, mode, ob, s));
         p.list = pl->order_list;
         if (solo) {
             solo_blocks = (n_rows + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;     // the diagonal; more duplicates queue up

@@ -1034,14 +1034,13 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(Gri
 
 // One-launch setup: Gibbs kernel images in MFMA operand order, first-product table, P converted to T.
 template <class C>
-__global__ void sinkhorn_setup_kernel(const double *__restrict__ Msrc, int K, int RT, double reg,
-                                      typename C::T *__restrict__ img, const double *__restrict__ Psrc,
-                                      typename C::T *__restrict__ Pdst, long n_p, int write_tail) {
+__device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT, double reg,
+                                  typename C::T *__restrict__ img, const double *__restrict__ Psrc,
+                                  typename C::T *__restrict__ Pdst, long n_p, int write_tail, int tid, int nthr) {
     using M = C;
     using T = typename C::T;
     const int KP = RT * M::TILE;
     const int nimg = KP * KP;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
     for (int idx = tid; idx < nimg; idx += nthr) {
         const int lane = idx % WAVE;
         int rest = idx / WAVE;
@@ -1138,27 +1137,27 @@ __device__ inline int lds_count_aggregated(int *counters, int b, bool valid) {
 // (coalesced global reads, conflict-free LDS reads), the row histograms are LDS broadcasts; 2 VALU per |a_k - b_k|.
 constexpr int ORDER_JW = 128, ORDER_RI = 8;
 
-template <typename T>
-__global__ void __launch_bounds__(256) order_bucket_kernel(const T *__restrict__ Pt, int N, int KP, int n_rows, int row_begin,
-                                                           int row_step, unsigned char *__restrict__ bucket,
-                                                           int *__restrict__ hist, int collapse) {
-    // Pt rows are KP long (zero padded, slot order -- L1 is permutation invariant and the padding adds 0)
-    extern __shared__ __attribute__((aligned(16))) unsigned char order_smem[];
-    float *Bt = reinterpret_cast<float *>(order_smem);           // [KP][ORDER_JW + 1]
-    float *Ar = Bt + (size_t)KP * (ORDER_JW + 1);                // [ORDER_RI][KP]
-    int *lh = reinterpret_cast<int *>(Ar + ORDER_RI * KP);       // [ORDER_NB]
+__device__ inline void bucket_body(int tile, const double *__restrict__ Psrc, int N, int K, int n_rows, int row_begin,
+                                   int row_step, unsigned char *__restrict__ bucket, int *__restrict__ hist, int collapse,
+                                   unsigned char *order_smem) {
+    // rows of the caller's N x K proportions (float is plenty for a sort key; L1 does not care about slot order)
+    const int K4 = (K + 3) & ~3;
+    float *Bt = reinterpret_cast<float *>(order_smem);           // [K4][ORDER_JW + 1]
+    float *Ar = Bt + (size_t)K4 * (ORDER_JW + 1);                // [ORDER_RI][K4]
+    int *lh = reinterpret_cast<int *>(Ar + ORDER_RI * K4);       // [ORDER_NB]
     const int n_jb = (N + ORDER_JW - 1) / ORDER_JW;
-    const int jb = (blockIdx.x % n_jb) * ORDER_JW, rb = (blockIdx.x / n_jb) * ORDER_RI;
+    const int jb = (tile % n_jb) * ORDER_JW, rb = (tile / n_jb) * ORDER_RI;
     const int nj = N - jb < ORDER_JW ? N - jb : ORDER_JW;
     const int nr = n_rows - rb < ORDER_RI ? n_rows - rb : ORDER_RI;
     for (int e = threadIdx.x; e < ORDER_NB; e += blockDim.x) lh[e] = 0;
-    for (int e = threadIdx.x; e < nj * KP; e += blockDim.x) {
-        const int row = e / KP, k = e % KP;
-        Bt[k * (ORDER_JW + 1) + row] = float(Pt[(size_t)jb * KP + e]);
+    for (int e = threadIdx.x; e < nj * K; e += blockDim.x) {
+        const int row = e / K, k = e % K;
+        Bt[k * (ORDER_JW + 1) + row] = float(Psrc[(size_t)jb * K + e]);
     }
-    for (int e = threadIdx.x; e < ORDER_RI * KP; e += blockDim.x) {
-        const int r = e / KP, k = e % KP;
-        Ar[e] = r < nr ? float(Pt[(size_t)(row_begin + (rb + r) * row_step) * KP + k]) : 0.f;
+    for (int e = threadIdx.x; e < (K4 - K) * ORDER_JW; e += blockDim.x) Bt[(K + e / ORDER_JW) * (ORDER_JW + 1) + e % ORDER_JW] = 0.f;
+    for (int e = threadIdx.x; e < ORDER_RI * K4; e += blockDim.x) {
+        const int r = e / K4, k = e % K4;
+        Ar[e] = (r < nr && k < K) ? float(Psrc[(size_t)(row_begin + (rb + r) * row_step) * K + k]) : 0.f;
     }
     __syncthreads();
     constexpr int R = ORDER_RI / 2;                               // rows per thread: the two halves of the block split the rows
@@ -1167,13 +1166,13 @@ __global__ void __launch_bounds__(256) order_bucket_kernel(const T *__restrict__
 #pragma unroll
     for (int r = 0; r < R; ++r) l1[r] = 0.f;
     using f4 = float __attribute__((ext_vector_type(4)));
-    for (int k = 0; k < KP; k += 4) {
+    for (int k = 0; k < K4; k += 4) {
         float bv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[e] = Bt[(k + e) * (ORDER_JW + 1) + jl];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const f4 av = *reinterpret_cast<const f4 *>(Ar + (half * R + r) * KP + k);
+            const f4 av = *reinterpret_cast<const f4 *>(Ar + (half * R + r) * K4 + k);
 #pragma unroll
             for (int e = 0; e < 4; ++e) l1[r] += fabsf(av[e] - bv[e]);
         }
@@ -1193,6 +1192,24 @@ __global__ void __launch_bounds__(256) order_bucket_kernel(const T *__restrict__
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ORDER_NB; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// One launch prepares a call: workgroups [0, n_tiles) compute the order keys (bucket_body), the rest build the operand
+// images, tables and the slot-ordered proportions (setup_body).  The two halves are independent.
+constexpr int PREP_SETUP_BLOCKS = 64;
+template <class C>
+__global__ void __launch_bounds__(256) sinkhorn_prep_kernel(const double *__restrict__ Msrc, int K, int RT, double reg,
+                                                            typename C::T *__restrict__ img, const double *__restrict__ Psrc,
+                                                            typename C::T *__restrict__ Pdst, int N, int write_tail, int n_tiles,
+                                                            int n_rows, int row_begin, int row_step,
+                                                            unsigned char *__restrict__ bucket, int *__restrict__ hist, int collapse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char order_smem[];
+    if ((int)blockIdx.x < n_tiles) {
+        bucket_body(blockIdx.x, Psrc, N, K, n_rows, row_begin, row_step, bucket, hist, collapse, order_smem);
+    } else {
+        setup_body<C>(Msrc, K, RT, reg, img, Psrc, Pdst, (long)N * RT * C::TILE, write_tail,
+                      ((int)blockIdx.x - n_tiles) * (int)blockDim.x + (int)threadIdx.x, PREP_SETUP_BLOCKS * (int)blockDim.x);
+    }
 }
 
 // list position of bucket b = (number of items in higher buckets) + a range reserved per workgroup.

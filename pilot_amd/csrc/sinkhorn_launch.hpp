@@ -20,11 +20,13 @@ hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const Gri
 // helpers
 hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p);
 hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p);
-hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s);
-hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s);
-hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s);
-hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s);
+// one call's preparation: operand images + tables + slot-ordered proportions and the longest-first order keys in one
+// launch (sinkhorn_prep_kernel), then the scatter.  mode: bit 0 cooperative head, bit 1 solo duplicates, bit 2 natural order.
+hipError_t launch_prep_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s);
+hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s);
 
 }  // namespace pilot

@@ -51,12 +51,28 @@ template <class C> hipError_t value_any(int RT, dim3 grid, hipStream_t s, const 
     default: return hipErrorInvalidValue;
     }
 }
+// prepare a call: operand images / tables / slot-ordered proportions + the longest-first order keys, then the scatter
 template <class C>
-hipError_t setup_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail,
-                     hipStream_t s) {
+hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                    int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                    int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
     using T = typename C::T;
-    hipLaunchKernelGGL(sinkhorn_setup_kernel<C>, dim3(64), dim3(256), 0, s, M, K, RT, reg, static_cast<T *>(img), P,
-                       static_cast<T *>(Pslot), n_p, write_tail);
+    const int collapse = (mode >> 2) & 1;    // bit 2: no longest-first order (experiment switch)
+    const int tiles = n_rows > 0 ? ((N + ORDER_JW - 1) / ORDER_JW) * ((n_rows + ORDER_RI - 1) / ORDER_RI) : 0;
+    const int K4 = (K + 3) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)K4 * (ORDER_JW + 1) + (size_t)ORDER_RI * K4) + sizeof(int) * ORDER_NB;
+    static bool attr_set = false;     // more than 64 KB of dynamic LDS (K > 112) needs the opt-in; once per process
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sinkhorn_prep_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sinkhorn_prep_kernel<C>, dim3(tiles + PREP_SETUP_BLOCKS), dim3(256), lds, s, M, K, RT, reg, static_cast<T *>(img), P,
+                       static_cast<T *>(Pslot), N, write_tail, tiles, n_rows, row_begin, row_step, bucket, hist, collapse);
+    if (n_rows > 0)
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_rows * N, hist, hist + ORDER_NB, list, split,
+                           main_queue_head, mode & 3);
     return hipGetLastError();
 }
 template <class C, int RT, bool SYM, int TV = 0>
@@ -80,27 +96,6 @@ hipError_t coop_any(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams
     default: return hipErrorInvalidValue;
     }
 }
-template <typename T>
-hipError_t order_any(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket, int *hist,
-                     int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
-    const int collapse = (coop_enabled >> 2) & 1;    // bit 2: no longest-first order (experiment switch)
-    const int n_rows = n_items / N;
-    const int tiles = ((N + ORDER_JW - 1) / ORDER_JW) * ((n_rows + ORDER_RI - 1) / ORDER_RI);
-    const size_t lds = sizeof(float) * ((size_t)KP * (ORDER_JW + 1) + (size_t)ORDER_RI * KP) + sizeof(int) * ORDER_NB;
-    static bool attr_set = false;     // more than 64 KB of dynamic LDS (K > 112) needs the opt-in; once per process
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(order_bucket_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((order_bucket_kernel<T>), dim3(tiles), dim3(256), lds, s, static_cast<const T *>(Pslot), N, KP, n_rows,
-                       row_begin, row_step, bucket, hist, collapse);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_items, hist, hist + ORDER_NB, list, split,
-                       main_queue_head, coop_enabled & 3);
-    return hipGetLastError();
-}
-
 }  // namespace
 
 #if SK_PART == 0
@@ -108,12 +103,11 @@ hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds
     return stream_any<CfgF32x16>(RT, sym, track, grid, lds, s, p);
 }
 hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF32x16>(RT, grid, s, p); }
-hipError_t launch_setup_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s) {
-    return setup_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, n_p, write_tail, s);
-}
-hipError_t launch_order_f32(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
-    return order_any<float>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, main_queue_head, coop_enabled, n_blocks, s);
+hipError_t launch_prep_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
+    return prep_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
 }
 hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16>(RT, sym, n_wgs, s, p); }
 #define PILOT_TV_DECL(NAME) \
@@ -134,12 +128,11 @@ hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds
     return stream_any<CfgF64x16>(RT, sym, track, grid, lds, s, p);
 }
 hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF64x16>(RT, grid, s, p); }
-hipError_t launch_setup_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, long n_p, int write_tail, hipStream_t s) {
-    return setup_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, n_p, write_tail, s);
-}
-hipError_t launch_order_f64(const void *Pslot, int N, int KP, int n_items, int row_begin, int row_step, unsigned char *bucket,
-                            int *hist, int *list, int *split, int *main_queue_head, int coop_enabled, int n_blocks, hipStream_t s) {
-    return order_any<double>(Pslot, N, KP, n_items, row_begin, row_step, bucket, hist, list, split, main_queue_head, coop_enabled, n_blocks, s);
+hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
+    return prep_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
 }
 hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF64x16>(RT, sym, n_wgs, s, p); }
 #else
