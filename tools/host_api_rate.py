@@ -11,8 +11,9 @@ engine.sinkhorn_grid(P, M, 0.1)
 for name, fn in (("sinkhorn reg=0.1 f32 (host API)", lambda: engine.sinkhorn_grid(P, M, 0.1)),
                  ("sinkhorn reg=0.1 f64 (host API)", lambda: engine.sinkhorn_grid(P, M, 0.1, precision="fp64")),
                  ("exact EMD (host API, mirror)", lambda: engine.emd_grid(P, M))):
-    fn()
-    t = time.perf_counter(); reps = 5
+    t = time.perf_counter()
+    while time.perf_counter() - t < 1.0: fn()      # first calls run 10x slower (allocation, clocks ramping up on an idle box)
+    t = time.perf_counter(); reps = 10
     for _ in range(reps): fn()
     dt = (time.perf_counter() - t) / reps
     print("%-36s %.3f ms per matrix  %.3e pairs/s" % (name, dt * 1e3, N * N / dt))
