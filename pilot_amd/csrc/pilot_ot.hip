@@ -347,7 +347,9 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         const int n_tail = K - (RT - 1) * TILE;
         // (RT = 8 variants spill: left on the MFMA path)
         if (RT >= 2 && RT <= 7 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
-        if (tv) lds += (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * ts;
+        const size_t tail_lds = (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * ts;
+        if (tv && lds + tail_lds > LDS_BYTES) tv = 0;       // the weights do not fit beside the images: MFMA path
+        if (tv) lds += tail_lds;
     }
     if (lds > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision", K, lds,
@@ -506,7 +508,13 @@ struct HostCtx {
     size_t n_out = 0;
     double *dP = nullptr, *dM = nullptr, *dE = nullptr, *dErr = nullptr;
     int *dIt = nullptr, *dFl = nullptr;
+    // pinned staging of the results: a D2H copy straight into the caller's pageable arrays makes the driver pin and
+    // unpin them on every call (measured: 2 ms -> 25 ms per c3 matrix whenever numpy hands out fresh pages)
+    unsigned char *pin = nullptr;
+    size_t pin_bytes = 0;
     void release() {
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr; pin_bytes = 0;
         if (dP) (void)hipFree(dP);
         if (dM) (void)hipFree(dM);
         if (dE) (void)hipFree(dE);
@@ -547,6 +555,43 @@ int host_ctx_prepare(int N, int K, size_t n_out) {
         if (e != hipSuccess) { h.release(); return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e)); }
         h.n_out = n_out;
     }
+    const size_t need = n_out * (2 * sizeof(double) + 2 * sizeof(int)) + 4 * 64;
+    if (need > h.pin_bytes) {
+        if (h.pin) (void)hipHostFree(h.pin);
+        h.pin = nullptr; h.pin_bytes = 0;
+        if (hipHostMalloc(reinterpret_cast<void **>(&h.pin), need, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h.pin = nullptr;               // no pinned memory: fall back to direct copies
+        } else {
+            h.pin_bytes = need;
+        }
+    }
+    return PILOT_OT_OK;
+}
+
+// device results -> caller's arrays through the pinned staging block (one stream sync for all of them)
+struct Fetch { void *dst; const void *src; size_t bytes; };
+int host_fetch(const Fetch *f, int n) {
+    HostCtx &h = g_host;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (!h.pin) {
+        for (int i = 0; i < n; ++i)
+            if (f[i].dst) HIP_TRY(hipMemcpy(f[i].dst, f[i].src, f[i].bytes, hipMemcpyDeviceToHost));
+        return PILOT_OT_OK;
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!f[i].dst) continue;
+        HIP_TRY(hipMemcpyAsync(h.pin + off, f[i].src, f[i].bytes, hipMemcpyDeviceToHost, nullptr));
+        off += (f[i].bytes + 63) & ~(size_t)63;
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!f[i].dst) continue;
+        memcpy(f[i].dst, h.pin + off, f[i].bytes);
+        off += (f[i].bytes + 63) & ~(size_t)63;
+    }
     return PILOT_OT_OK;
 }
 }  // namespace
@@ -583,13 +628,9 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
                                     f32_floor_ulps, cost_is_symmetric, row_begin, row_end, row_step, h.dE,
                                     iters ? h.dIt : nullptr, err ? h.dErr : nullptr, h.dFl, nullptr);
     if (rc != PILOT_OT_OK) return rc;
-    e = hipStreamSynchronize(nullptr);
-    if (e == hipSuccess) e = hipMemcpy(emd, h.dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && iters) e = hipMemcpy(iters, h.dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && err) e = hipMemcpy(err, h.dErr, sizeof(double) * n_out, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && flags) e = hipMemcpy(flags, h.dFl, sizeof(int) * n_out, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
-    return PILOT_OT_OK;
+    const Fetch f[4] = {{emd, h.dE, sizeof(double) * n_out}, {iters, h.dIt, sizeof(int) * n_out},
+                        {err, h.dErr, sizeof(double) * n_out}, {flags, h.dFl, sizeof(int) * n_out}};
+    return host_fetch(f, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,11 +700,8 @@ PILOT_API int pilot_ot_emd_grid(const double *P, int N, int K, const double *M, 
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
     rc = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, mode, row_begin, row_end, row_step, h.dE, h.dIt, nullptr);
     if (rc != PILOT_OT_OK) return rc;
-    e = hipStreamSynchronize(nullptr);
-    if (e == hipSuccess) e = hipMemcpy(emd, h.dE, sizeof(double) * n_out, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && n_aug) e = hipMemcpy(n_aug, h.dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "kernel execution / copy-back failed: %s", hipGetErrorString(e));
-    return PILOT_OT_OK;
+    const Fetch f[2] = {{emd, h.dE, sizeof(double) * n_out}, {n_aug, h.dIt, sizeof(int) * n_out}};
+    return host_fetch(f, 2);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -49,17 +49,20 @@ def sinkhorn_grid(P, M, reg, num_iter_max=NUM_ITER_MAX, stop_thr=STOP_THR, tau=T
         raise ValueError("precision must be one of %s" % sorted(_lib.PREC))
     row_end = N if row_end is None else int(row_end)
     n_rows = n_rows_of(N, row_begin, row_end, row_step)
-    emd = np.zeros((n_rows, N), dtype=np.float64)
-    iters = np.zeros((n_rows, N), dtype=np.int32)
-    err = np.zeros((n_rows, N), dtype=np.float64)
-    flags = np.zeros((n_rows, N), dtype=np.int32)
+    emd = np.empty((n_rows, N), dtype=np.float64)
     L = _lib.load()
     sym = int(np.array_equal(M, M.T))
+    if return_info:
+        iters = np.empty((n_rows, N), dtype=np.int32)
+        err = np.empty((n_rows, N), dtype=np.float64)
+        flags = np.empty((n_rows, N), dtype=np.int32)
+        pi, pe, pf = _lib.iptr(iters), _lib.dptr(err), _lib.iptr(flags)
+    else:                                  # only the matrix travels back
+        pi = pe = pf = None
     _lib.check(L.pilot_ot_sinkhorn_grid(
         _lib.dptr(P), N, K, _lib.dptr(M), float(reg), int(num_iter_max), float(stop_thr), float(tau),
         int(check_period), _lib.PREC[precision], float(f32_floor_ulps), sym,
-        int(row_begin), row_end, int(row_step),
-        _lib.dptr(emd), _lib.iptr(iters), _lib.dptr(err), _lib.iptr(flags)))
+        int(row_begin), row_end, int(row_step), _lib.dptr(emd), pi, pe, pf))
     if return_info:
         return emd, dict(iters=iters, err=err, flags=flags)
     return emd

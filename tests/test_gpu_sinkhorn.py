@@ -100,6 +100,47 @@ def test_nonsymmetric_cost(prec, tol):
     assert np.abs(Eg - Eo).max() <= tol
 
 
+@pytest.mark.parametrize("K", [34, 67])
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("fp64", TOL64)])
+def test_nonsymmetric_cost_with_tail_rows(K, prec, tol):
+    """K mod 16 <= 4 puts the last row-tile on the VALU (tail_rows); a non-symmetric cost uses the second weight form
+    and (small grid, no solo waves) the cooperative kernel."""
+    rng = np.random.default_rng(K)
+    P, _ = make_problem(23, K, 6, seed=K, cells_per_patient=300)
+    M = rng.random((K, K))
+    M /= M.max()
+    Eo = O.sinkhorn_grid(P, M, 0.3, n_threads=16)
+    Eg = engine.sinkhorn_grid(P, M, 0.3, precision=prec)
+    assert np.abs(Eg - Eo).max() <= tol
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("fp64", TOL64)])
+def test_duplicate_patients_take_the_solo_path(prec, tol, monkeypatch):
+    """Pairs with a == b bit for bit (the diagonal AND duplicate patients) are solved one per wavefront; more duplicates
+    than rows must queue up, row shards must reproduce the full matrix, and switching the path off must agree within
+    the tolerance (different summation order, same iteration)."""
+    P, M = make_problem(30, 50, 6, seed=77, cells_per_patient=300)
+    P[[5, 12, 20]] = P[0]
+    P[29] = P[3]
+    Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.1, precision=prec, return_info=True)
+    assert np.abs(Eg - Eo).max() <= tol
+    if prec == "fp64":
+        np.testing.assert_array_equal(ig["iters"], io["iters"])
+    for r in (0, 5, 29):                                       # one-row shards: 4 (resp. 2) duplicates on one solo workgroup
+        part = engine.sinkhorn_grid(P, M, 0.1, precision=prec, row_begin=r, row_end=r + 1)
+        np.testing.assert_array_equal(part[0], Eg[r])
+    monkeypatch.setenv("PILOT_OT_DEBUG", "512")
+    Eoff = engine.sinkhorn_grid(P, M, 0.1, precision=prec)
+    monkeypatch.delenv("PILOT_OT_DEBUG")
+    dup = np.zeros((30, 30), dtype=bool)
+    for grp in ([0, 5, 12, 20], [3, 29]):
+        dup[np.ix_(grp, grp)] = True
+    dup |= np.eye(30, dtype=bool)
+    np.testing.assert_array_equal(Eoff[~dup], Eg[~dup])        # everything else is the same code path, bit for bit
+    assert np.abs(Eoff - Eg).max() <= tol
+
+
 def test_row_selection_and_single_row_grids():
     P, M = make_problem(**CONFIGS["c2"])
     full = engine.sinkhorn_grid(P, M, 0.1, precision="fp64")
