@@ -18,6 +18,17 @@ def test_device_is_gfx950():
     assert "gfx950" in _lib.device_name()
 
 
+def test_pot_docstring_known_answers_through_the_c_abi():
+    """ot.sinkhorn2([.5, .5], [.5, .5], [[0, 1], [1, 0]], 1) = 0.26894142 and ot.emd2(...) = 0.0 (POT docstrings)."""
+    P = np.array([[0.5, 0.5], [0.5, 0.5], [1.0, 0.0], [0.0, 1.0]])
+    M = np.array([[0.0, 1.0], [1.0, 0.0]])
+    for prec, tol in (("fp32", 1e-6), ("fp64", 5e-9)):
+        E = engine.sinkhorn_grid(P, M, 1.0, precision=prec)
+        assert abs(E[0, 1] - 0.26894142) < tol and abs(E[0, 0] - 0.26894142) < tol
+    X = engine.emd_grid(P, M)
+    assert X[0, 1] == 0.0 and X[2, 3] == 1.0 and X[3, 2] == 1.0 and X[2, 2] == 0.0
+
+
 @pytest.mark.parametrize("cfg,step", [("c1", 1), ("c2", 5), ("c3", 40)])
 @pytest.mark.parametrize("reg", [1.0, 0.1])
 def test_parity_f32_and_f64(cfg, step, reg):

@@ -1,7 +1,7 @@
 """The Sinkhorn oracle (oracle/pilot_oracle.c) against independent evidence.  CPU only.
 
-POT itself cannot be run here ("parity unpinned"); what is pinned: converged values against an
-independent log-domain fixed point (unique entropic optimum), POT's documented control flow
+POT itself cannot be run here ("parity unpinned"); what is pinned: POT's own docstring example, converged values
+against an independent log-domain fixed point (unique entropic optimum), POT's documented control flow
 (check every 20 updates, v-first, cap), and the committed golden numbers."""
 import numpy as np
 import pytest
@@ -9,6 +9,23 @@ import pytest
 from conftest import GOLDEN_CASES, load_golden
 from oracle import oracle as O
 from pilot_amd.synthetic import CONFIGS, make_problem
+
+
+def test_pot_docstring_known_answers():
+    """The only numbers POT itself publishes for this path: the example in the docstrings of ot.sinkhorn /
+    ot.bregman.sinkhorn_stabilized / ot.sinkhorn2 (a = b = [.5, .5], M = [[0, 1], [1, 0]], reg = 1: plan
+    [[0.36552929, 0.13447071], [0.13447071, 0.36552929]], sinkhorn2 = 0.26894142) and of ot.emd / ot.emd2 on the same
+    inputs (plan diag(.5, .5), cost 0.0).  Printed to 8 digits there."""
+    a = np.array([0.5, 0.5])
+    M = np.array([[0.0, 1.0], [1.0, 0.0]])
+    val, info = O.sinkhorn2(a, a, M, 1.0, return_info=True)
+    assert info["flags"] & O.FLAG_CONVERGED
+    assert abs(val - 0.26894142) < 5e-9
+    assert abs(val - 2 * 0.13447071) < 2e-8
+    assert O.emd2(a, a, M) == 0.0
+    # the documented asymmetric case of ot.emd2's tests (test_ot.py::test_emd_1d_emd2_1d analogue on a line): cost of
+    # moving [1, 0] to [0, 1] with unit distance is exactly 1
+    assert O.emd2(np.array([1.0, 0.0]), np.array([0.0, 1.0]), M) == 1.0
 
 
 def test_converged_pairs_match_independent_logdomain_solver():
