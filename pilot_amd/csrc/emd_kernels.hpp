@@ -3,7 +3,8 @@
 //
 // POT solves each K x K transportation LP with a LEMON-derived network simplex on the CPU.  The LP
 // optimum VALUE is unique, so any exact algorithm returns the same number up to rounding; on the
-// GPU the problem is solved by successive shortest augmenting paths with node potentials
+// GPU the problem is solved by successive shortest augmenting paths (multi-source: from any row with supply left
+// to any column with demand left) with node potentials
 // (complementary slackness is kept after every augmentation, so the final flow is optimal):
 //   * lane l owns row l and column l (and l+64 when K > 64): supplies/demands, potentials, Dijkstra
 //     labels and predecessor links live in registers;
@@ -172,140 +173,191 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
         if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         int n_aug = 0;
+#ifdef EMD_COUNT_STEPS
+        int n_steps = 0;
+#endif
         const int aug_guard = 64 * K + 64;   // far above the O(K) augmentations SSP needs; bounds every loop
         bool tripped = false;
         int trip_code = 0;
         const unsigned long long t_start = wall_clock64();
         const unsigned long long watchdog_ticks = 400000000ull;  // 4 s of the 100 MHz constant clock per pair
 
-        for (int s = 0; s < K && !tripped; ++s) {
-            const int se = s / 64, sl = s % 64;
-            for (;;) {
-                double ra_s = 0.0;
+        // One augmentation per round: shortest path from ANY row that still has supply to ANY column that still has
+        // demand (multi-source Dijkstra on the reduced costs).  All source rows are relaxed up front without an arg-min
+        // each; the search then usually pops a demand column within a few steps.
+        for (;;) {
+            unsigned long long srcmask[NK];
+            bool any_src = false;
 #pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == se) ra_s = rl_f64(ra[e], sl);
-                if (!(ra_s > tol)) break;
-                if (n_aug > aug_guard) { tripped = true; trip_code = 5; break; }
+            for (int e = 0; e < NK; ++e) {
+                srcmask[e] = __ballot(lane + 64 * e < K && ra[e] > tol);
+                any_src = any_src || srcmask[e] != 0ull;
+            }
+            if (!any_src) break;
+            if (n_aug > aug_guard) { tripped = true; trip_code = 5; break; }
+            if ((n_aug & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
 #pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    dR[e] = INF; dC[e] = INF; parR[e] = -1; parC[e] = -1;
-                    doneR[e] = false; doneC[e] = false;
-                    if (lane + 64 * e == s) dR[e] = 0.0;
-                }
-                int target = -1;
-                double dstar = 0.0;
-                for (int step = 0;; ++step) {
-                    if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: one node is scanned per step
-                    if ((step & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
-                    // arg-min over the unscanned labels of all rows and columns
-                    double best = INF;
-                    int code = -1;  // node id: rows 0..K-1, columns 128..128+K-1
+            for (int e = 0; e < NK; ++e) {
+                const bool src = ra[e] > tol && lane + 64 * e < K;
+                dR[e] = src ? 0.0 : INF; dC[e] = INF; parR[e] = -1; parC[e] = -1;
+                doneR[e] = src; doneC[e] = false;
+            }
 #pragma unroll
-                    for (int e = 0; e < NK; ++e) {
-                        const int idx = lane + 64 * e;
+            for (int e = 0; e < NK; ++e) {
+                unsigned long long m = srcmask[e];
+                while (m) {                                        // wave-uniform
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const int in = l + 64 * e;
+                    const double pu_i = rl_f64(pu[e], l);
+#pragma unroll
+                    for (int e2 = 0; e2 < NK; ++e2) {
+                        const int idx = lane + 64 * e2;
                         if (idx < K) {
-                            if (!doneR[e] && dR[e] < best) { best = dR[e]; code = idx; }
-                            if (!doneC[e] && dC[e] < best) { best = dC[e]; code = 128 + idx; }
+                            double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e2];
+                            rc = rc < 0.0 ? 0.0 : rc;
+                            if (rc < dC[e2]) { dC[e2] = rc; parC[e2] = in; }
                         }
                     }
-                    const double bd = uni_f64(wave_min_f64(best));
-                    if (!(bd < INF)) break;                        // nothing reachable: only rounding dust left
-                    const unsigned long long holders = __ballot(best == bd && code >= 0);
-                    const int win = uni_i32(__builtin_ctzll(holders));
-                    const int node = rl_i32(code, win);
-                    if (node >= 128) {                              // a column
-                        const int jn = node - 128, je = jn / 64, jl = jn % 64;
-                        double rb_j = 0.0;
+                }
+            }
+            int target = -1;
+            double dstar = 0.0;
+            for (int step = 0;; ++step) {
+                if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: one node is scanned per step
+#ifdef EMD_COUNT_STEPS
+                ++n_steps;
+#endif
+                // smallest unscanned label; ALL nodes that carry it are final and are scanned in this one step (after the
+                // first augmentations most arcs around the sources are tight, so dozens of nodes tie at the same label)
+                double best = INF;
 #pragma unroll
-                        for (int e = 0; e < NK; ++e) {
-                            if (e == je) { rb_j = rl_f64(rb[e], jl); if (lane == jl) doneC[e] = true; }
-                        }
-                        if (rb_j > 0.0) { target = jn; dstar = bd; break; }
-                        // backward arcs jn -> i for rows currently shipping to jn (reduced cost 0)
+                for (int e = 0; e < NK; ++e) {
+                    const int idx = lane + 64 * e;
+                    if (idx < K) {
+                        if (!doneC[e] && dC[e] < best) best = dC[e];
+                        if (!doneR[e] && dR[e] < best) best = dR[e];
+                    }
+                }
+                const double bd = uni_f64(wave_min_f64(best));
+                if (!(bd < INF)) break;                        // nothing reachable: only rounding dust left
+                unsigned long long tieC[NK], tieR[NK];
+                bool found = false;
 #pragma unroll
-                        for (int e = 0; e < NK; ++e) {
-                            const int idx = lane + 64 * e;
-                            if (idx < K && !doneR[e]) {
+                for (int e = 0; e < NK; ++e) {
+                    const bool tc = lane + 64 * e < K && !doneC[e] && dC[e] == bd;
+                    tieC[e] = __ballot(tc);
+                    const unsigned long long dm = __ballot(tc && rb[e] > 0.0);    // a column with demand left: done
+                    if (dm && !found) { target = __builtin_ctzll(dm) + 64 * e; dstar = bd; found = true; }
+                    if (tc) doneC[e] = true;
+                }
+                if (found) break;
+                // columns: backward arcs jn -> i for rows currently shipping to jn (reduced cost 0)
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    unsigned long long m = tieC[e];
+                    while (m) {                                    // wave-uniform
+                        const int jn = __builtin_ctzll(m) + 64 * e;
+                        m &= m - 1ull;
+#pragma unroll
+                        for (int e2 = 0; e2 < NK; ++e2) {
+                            const int idx = lane + 64 * e2;
+                            if (idx < K && !doneR[e2]) {
                                 const double f = FT[(size_t)jn * K + idx];
-                                if (f > 0.0 && bd < dR[e]) { dR[e] = bd; parR[e] = jn; }
+                                if (f > 0.0 && bd < dR[e2]) { dR[e2] = bd; parR[e2] = jn; }
                             }
                         }
-                    } else {                                        // a row: forward arcs to every column
-                        const int in = node, ie = in / 64, il = in % 64;
-                        double pu_i = 0.0;
+                    }
+                }
+                // rows (including the ones that just got this label): forward arcs to every column
 #pragma unroll
-                        for (int e = 0; e < NK; ++e) {
-                            if (e == ie) { pu_i = rl_f64(pu[e], il); if (lane == il) doneR[e] = true; }
-                        }
+                for (int e = 0; e < NK; ++e) {
+                    const bool tr = lane + 64 * e < K && !doneR[e] && dR[e] == bd;
+                    tieR[e] = __ballot(tr);
+                    if (tr) doneR[e] = true;
+                }
 #pragma unroll
-                        for (int e = 0; e < NK; ++e) {
-                            const int idx = lane + 64 * e;
-                            if (idx < K && !doneC[e]) {
-                                double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e];
+                for (int e = 0; e < NK; ++e) {
+                    unsigned long long m = tieR[e];
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const int in = l + 64 * e;
+                        const double pu_i = rl_f64(pu[e], l);
+#pragma unroll
+                        for (int e2 = 0; e2 < NK; ++e2) {
+                            const int idx = lane + 64 * e2;
+                            if (idx < K && !doneC[e2]) {
+                                double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e2];
                                 rc = rc < 0.0 ? 0.0 : rc;
                                 const double nd = bd + rc;
-                                if (nd < dC[e]) { dC[e] = nd; parC[e] = in; }
+                                if (nd < dC[e2]) { dC[e2] = nd; parC[e2] = in; }
                             }
                         }
                     }
                 }
-                if (tripped) break;
-                if (target < 0) {   // numerically exhausted: drop the dust (<= tol-scale mass)
-#pragma unroll
-                    for (int e = 0; e < NK; ++e) if (lane + 64 * e == s) ra[e] = 0.0;
-                    break;
-                }
-                // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the path
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    pu[e] -= dR[e] < dstar ? dR[e] : dstar;
-                    pv[e] += dC[e] < dstar ? dC[e] : dstar;
-                }
-                // bottleneck along target <- ... <- s
-                double delta = ra_s;
-                {
-                    double rb_t = 0.0;
-#pragma unroll
-                    for (int e = 0; e < NK; ++e) if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
-                    delta = uni_f64(rb_t < delta ? rb_t : delta);
-                }
-                for (int j = target, hop = 0;; ++hop) {
-                    if (hop > K + 1 || j < 0) { tripped = true; trip_code = 2; break; }
-                    int i = 0;
-#pragma unroll
-                    for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
-                    if (i == s) break;
-                    if (i < 0) { tripped = true; trip_code = 3; break; }
-                    int jb = 0;
-#pragma unroll
-                    for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
-                    if (jb < 0) { tripped = true; trip_code = 4; break; }
-                    const double f = uni_f64(FT[(size_t)jb * K + i]);
-                    delta = f < delta ? f : delta;
-                    j = jb;
-                }
-                if (tripped) break;
-                for (int j = target;;) {
-                    int i = 0;
-#pragma unroll
-                    for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
-                    if (lane == 0) FT[(size_t)j * K + i] += delta;
-                    if (i == s) break;
-                    int jb = 0;
-#pragma unroll
-                    for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
-                    if (lane == 0) FT[(size_t)jb * K + i] -= delta;
-                    j = jb;
-                }
-                if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    if (lane + 64 * e == s) ra[e] -= delta;
-                    if (lane + 64 * e == target) rb[e] -= delta;
-                }
-                ++n_aug;
             }
+            if (tripped) break;
+            if (target < 0) {   // numerically exhausted: drop the dust (<= tol-scale mass) of every remaining source
+#pragma unroll
+                for (int e = 0; e < NK; ++e) ra[e] = 0.0;
+                break;
+            }
+            // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the path
+#pragma unroll
+            for (int e = 0; e < NK; ++e) {
+                pu[e] -= dR[e] < dstar ? dR[e] : dstar;
+                pv[e] += dC[e] < dstar ? dC[e] : dstar;
+            }
+            // bottleneck along target <- ... <- source row (the first row on the way back that has no predecessor)
+            double delta = 0.0;
+            {
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == target / 64) delta = rl_f64(rb[e], target % 64);
+                delta = uni_f64(delta);
+            }
+            int src_row = -1;
+            for (int j = target, hop = 0;; ++hop) {
+                if (hop > K + 1 || j < 0) { tripped = true; trip_code = 2; break; }
+                int i = 0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
+                if (i < 0) { tripped = true; trip_code = 3; break; }
+                int jb = 0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
+                if (jb < 0) { src_row = i; break; }              // a source row
+                const double f = uni_f64(FT[(size_t)jb * K + i]);
+                delta = f < delta ? f : delta;
+                j = jb;
+            }
+            if (tripped) break;
+            {
+                double ra_s = 0.0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == src_row / 64) ra_s = rl_f64(ra[e], src_row % 64);
+                delta = uni_f64(ra_s < delta ? ra_s : delta);
+            }
+            for (int j = target;;) {
+                int i = 0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
+                if (lane == 0) FT[(size_t)j * K + i] += delta;
+                if (i == src_row) break;
+                int jb = 0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
+                if (lane == 0) FT[(size_t)jb * K + i] -= delta;
+                j = jb;
+            }
+            if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < NK; ++e) {
+                if (lane + 64 * e == src_row) ra[e] -= delta;
+                if (lane + 64 * e == target) rb[e] -= delta;
+            }
+            ++n_aug;
         }
         double cost = 0.0;
         for (int t = lane; t < K * K; t += 64) {
@@ -315,7 +367,11 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
         cost = uni_f64(wave_sum_f64(cost));
         if (lane == 0) {
             p.emd[q] = tripped ? __builtin_nan("") : cost;
+#ifdef EMD_COUNT_STEPS
+            if (p.n_aug) p.n_aug[q] = n_steps;
+#else
             if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;
+#endif
         }
     }
 }
