@@ -11,8 +11,7 @@
 //   * one Dijkstra step = wave-wide arg-min over the unscanned labels (xor-shuffle reduction) and ONE
 //     parallel relaxation: a scanned row relaxes all K columns at once (row of M from LDS, coalesced),
 //     a scanned column relaxes all rows that currently ship to it (column of the flow matrix);
-//   * the flow matrix is stored column-major so that column scans are conflict-free; it lives in LDS
-//     for K <= 64 and in an L2-resident global slab per wave above that;
+//   * flow values in an L2-resident global slab per wave, flow support as bit masks in registers (see below);
 //   * path tracing / bottleneck / flow update walk the predecessor links with wave-uniform indices
 //     (v_readlane), touching one flow entry per hop.
 // All arithmetic is fp64 like POT's.
@@ -21,7 +20,6 @@
 
 namespace pilot {
 
-constexpr int EMD_MAX_WAVES_PER_WG = 16;
 
 struct EmdParams {
     const double *P;    // N x K
@@ -101,30 +99,41 @@ __device__ inline double wave_sum_f64(double x) {
     return x;
 }
 
-// NK = rows/columns per lane (1: K <= 64, 2: K <= 128).  F_IN_LDS: flow matrix in LDS, else global slab.
-template <int NK, bool F_IN_LDS>
-__global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(EmdParams p) {
+// lane-indexed scalar helpers for the path registers
+__device__ inline int wl_i32(int old, int value, int lane) { return (int)(threadIdx.x % 64) == lane ? value : old; }
+
+// NK = rows/columns per lane (1: K <= 64, 2: K <= 128).
+//   * the cost matrix M and its row minima live in LDS (shared by the workgroup);
+//   * the flow VALUES live in an L2-resident global slab of K*K doubles per resident wave (row-major, zeroed per pair) and
+//     are touched only along augmenting paths and for the final cost;
+//   * the flow SUPPORT lives in registers: lane i keeps a bit mask of the columns row i currently ships to, so "which
+//     rows ship to the columns being scanned" is one 64-bit AND against the ballot mask of those columns.
+// Nothing per wave is in LDS, so occupancy is bounded by registers only (the step loop is pure latency).
+constexpr int EMD_WAVES = 8;
+
+template <int NK>
+__global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    double *Msh = reinterpret_cast<double *>(smem_raw);  // K*K (only when F_IN_LDS; else M is read from global/L2)
-    const double *Mrd;
-    double *FT;                                          // column-major flows: FT[j*K + i] = F[i][j]
-    if constexpr (F_IN_LDS) {
-        for (int t = threadIdx.x; t < K * K; t += blockDim.x) Msh[t] = p.M[t];
-        __syncthreads();
-        Mrd = Msh;
-        FT = Msh + (size_t)K * K + (size_t)wave * K * K;
-    } else {
-        Mrd = p.M;
-        FT = p.f_slab + ((size_t)blockIdx.x * (blockDim.x / 64) + wave) * K * K;
+    double *Msh = reinterpret_cast<double *>(smem_raw);   // K*K
+    double *rowmin = Msh + (size_t)K * K;                 // K: min_j M_ij (initial row potentials)
+    for (int t = threadIdx.x; t < K * K; t += blockDim.x) Msh[t] = p.M[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        double m = __builtin_inf();
+        for (int j = 0; j < K; ++j) { const double v = Msh[(size_t)i * K + j]; m = v < m ? v : m; }
+        rowmin[i] = m;
     }
+    __syncthreads();
+    const double *Mrd = Msh;
+    double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
     const double INF = __builtin_inf();
     const long total = (long)p.n_rows * N;
 
     // pairs are dealt round-robin to the resident waves (wave-uniform loop bounds)
-    const long n_waves = (long)gridDim.x * (blockDim.x / 64);
-    const long first = uni_i32(blockIdx.x * (blockDim.x / 64) + wave);
+    const long n_waves = (long)gridDim.x * EMD_WAVES;
+    const long first = uni_i32(blockIdx.x * EMD_WAVES + wave);
     for (long q = first; q < total; q += n_waves) {
         const int r = (int)(q / N), j_s = (int)(q % N);
         const int i_s = p.row_begin + r * p.row_step;
@@ -133,6 +142,7 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
         double pu[NK], pv[NK], ra[NK], rb[NK], dR[NK], dC[NK];
         int parR[NK], parC[NK];
         bool doneR[NK], doneC[NK];
+        unsigned long long ship[NK][NK];           // ship[e][w] bit b: row (lane + 64e) ships to column 64w + b
         // POT pre-step: b *= sum(a) / sum(b)   (ot/lp/__init__.py::emd2)
         double sa = 0.0, sb = 0.0;
 #pragma unroll
@@ -145,19 +155,7 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
         sa = uni_f64(wave_sum_f64(sa)); sb = uni_f64(wave_sum_f64(sb));
         const double scale = sa / sb;
         const double tol = 1e-15 * (sa > 0.0 ? sa : 1.0);
-#pragma unroll
-        for (int e = 0; e < NK; ++e) {
-            const int idx = lane + 64 * e;
-            rb[e] *= scale;
-            pv[e] = 0.0;
-            double m = INF;   // pu_i = min_j M_ij keeps every reduced cost >= 0 at the start
-            if (idx < K)
-                for (int j = 0; j < K; ++j) { const double v = Mrd[(size_t)idx * K + j]; m = v < m ? v : m; }
-            pu[e] = idx < K ? m : 0.0;
-        }
-        for (int t = lane; t < K * K; t += 64) FT[t] = 0.0;
-        if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < K * K; t += 64) F[t] = 0.0;
         // warm start: wherever the diagonal arc (i, i) has zero reduced cost (always, for a metric-like cost with a
         // zero diagonal) ship min(a_i, b_i) along it.  Flow only on zero-reduced-cost arcs keeps complementary
         // slackness, so the augmenting-path phase continues from an optimal partial flow and only has to move the
@@ -165,12 +163,17 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
 #pragma unroll
         for (int e = 0; e < NK; ++e) {
             const int idx = lane + 64 * e;
+            rb[e] *= scale;
+            pv[e] = 0.0;
+            pu[e] = idx < K ? rowmin[idx] : 0.0;   // pu_i = min_j M_ij keeps every reduced cost >= 0 at the start
+#pragma unroll
+            for (int w = 0; w < NK; ++w) ship[e][w] = 0ull;
             if (idx < K && Mrd[(size_t)idx * K + idx] - pu[e] == 0.0) {
                 const double f = ra[e] < rb[e] ? ra[e] : rb[e];
-                if (f > 0.0) { FT[(size_t)idx * K + idx] = f; ra[e] -= f; rb[e] -= f; }
+                if (f > 0.0) { F[(size_t)idx * K + idx] = f; ship[e][e] = 1ull << lane; ra[e] -= f; rb[e] -= f; }
             }
         }
-        if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         int n_aug = 0;
 #ifdef EMD_COUNT_STEPS
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
 
         // One augmentation per round: shortest path from ANY row that still has supply to ANY column that still has
         // demand (multi-source Dijkstra on the reduced costs).  All source rows are relaxed up front without an arg-min
-        // each; the search then usually pops a demand column within a few steps.
+        // each, and every step scans ALL nodes tied at the smallest label.
         for (;;) {
             unsigned long long srcmask[NK];
             bool any_src = false;
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
             int target = -1;
             double dstar = 0.0;
             for (int step = 0;; ++step) {
-                if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: one node is scanned per step
+                if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: >= one node is scanned per step
 #ifdef EMD_COUNT_STEPS
                 ++n_steps;
 #endif
@@ -252,20 +255,15 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
                     if (tc) doneC[e] = true;
                 }
                 if (found) break;
-                // columns: backward arcs jn -> i for rows currently shipping to jn (reduced cost 0)
+                // columns: backward arcs to the rows that ship to ANY of the tied columns (reduced cost 0): the ballot
+                // mask of the tied columns IS a column bit mask, so one AND with the row's support finds them
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
-                    unsigned long long m = tieC[e];
-                    while (m) {                                    // wave-uniform
-                        const int jn = __builtin_ctzll(m) + 64 * e;
-                        m &= m - 1ull;
+                    if (!doneR[e] && bd < dR[e]) {
 #pragma unroll
-                        for (int e2 = 0; e2 < NK; ++e2) {
-                            const int idx = lane + 64 * e2;
-                            if (idx < K && !doneR[e2]) {
-                                const double f = FT[(size_t)jn * K + idx];
-                                if (f > 0.0 && bd < dR[e2]) { dR[e2] = bd; parR[e2] = jn; }
-                            }
+                        for (int w = 0; w < NK; ++w) {
+                            const unsigned long long hit = ship[e][w] & tieC[w];
+                            if (hit) { dR[e] = bd; parR[e] = __builtin_ctzll(hit) + 64 * w; }
                         }
                     }
                 }
@@ -309,16 +307,14 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
                 pu[e] -= dR[e] < dstar ? dR[e] : dstar;
                 pv[e] += dC[e] < dstar ? dC[e] : dstar;
             }
-            // bottleneck along target <- ... <- source row (the first row on the way back that has no predecessor)
-            double delta = 0.0;
-            {
+            // walk target <- ... <- source row once with wave-uniform indices; hop h is recorded in lane h (h % 64, slot
+            // h / 64): forward arc (hi -> hj) gains flow, backward arc (hi -> hb) loses it (hb < 0 at the source row)
+            int hi[NK], hj[NK], hb[NK];
 #pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == target / 64) delta = rl_f64(rb[e], target % 64);
-                delta = uni_f64(delta);
-            }
-            int src_row = -1;
-            for (int j = target, hop = 0;; ++hop) {
-                if (hop > K + 1 || j < 0) { tripped = true; trip_code = 2; break; }
+            for (int e = 0; e < NK; ++e) { hi[e] = 0; hj[e] = 0; hb[e] = -1; }
+            int n_hops = 0, src_row = -1;
+            for (int j = target;;) {
+                if (n_hops >= 64 * NK || j < 0) { tripped = true; trip_code = 2; break; }
                 int i = 0;
 #pragma unroll
                 for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
@@ -326,32 +322,69 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
                 int jb = 0;
 #pragma unroll
                 for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
+#pragma unroll
+                for (int e = 0; e < NK; ++e)
+                    if (e == n_hops / 64) {
+                        hi[e] = wl_i32(hi[e], i, n_hops % 64);
+                        hj[e] = wl_i32(hj[e], j, n_hops % 64);
+                        hb[e] = wl_i32(hb[e], jb, n_hops % 64);
+                    }
+                ++n_hops;
                 if (jb < 0) { src_row = i; break; }              // a source row
-                const double f = uni_f64(FT[(size_t)jb * K + i]);
-                delta = f < delta ? f : delta;
                 j = jb;
             }
             if (tripped) break;
-            {
-                double ra_s = 0.0;
+            // bottleneck: all backward-arc flows at once
+            double fb[NK], fmin = INF;
 #pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == src_row / 64) ra_s = rl_f64(ra[e], src_row % 64);
+            for (int e = 0; e < NK; ++e) {
+                const bool act = lane + 64 * e < n_hops;
+                fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
+                fmin = fb[e] < fmin ? fb[e] : fmin;
+            }
+            double delta = wave_min_f64(fmin);
+            {
+                double rb_t = 0.0, ra_s = 0.0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
+                    if (e == src_row / 64) ra_s = rl_f64(ra[e], src_row % 64);
+                }
+                delta = rb_t < delta ? rb_t : delta;
                 delta = uni_f64(ra_s < delta ? ra_s : delta);
             }
-            for (int j = target;;) {
-                int i = 0;
+            // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
+            unsigned long long emptied[NK];
 #pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
-                if (lane == 0) FT[(size_t)j * K + i] += delta;
-                if (i == src_row) break;
-                int jb = 0;
-#pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
-                if (lane == 0) FT[(size_t)jb * K + i] -= delta;
-                j = jb;
+            for (int e = 0; e < NK; ++e) {
+                const bool act = lane + 64 * e < n_hops;
+                if (act) {
+                    F[(size_t)hi[e] * K + hj[e]] += delta;
+                    if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
+                }
+                emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
             }
-            if constexpr (!F_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            // flow support: set the forward bits, clear the backward bits of the arcs that ran empty
+            for (int h = 0; h < n_hops; ++h) {
+                int i = 0, j = 0, jb = 0;
+#pragma unroll
+                for (int e = 0; e < NK; ++e)
+                    if (e == h / 64) { i = rl_i32(hi[e], h % 64); j = rl_i32(hj[e], h % 64); jb = rl_i32(hb[e], h % 64); }
+                bool gone = false;
+#pragma unroll
+                for (int e = 0; e < NK; ++e) if (e == h / 64) gone = (emptied[e] >> (h % 64)) & 1ull;
+#pragma unroll
+                for (int e = 0; e < NK; ++e)
+                    if (lane + 64 * e == i) {
+#pragma unroll
+                        for (int w = 0; w < NK; ++w) {
+                            if (w == j / 64) ship[e][w] |= 1ull << (j % 64);
+                            if (gone && w == jb / 64) ship[e][w] &= ~(1ull << (jb % 64));
+                        }
+                    }
+            }
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
                 if (lane + 64 * e == src_row) ra[e] -= delta;
@@ -359,10 +392,20 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
             }
             ++n_aug;
         }
+        // cost = sum over the support of F_ij * M_ij (lane i walks the bits of row i)
         double cost = 0.0;
-        for (int t = lane; t < K * K; t += 64) {
-            const int j = t / K, i = t % K;
-            cost += FT[t] * Mrd[(size_t)i * K + j];
+#pragma unroll
+        for (int e = 0; e < NK; ++e) {
+            const int idx = lane + 64 * e;
+#pragma unroll
+            for (int w = 0; w < NK; ++w) {
+                unsigned long long m = ship[e][w];
+                while (m) {
+                    const int j = __builtin_ctzll(m) + 64 * w;
+                    m &= m - 1ull;
+                    cost += F[(size_t)idx * K + j] * Mrd[(size_t)idx * K + j];
+                }
+            }
         }
         cost = uni_f64(wave_sum_f64(cost));
         if (lane == 0) {
@@ -373,6 +416,7 @@ __global__ void __launch_bounds__(64 * EMD_MAX_WAVES_PER_WG) emd_grid_kernel(Emd
             if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;
 #endif
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -106,8 +106,16 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 
 constexpr int MAX_K = 128;
 constexpr int TIMING_RING = 64;
-constexpr int EMD_SLAB_WGS_PER_CU = 2, EMD_SLAB_WAVES = 4;  // resident waves of the K > 64 exact kernel
+
 constexpr size_t LDS_BYTES = 160 * 1024;
+// exact-EMD kernel: workgroups of pilot::EMD_WAVES waves, M (+ row minima) in LDS; resident workgroups per CU
+static int emd_wgs_per_cu(int K) {
+    const size_t lds = sizeof(double) * ((size_t)K * K + K);
+    int by_lds = (int)(LDS_BYTES / lds);
+    const int by_regs = K <= 64 ? 4 : 2;        // 58 / 88 VGPRs per lane: 8 / 5 waves per SIMD
+    if (by_lds > by_regs) by_lds = by_regs;
+    return by_lds < 1 ? 1 : by_lds;
+}
 
 }  // namespace
 
@@ -129,7 +137,7 @@ struct pilot_ot_plan {
     int *flags_ws;     // per-pair flags when the caller passes none
     size_t flags_ws_n;
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
-    double *f_slab;    // exact-EMD flow slabs for K > 64 (one K*K block per resident wave)
+    double *f_slab;    // exact-EMD flow values: one K*K block per resident wave
     int n_cu;
     // event ring for per-launch kernel timing (bench.py roofline)
     int timing;                       // 0 off
@@ -259,9 +267,9 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
-    if (e == hipSuccess && K > 64)
+    if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
-                      sizeof(double) * (size_t)K * K * EMD_SLAB_WGS_PER_CU * pl->n_cu * EMD_SLAB_WAVES);
+                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::EMD_WAVES);
     if (e != hipSuccess) {
         pilot_ot_plan_destroy(pl);
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
@@ -652,26 +660,21 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.upper_only = mode != PILOT_OT_EMD_ALL;
     p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab;
     const long total = (long)n_rows * N;
-    const size_t mat = sizeof(double) * (size_t)K * K;
-    if (K <= 64) {
-        // M + one flow matrix per wave in LDS; as many waves per workgroup as fit (<= 16)
-        int waves = (int)((LDS_BYTES - mat) / mat);
-        if (waves > pilot::EMD_MAX_WAVES_PER_WG) waves = pilot::EMD_MAX_WAVES_PER_WG;
-        if (waves > 8 && mat * (waves + 1) > LDS_BYTES / 2) waves = 8;  // prefer two smaller workgroups per CU
-        if (waves < 1) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
-        const size_t lds = mat * (size_t)(waves + 1);
-        long wgs = (total + waves - 1) / waves;
-        const long cap = (long)pl->n_cu * (lds * 2 <= LDS_BYTES ? 2 : 1) * 2;
+    {
+        const size_t lds = sizeof(double) * ((size_t)K * K + K);
+        if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
+        long wgs = (total + pilot::EMD_WAVES - 1) / pilot::EMD_WAVES;
+        const long cap = (long)pl->n_cu * emd_wgs_per_cu(K);
         if (wgs > cap) wgs = cap;
-        auto kern = pilot::emd_grid_kernel<1, true>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
-    } else {
-        const long cap = (long)EMD_SLAB_WGS_PER_CU * pl->n_cu;
-        long wgs = (total + EMD_SLAB_WAVES - 1) / EMD_SLAB_WAVES;
-        if (wgs > cap) wgs = cap;
-        hipLaunchKernelGGL((pilot::emd_grid_kernel<2, false>), dim3((unsigned)wgs), dim3(64 * EMD_SLAB_WAVES), 0, s, p);
+        if (K <= 64) {
+            auto kern = pilot::emd_grid_kernel<1>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+        } else {
+            auto kern = pilot::emd_grid_kernel<2>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (mode == PILOT_OT_EMD_MIRROR) {
