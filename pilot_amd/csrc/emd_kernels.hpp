@@ -188,6 +188,11 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
         // One augmentation per round: shortest path from ANY row that still has supply to ANY column that still has
         // demand (multi-source Dijkstra on the reduced costs).  All source rows are relaxed up front without an arg-min
         // each, and every step scans ALL nodes tied at the smallest label.
+        unsigned long long prev_src[NK];
+        double A[NK];
+        int Apar[NK];
+#pragma unroll
+        for (int e = 0; e < NK; ++e) { prev_src[e] = 0ull; A[e] = INF; Apar[e] = -1; }
         for (;;) {
             unsigned long long srcmask[NK];
             bool any_src = false;
@@ -199,30 +204,40 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
             if (!any_src) break;
             if (n_aug > aug_guard) { tripped = true; trip_code = 5; break; }
             if ((n_aug & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
+            // initial column labels min over sources i of rc(i, j) = (A_j - pv_j)+ with A_j = min_i (M_ij - pu_i): a source's
+            // potential never moves (its distance is 0), so A and its arg-min only change when a source runs dry
+            bool src_changed = false;
 #pragma unroll
-            for (int e = 0; e < NK; ++e) {
-                const bool src = ra[e] > tol && lane + 64 * e < K;
-                dR[e] = src ? 0.0 : INF; dC[e] = INF; parR[e] = -1; parC[e] = -1;
-                doneR[e] = src; doneC[e] = false;
-            }
+            for (int e = 0; e < NK; ++e) { src_changed = src_changed || srcmask[e] != prev_src[e]; prev_src[e] = srcmask[e]; }
+            if (src_changed) {
 #pragma unroll
-            for (int e = 0; e < NK; ++e) {
-                unsigned long long m = srcmask[e];
-                while (m) {                                        // wave-uniform
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1ull;
-                    const int in = l + 64 * e;
-                    const double pu_i = rl_f64(pu[e], l);
+                for (int e = 0; e < NK; ++e) { A[e] = INF; Apar[e] = -1; }
 #pragma unroll
-                    for (int e2 = 0; e2 < NK; ++e2) {
-                        const int idx = lane + 64 * e2;
-                        if (idx < K) {
-                            double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e2];
-                            rc = rc < 0.0 ? 0.0 : rc;
-                            if (rc < dC[e2]) { dC[e2] = rc; parC[e2] = in; }
+                for (int e = 0; e < NK; ++e) {
+                    unsigned long long m = srcmask[e];
+                    while (m) {                                        // wave-uniform
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const int in = l + 64 * e;
+                        const double pu_i = rl_f64(pu[e], l);
+#pragma unroll
+                        for (int e2 = 0; e2 < NK; ++e2) {
+                            const int idx = lane + 64 * e2;
+                            if (idx < K) {
+                                const double v = Mrd[(size_t)in * K + idx] - pu_i;
+                                if (v < A[e2]) { A[e2] = v; Apar[e2] = in; }
+                            }
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int e = 0; e < NK; ++e) {
+                const bool src = ra[e] > tol && lane + 64 * e < K;
+                double rc = A[e] - pv[e];
+                rc = rc < 0.0 ? 0.0 : rc;
+                dR[e] = src ? 0.0 : INF; dC[e] = lane + 64 * e < K ? rc : INF; parR[e] = -1; parC[e] = Apar[e];
+                doneR[e] = src; doneC[e] = false;
             }
             int target = -1;
             double dstar = 0.0;
