@@ -230,7 +230,7 @@ template <typename T, int RT, int TV> struct TailFromRegs {
 struct TailNone {};
 
 template <class C, int RT, int TV, class WOp>
-__device__ inline typename C::T tail_rows(const WOp &w, const typename C::acc_t (&IN)[RT], typename C::T init0, int grp) {
+__device__ inline typename C::acc_t tail_rows(const WOp &w, const typename C::acc_t (&IN)[RT], const typename C::acc_t &last_init, int grp) {
     static_assert(C::NGRP == 4 && C::NREG == 4 && C::lidx(1, 0, 1) == 17, "VALU tail rows: 16x16x4 layouts with lidx = 16t + 4r + g");
     using T = typename C::T;
     using f2_t = pair_of<T>;
@@ -246,6 +246,7 @@ __device__ inline typename C::T tail_rows(const WOp &w, const typename C::acc_t 
 #pragma unroll
             for (int c = 0; c < TV; ++c) acc[c] = __builtin_elementwise_fma(w(c, tp * 4 + r), x, acc[c]);
         }
+    if constexpr (sizeof(T) == 8) {     // f64: the permlane reduction is cheaper than two more 64-cycle MFMAs (measured)
 #pragma unroll
     for (int c = 0; c < TV; ++c) {
         acc[c][0] = sum_xor16(sum_xor32(acc[c][0]));
@@ -256,7 +257,24 @@ __device__ inline typename C::T tail_rows(const WOp &w, const typename C::acc_t 
         const T hi = (grp & 1) ? acc[1][1] : acc[1][0];
         val = grp < 2 ? val : hi;
     }
-    return init0 + val;    // init0 = 1 in padded slots (their weights are 0), 0 in live ones
+    typename C::acc_t out = last_init;
+    out[0] = last_init[0] + val;    // 1 in padded slots (their weights are 0), 0 in live ones
+    return out;
+    } else {
+    // the four lane-group partials of a column are the four k-slots of ONE more MFMA whose A operand is 1 in the hardware
+    // row of that cell type and 0 elsewhere: the matrix pipe does the cross-lane sum and drops it into the right
+    // accumulator slot, on top of the padding seed (2 MFMAs = 64 pipe cycles instead of ~14 VALU/permlane instructions)
+    typename C::acc_t out = last_init;
+    const int lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int c = 0; c < TV; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const T sel = C::lidx_of_row(0, lane % C::TILE) == 2 * c + h ? T(1) : T(0);
+            out = C::mfma(sel, acc[c][h], out);
+        }
+    return out;
+    }
 }
 
 // panel product with the last row-tile on the VALU (TV > 0): MFMA chains for row-tiles 0 .. RT-2 only
@@ -276,8 +294,7 @@ __device__ inline void panel_product_tail(const AOp &aop, const WOp &wop, const 
 #pragma unroll
             for (int t = 0; t < RT - 1; ++t)
                 OUT[t] = M::mfma(aop((tp * M::NREG + r) * RT + t), IN[tp][r], OUT[t]);
-    OUT[RT - 1] = last_init;
-    OUT[RT - 1][0] = tail_rows<C, RT, TV>(wop, IN, last_init[0], grp);
+    OUT[RT - 1] = tail_rows<C, RT, TV>(wop, IN, last_init, grp);
 }
 
 template <class C> __device__ inline void store_regs(typename C::T *dst, const typename C::acc_t &x) {
@@ -837,8 +854,7 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
         acc_t out = PADC;
         if constexpr (TV > 0) {
             if (w == RT - 1) {       // wave-uniform
-                out[0] = tail_rows<C, RT, TV>(W, IN, PADC[0], grp);
-                return out;
+                return tail_rows<C, RT, TV>(W, IN, PADC, grp);
             }
         }
 #pragma unroll
