@@ -39,7 +39,7 @@ def test_emd_modes_and_symmetry():
 
 @pytest.mark.parametrize("K", [1, 2, 17, 64, 65, 100, 128])
 def test_emd_every_k_regime(K):
-    """K <= 64: flows in LDS; K > 64: two rows/columns per lane and flows in a global slab."""
+    """K <= 64: one row/column per lane; K > 64: two (flow support masks of 2 x 64 bits per row)."""
     P, M = make_problem(12, K, 6, seed=200 + K, cells_per_patient=500)
     if K == 1:
         M = np.zeros((1, 1))
@@ -58,6 +58,31 @@ def test_emd_nonsymmetric_cost_and_sparse_histograms():
     Eo = O.emd_grid(P, M, n_threads=16)
     Eg = engine.emd_grid(P, M)                                     # auto -> all (not symmetric)
     assert np.abs(Eg - Eo).max() <= 1e-12
+
+
+@pytest.mark.parametrize("K,sparsity,nonzero_diag,seed", [(5, 0.5, False, 1), (33, 0.8, True, 2), (64, 0.3, False, 3),
+                                                         (70, 0.9, True, 4), (128, 0.6, False, 5)])
+def test_emd_randomized_stress(K, sparsity, nonzero_diag, seed):
+    """Degenerate inputs for the augmenting-path solver: very sparse histograms (most bins empty, single-bin patients),
+    duplicates, unequal total mass (POT rescales b), random non-metric costs with ties (quantised) and, optionally, a
+    non-zero diagonal (no warm start).  Value against the CPU oracle, and the LP bounds 0 <= cost <= max(M)."""
+    rng = np.random.default_rng(seed)
+    N = 14
+    P = rng.random((N, K)) ** 3
+    P[rng.random((N, K)) < sparsity] = 0.0
+    P[0] = 0.0; P[0, K // 2] = 1.0                                  # all mass in one bin
+    P[1] = P[2]                                                     # duplicate patients
+    P[P.sum(1) == 0, 0] = 1.0
+    P /= P.sum(1, keepdims=True)
+    P[3] *= 0.5                                                     # unequal mass: emd2 rescales the second histogram
+    M = np.round(rng.random((K, K)) * 8) / 8                        # many exactly equal costs
+    if not nonzero_diag:
+        np.fill_diagonal(M, 0.0)
+    Eo = O.emd_grid(P, M, n_threads=16)
+    Eg, info = engine.emd_grid(P, M, mode="all", return_info=True)
+    assert (info["n_aug"] >= 0).all()
+    assert np.abs(Eg - Eo).max() <= 1e-12
+    assert Eg.min() >= -1e-15 and Eg.max() <= M.max() * P.sum(1).max() + 1e-12
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
