@@ -258,7 +258,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     }
     const int kp = ((K + 31) / 32) * 32;
     if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp + 2 * 2 * (size_t)(kp / 4) * 64 * 2 + 2 * 64 * 64));   // + tail-row weights + plain tables
-    if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * (size_t)N * kp);
+    if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * ((size_t)N * kp + N));   // + one stop threshold per patient
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (8 + 2 * pilot::ORDER_NB) * sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking);
@@ -420,9 +420,9 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         if (ob > pl->n_cu) ob = pl->n_cu;
         int *split = pl->track_count + 4;
         const int mode = (coop ? 1 : 0) | (solo ? 2 : 0) | ((p.debug & 2) ? 4 : 0);   // bit 2: natural order (experiment)
-        HIP_TRY(f32 ? pilot::launch_prep_f32(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, n_rows, row_begin, row_step,
+        HIP_TRY(f32 ? pilot::launch_prep_f32(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, stop_thr, floor_ulps, n_rows, row_begin, row_step,
                                              pl->order_bucket, pl->order_hist, pl->order_list, split, pl->track_count + 1, mode, ob, s)
-                    : pilot::launch_prep_f64(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, n_rows, row_begin, row_step,
+                    : pilot::launch_prep_f64(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, stop_thr, floor_ulps, n_rows, row_begin, row_step,
                                              pl->order_bucket, pl->order_hist, pl->order_list, split, pl->track_count + 1, mode, ob, s));
         p.list = pl->order_list;
         if (solo) {

@@ -318,7 +318,8 @@ template <class C> __device__ inline void load_regs(const typename C::T *src, ty
 }
 
 struct GridParams {
-    const void *P;        // N x KP, element type T, every row in accumulator-slot order [tile][group][reg], 0 in padding
+    const void *P;        // N x KP, element type T, every row in accumulator-slot order [tile][group][reg], 0 in padding;
+                          // then N stop thresholds (one per column patient)
     const void *img;      // 3 images of KP*KP elements of T (G^T-form, G-form, (G o M)-form) + KP first-product values
     void *scratch;        // n_items records of scratch_stride<T>(RT) elements of T
     int N, K;
@@ -418,11 +419,7 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
         const int q = p.list[item];
         const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
         const T a = inrec ? Pt[(size_t)i * KP + pos] : T(0), b = inrec ? Pt[(size_t)j * KP + pos] : T(0);
-        T thr = T(p.stop_thr);
-        if constexpr (sizeof(T) == 4) {
-            const T fl = T(p.floor_ulps) * C::eps() * sqrtf(wave_sum(b * b));
-            thr = thr > fl ? thr : fl;
-        }
+        const T thr = Pt[(size_t)N * KP + j];
         T u = live ? T(1) / T(K) : T(0), v = u, ACC = acc0, errv = T(1);
         int ii = 0, chk = 1, flags = sizeof(T) == 8 ? FLAG_F64 : 0;
         for (;;) {
@@ -596,7 +593,6 @@ sinkhorn_stream_kernel(GridParams p) {
     int res_next = 0, res_end = 0;
     bool exhausted = false;
     bool want = true;  // column asks for a (new) pair
-    unsigned loop_count = 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
         const unsigned long long wmask = __ballot(want) & colmask;
@@ -629,7 +625,6 @@ sinkhorn_stream_kernel(GridParams p) {
                 q = p.list ? p.list[item] : item;
                 const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
                 const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
-                T bnorm2 = T(0);
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     load_regs<C>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
@@ -637,34 +632,16 @@ sinkhorn_stream_kernel(GridParams p) {
                     load_regs<C>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
-                        const T ui = (t == RT - 1) ? uinit - uinit * PADC[r] : uinit;   // 0 in padded slots
-                        U[t][r] = ui;
-                        V[t][r] = ui;
-                        bnorm2 += B[t][r] * B[t][r];
+                        U[t][r] = (t == RT - 1) ? uinit - uinit * PADC[r] : uinit;   // 0 in padded slots; v follows from ACC
                         if constexpr (TRACK) { RU[t][r] = T(1); RV[t][r] = T(1); }
                     }
                 }
-                bnorm2 = sum_xor32(bnorm2);
-                if constexpr (NGRP == 4) bnorm2 = sum_xor16(bnorm2);
-                thr = T(p.stop_thr);
-                if constexpr (sizeof(T) == 4) {
-                    const T fl = T(p.floor_ulps) * M::eps() * sqrtf(bnorm2);
-                    thr = thr > fl ? thr : fl;
-                }
+                thr = Pt[(size_t)N * KP + j];      // stop threshold of column patient j (prep: f32 floor folded in)
                 chk = 1;
                 ii = 0; flags = 0; abs_at = -1; errv = T(1);
             }
         }
         if (__ballot(active || want) == 0ull) break;
-
-        // a pair's updates are a serial chain: waves carrying old pairs go first on the shared matrix pipe
-        if ((loop_count++ & 7) == 0 && !(p.debug & 1)) {
-            const bool old2 = __ballot(active && ii > 8 * p.period) != 0ull;
-            const bool old1 = __ballot(active && ii > 4 * p.period) != 0ull;
-            if (old2) __builtin_amdgcn_s_setprio(3);
-            else if (old1) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(0);
-        }
 
         // ---- v = b / (G^T u) --------------------------------------------------------------------------
 #pragma unroll
@@ -900,21 +877,7 @@ __global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) 
                 load_regs<C>(Pt + (size_t)j * KP + (w * NGRP + grp) * NREG, B);
                 acc_t a0;
                 load_regs<C>(acc0g + (w * NGRP + grp) * NREG, a0);
-                T bnorm2 = T(0);          // ||b||^2 over ALL tiles, summed exactly like the stream kernel does
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    acc_t bt;
-                    load_regs<C>(Pt + (size_t)j * KP + (t * NGRP + grp) * NREG, bt);
-#pragma unroll
-                    for (int r = 0; r < NREG; ++r) bnorm2 += bt[r] * bt[r];
-                }
-                bnorm2 = sum_xor32(bnorm2);
-                if constexpr (NGRP == 4) bnorm2 = sum_xor16(bnorm2);
-                thr = T(p.stop_thr);
-                if constexpr (sizeof(T) == 4) {
-                    const T fl = T(p.floor_ulps) * C::eps() * sqrtf(bnorm2);
-                    thr = thr > fl ? thr : fl;
-                }
+                thr = Pt[(size_t)N * KP + j];
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) { U[r] = UINIT[r]; V[r] = B[r] * C::rcp(a0[r]); }   // first v-update
                 ii = 0; chk = 1; flags = 0; errv = T(1);
@@ -1052,7 +1015,8 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(Gri
 template <class C>
 __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT, double reg,
                                   typename C::T *__restrict__ img, const double *__restrict__ Psrc,
-                                  typename C::T *__restrict__ Pdst, long n_p, int write_tail, int tid, int nthr) {
+                                  typename C::T *__restrict__ Pdst, long n_p, int write_tail, double stop_thr,
+                                  double floor_ulps, int tid, int nthr) {
     using M = C;
     using T = typename C::T;
     const int KP = RT * M::TILE;
@@ -1112,6 +1076,15 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
             if (row < K && k < K) v = form == 0 ? exp(-Msrc[(size_t)k * K + row] / reg) : exp(-Msrc[(size_t)row * K + k] / reg);
             tail[idx] = T(v);
         }
+    }
+    // stop threshold per (column) patient behind the proportions: POT's stopThr, floored in f32 at floor_ulps * eps * ||b||_2
+    // (the marginal error cannot get below the rounding of b itself)
+    for (long row = tid; row < n_p / KP; row += nthr) {
+        double n2 = 0.0;
+        for (int k = 0; k < K; ++k) n2 += Psrc[row * K + k] * Psrc[row * K + k];
+        double thr = stop_thr;
+        if (sizeof(T) == 4) { const double fl = floor_ulps * 1.1920928955078125e-07 * sqrt(n2); thr = thr > fl ? thr : fl; }
+        Pdst[n_p + row] = T(thr);
     }
     // proportions: N rows of KP values in slot order, zero in padding (n_p = N * KP)
     for (long idx = tid; idx < n_p; idx += nthr) {
@@ -1216,14 +1189,15 @@ constexpr int PREP_SETUP_BLOCKS = 64;
 template <class C>
 __global__ void __launch_bounds__(256) sinkhorn_prep_kernel(const double *__restrict__ Msrc, int K, int RT, double reg,
                                                             typename C::T *__restrict__ img, const double *__restrict__ Psrc,
-                                                            typename C::T *__restrict__ Pdst, int N, int write_tail, int n_tiles,
+                                                            typename C::T *__restrict__ Pdst, int N, int write_tail, double stop_thr,
+                                                            double floor_ulps, int n_tiles,
                                                             int n_rows, int row_begin, int row_step,
                                                             unsigned char *__restrict__ bucket, int *__restrict__ hist, int collapse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char order_smem[];
     if ((int)blockIdx.x < n_tiles) {
         bucket_body(blockIdx.x, Psrc, N, K, n_rows, row_begin, row_step, bucket, hist, collapse, order_smem);
     } else {
-        setup_body<C>(Msrc, K, RT, reg, img, Psrc, Pdst, (long)N * RT * C::TILE, write_tail,
+        setup_body<C>(Msrc, K, RT, reg, img, Psrc, Pdst, (long)N * RT * C::TILE, write_tail, stop_thr, floor_ulps,
                       ((int)blockIdx.x - n_tiles) * (int)blockDim.x + (int)threadIdx.x, PREP_SETUP_BLOCKS * (int)blockDim.x);
     }
 }

@@ -23,10 +23,10 @@ hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &
 // one call's preparation: operand images + tables + slot-ordered proportions and the longest-first order keys in one
 // launch (sinkhorn_prep_kernel), then the scatter.  mode: bit 0 cooperative head, bit 1 solo duplicates, bit 2 natural order.
 hipError_t launch_prep_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
-                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s);
 hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
-                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s);
 
 }  // namespace pilot

@@ -54,7 +54,7 @@ template <class C> hipError_t value_any(int RT, dim3 grid, hipStream_t s, const 
 // prepare a call: operand images / tables / slot-ordered proportions + the longest-first order keys, then the scatter
 template <class C>
 hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
-                    int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                    double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                     int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
     using T = typename C::T;
     const int collapse = (mode >> 2) & 1;    // bit 2: no longest-first order (experiment switch)
@@ -69,7 +69,7 @@ hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const
         attr_set = true;
     }
     hipLaunchKernelGGL(sinkhorn_prep_kernel<C>, dim3(tiles + PREP_SETUP_BLOCKS), dim3(256), lds, s, M, K, RT, reg, static_cast<T *>(img), P,
-                       static_cast<T *>(Pslot), N, write_tail, tiles, n_rows, row_begin, row_step, bucket, hist, collapse);
+                       static_cast<T *>(Pslot), N, write_tail, stop_thr, floor_ulps, tiles, n_rows, row_begin, row_step, bucket, hist, collapse);
     if (n_rows > 0)
         hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bucket, n_rows * N, hist, hist + ORDER_NB, list, split,
                            main_queue_head, mode & 3);
@@ -104,9 +104,9 @@ hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds
 }
 hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF32x16>(RT, grid, s, p); }
 hipError_t launch_prep_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
-                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
-    return prep_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, n_rows, row_begin, row_step, bucket, hist, list, split,
+    return prep_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
                                main_queue_head, mode, n_blocks, s);
 }
 hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16>(RT, sym, n_wgs, s, p); }
@@ -129,9 +129,9 @@ hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds
 }
 hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF64x16>(RT, grid, s, p); }
 hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
-                           int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
-    return prep_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, n_rows, row_begin, row_step, bucket, hist, list, split,
+    return prep_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
                                main_queue_head, mode, n_blocks, s);
 }
 hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF64x16>(RT, sym, n_wgs, s, p); }
