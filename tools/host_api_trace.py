@@ -1,3 +1,5 @@
+"""A dozen host-buffer calls in a row with per-call wall time (run it under rocprofv3 --kernel-trace --memory-copy-trace
+to see what a slow call spends its time on; see tools/trace_dump.py)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+"""Print the last N kernel records of a rocprofv3 --kernel-trace csv with the gaps between them. usage: trace_dump.py DIR N"""
 import csv, glob, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
