@@ -3,24 +3,29 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N              (no launcher: ONE process drives the N devices, pilot_ot_multi_*)
 
-One "step" = one complete pass of the hot path over the workload: every one of the N^2 ordered
-patient pairs solved with POT's sinkhorn_stabilized semantics (setup kernel + pair-grid kernel +
-tau-tracking kernel), and for N_gpus > 1 the RCCL all-gather that assembles the full matrix on
-every rank.  Inputs (N x K proportions, K x K cost) are resident in HBM before the timed region.
+One "step" = one complete pass of the hot path over the workload: every one of the N^2 ordered patient pairs solved
+with POT's sinkhorn_stabilized semantics (prep kernel + pair-grid kernel + tau-tracking kernel), and for N_gpus > 1
+the RCCL all-gather + row interleave that assembles the full matrix on every rank.  Inputs (N x K proportions, K x K
+cost) are resident in HBM before the timed region.  Everything goes through the C ABI of libpilot_ot.so (ctypes); this
+script imports neither torch nor any other GPU framework -- under a launcher it only reads RANK / LOCAL_RANK /
+WORLD_SIZE, and the RCCL unique id travels through a temp file (pilot_amd/multi.py).
 
-Workload: BASELINE configs[2] at reg = 0.1 -- 600 patients x 50 cell types x 30 PCA dims, the
-configuration the metric is quoted on (it fits one GPU).  Total work is fixed as GPUs are added
-(the 600^2 pair grid is row-sharded round-robin), hence "scaling": "strong".
+Workload: BASELINE configs[2] at reg = 0.1 -- 600 patients x 50 cell types x 30 PCA dims, the configuration the metric
+is quoted on (it fits one GPU).  Total work is fixed as GPUs are added (the 600^2 pair grid is row-sharded
+round-robin), hence "scaling": "strong".  The line also carries, as extra keys: `value_host_to_host` (numpy in ->
+numpy out, SURVEY.md 8(d)'s definition of t), `reg_sweep` (reg 0.01 / 0.1 / 1.0 with parity against the oracle on a row
+sample), `exact_emd` (the reference's DEFAULT mode on the same cohort) and `c4` (2000 x 100, the shape that scales).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32 MFMA pair-grid kernel):
-achieved = algorithmic flop of one launch / its mean duration (HIP events on the launch stream).
-`cpu_baseline` is the CPU oracle (C fp64 restatement of POT's loop) timed on this box's host cores on
-a bounded sample of the same workload (rank 0, 1 GPU runs only).
+`roofline` is for the dominant kernel (the MFMA pair-grid kernel): achieved = algorithmic flop of one launch / its mean
+duration (HIP events on the launch stream, recorded inside the timed region).  `cpu_baseline` is the CPU oracle (C fp64
+restatement of POT's loop) timed on this box's host cores on a bounded sample of the same workload (rank 0, 1 GPU).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -33,13 +38,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA == f32 vector peak
+PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
 def algorithmic_flops(iters, K, period=20):
     """per pair, iters*(4K^2+2K) + ceil(iters/period)*(2K^2+3K) + 3K^2."""
     it = iters.astype(np.float64)
     return float(np.sum(it * (4 * K * K + 2 * K) + np.ceil(it / period) * (2 * K * K + 3 * K) + 3 * K * K))
+
+
+class DevBuf:
+    def __init__(self, L, nbytes):
+        from pilot_amd import _lib
+        self.L, self.p = L, ctypes.c_void_p()
+        _lib.check(L.pilot_ot_dev_alloc(ctypes.byref(self.p), int(nbytes)))
+
+    def free(self):
+        if self.p:
+            self.L.pilot_ot_dev_free(self.p)
+            self.p = ctypes.c_void_p()
 
 
 def main():
@@ -50,112 +69,142 @@ def main():
     ap.add_argument("--config", default="c3", help="synthetic config (c2 | c3 | c4)")
     ap.add_argument("--reg", type=float, default=0.1)
     ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64"])
+    ap.add_argument("--mode", default="sinkhorn", choices=["sinkhorn", "emd"],
+                    help="emd: time the exact-OT pair grid (the reference's default mode) instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / reg_sweep / exact_emd / c4")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the baseline sample")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for --gpus > 1 (gloo: host all-gather; used to test the multi-rank "
-                         "path on a single-GPU box together with --single-device)")
-    ap.add_argument("--single-device", action="store_true", help="every rank uses HIP device 0 (testing only)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="testing on a 1-GPU box: run the one-process-per-GPU path (RCCL communicator, all-gather, max over "
+                         "ranks) with a world of one")
+    ap.add_argument("--logical-shards", action="store_true",
+                    help="testing on a 1-GPU box: --gpus N becomes N logical shards on device 0 (peer-copy gather)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+    if world > 1 and world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
-    import torch  # device memory for the all-gather buffers, streams, torch.distributed (RCCL): plumbing only
-    import torch.distributed as dist
-
-    from pilot_amd import _lib, engine, sharding
+    from pilot_amd import _lib, engine, multi, sharding
     from pilot_amd.synthetic import CONFIGS, make_problem
 
-    if not torch.cuda.is_available() or _lib.device_count() < 1:
+    L = _lib.load()
+    n_dev = _lib.device_count()
+    if n_dev < 1:
         raise SystemExit("bench.py needs an MI355X; pilot_amd has no CPU path")
-    dev = 0 if args.single_device else local_rank
-    torch.cuda.set_device(dev)
-    _lib.check(_lib.load().pilot_ot_set_device(dev))
+    single_process_multi = world == 1 and args.gpus > 1
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))     # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
-
+        _lib.check(L.pilot_ot_set_device(local_rank))
     cfg = CONFIGS[args.config]
     P, M = make_problem(**cfg)
     N, K = P.shape
     prec = args.precision
     if prec == "auto":
-        prec = "fp32" if _lib.load().pilot_ot_auto_precision(float(M.max()) / args.reg) == 1 else "fp64"
-    rb, re_, rs = sharding.shard_rows(N, rank, world)
-    n_local = sharding.n_local_rows(N, rank, world)
-    n_pad = sharding.n_padded_rows(N, world)
+        prec = "fp32" if L.pilot_ot_auto_precision(float(M.max()) / args.reg) == 1 else "fp64"
 
-    plan = engine.DevicePlan(P, M, n_rows_max=max(n_pad, 1))       # P, M -> HBM (resident from here on)
-    plan.enable_timing(True)
-    local = torch.zeros((n_pad, N), dtype=torch.float64, device="cuda")   # this rank's row block (padded)
-    stream = torch.cuda.current_stream().cuda_stream
+    if args.mode == "emd":
+        out = bench_emd(args, L, P, M, cfg)
+        print(json.dumps(out), flush=True)
+        return
 
-    def step():
-        plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=prec, stream=stream,
-                 d_emd=local.data_ptr())
-        if world == 1:
-            return local
-        if args.dist_backend == "nccl":
-            return sharding.all_gather_rows(local, N)          # RCCL all-gather of the HBM-resident row blocks
-        torch.cuda.synchronize()
-        return sharding.all_gather_rows(local.cpu(), N)
+    per_rank = None
+    if single_process_multi:
+        devices = [0] * args.gpus if args.logical_shards else list(range(args.gpus))
+        mp = multi.MultiPlan(P, M, devices=devices)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():
+            mp.sinkhorn(args.reg, precision=prec)
+
+        def fence():
+            mp.sync()
+        comm = None
+    else:
+        rb, re_, rs = sharding.shard_rows(N, rank, world)
+        n_local = sharding.n_local_rows(N, rank, world)
+        n_pad = sharding.n_padded_rows(N, world)
+        plan = engine.DevicePlan(P, M, n_rows_max=max(n_pad, 1))       # P, M -> HBM (resident from here on)
+        plan.enable_timing(True)
+        comm = multi.Comm(rank, world) if (world > 1 or args.force_comm) else None
+        if comm:
+            d_stage, d_full = DevBuf(L, 8 * world * n_pad * N), DevBuf(L, 8 * N * N)
+            _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, np.zeros(n_pad * N).ctypes.data, 8 * n_pad * N))   # padding rows = 0
+
+        def step():
+            plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=prec)
+            if comm:
+                comm.all_gather_rows(plan.dE, n_pad, N, d_stage.p, d_full.p)
+
+        def fence():
+            if comm:
+                comm.barrier()
+            plan.sync()
 
     for _ in range(args.warmup):
-        full = step()
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        full = step()
+        step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm:
+        elapsed = comm.all_reduce_max(elapsed)
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * N / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel (this rank's launches inside the timed region) -------------
-    main_ms, track_ms = plan.kernel_times_ms(max_n=min(args.steps, 64))
-    _, info = plan.fetch(n_rows=n_local)
-    iters = info["iters"]
-    flops_launch = algorithmic_flops(iters, K)
-    kern_ms = float(np.mean(main_ms)) if len(main_ms) else float("nan")
+    # ---- the assembled matrix + per-pair update counts ------------------------------------------------------------
+    if single_process_multi:
+        E, info = mp.fetch(info=True)
+        iters = info["iters"]
+        grid_ms, gather_ms = mp.times_ms()
+        kern_ms, track_ms = float(np.max(grid_ms)), None
+        per_rank = {"grid_ms_per_shard": [round(float(x), 4) for x in grid_ms], "gather_ms": round(gather_ms, 4)}
+    else:
+        main_ms, track = plan.kernel_times_ms(max_n=min(args.steps, 64))
+        kern_ms = float(np.mean(main_ms)) if len(main_ms) else float("nan")
+        track_ms = float(np.mean(track)) if len(track) else None
+        _, info = plan.fetch(n_rows=n_local)
+        iters = info["iters"]
+        if comm:
+            E = np.empty((N, N))
+            _lib.check(L.pilot_ot_memcpy_d2h(E.ctypes.data, d_full.p, 8 * N * N))
+            per_rank = {"rank0_kernel_ms": round(kern_ms, 4), "rank0_step_minus_kernel_ms": round(ms_per_step - kern_ms, 4)}
+        else:
+            E = plan.fetch(n_rows=N)[0]
+    assert E.shape == (N, N) and np.isfinite(E).all(), "bench produced a non-finite matrix"
+    if args.reg >= 0.05:   # converged entropic costs are symmetric; a bad row interleave would break this
+        assert float(np.abs(E - E.T).max()) < 1e-5, "assembled matrix is not symmetric: bad row interleave?"
+
+    # ---- roofline of the dominant kernel (this rank's launches inside the timed region) -------------------------------
+    peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F64_MFMA_TFLOPS
+    flops_launch = algorithmic_flops(iters, K) * (1.0 if not single_process_multi else 1.0 / args.gpus)
     achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
     s_bytes = 4 if prec == "fp32" else 8
-    bytes_launch = float(iters.size) * (2 * K * s_bytes + s_bytes)     # 2*K*s + s per pair
+    pairs_launch = iters.size if not single_process_multi else iters.size // args.gpus
+    bytes_launch = float(pairs_launch) * (2 * K * s_bytes + s_bytes)     # 2*K*s + s per pair
     roofline = {
         "bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % ("float" if prec == "fp32" else "double"),
-        "achieved": round(achieved_tf, 3), "peak": PEAK_F32_MFMA_TFLOPS if prec == "fp32" else 78.6,
-        "unit": "TFLOP/s", "frac": round(achieved_tf / (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else 78.6), 4),
+        "achieved": round(achieved_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
         "traffic": None,
-        "kernel_ms": round(kern_ms, 4), "track_kernel_ms": round(float(np.mean(track_ms)), 4) if len(track_ms) else None,
-        "algorithmic_flop_per_launch": flops_launch, "pairs_per_launch": int(iters.size),
+        "kernel_ms": round(kern_ms, 4), "kernel_ms_source": "HIP events on the launch stream, mean over the timed steps",
+        "track_kernel_ms": round(track_ms, 4) if track_ms is not None else None,
+        "algorithmic_flop_per_launch": flops_launch, "pairs_per_launch": int(pairs_launch),
         "mean_updates_per_pair": round(float(iters.mean()), 2),
     }
-    # HBM traffic per launch: measured offline with rocprofv3 --pmc (bench.py cannot profile itself); the committed
-    # measurement for this exact workload is attached, else null
+    # offline rocprofv3 measurements of this exact workload (bench.py cannot profile itself): HBM traffic per launch from
+    # the PMC passes and the kernel-trace average duration, both written by tools/profile_pmc.sh and keyed by workload
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
+        with open(os.path.join(PROFILE_DIR, "traffic.json")) as fh:
             tr = json.load(fh).get("%s|%g|%s" % (args.config, args.reg, prec))
-        if tr and world == 1:
+        if tr and world == 1 and not single_process_multi:
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+            roofline["traffic_source"] = ("profiles/r02/traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per launch, "
+                                          "measured at git %s)" % tr.get("git", "?"))
+            if tr.get("kernel_ms_rocprofv3"):
+                roofline["kernel_ms_rocprofv3"] = tr["kernel_ms_rocprofv3"]
+                roofline["frac_rocprofv3"] = round(flops_launch / (tr["kernel_ms_rocprofv3"] * 1e-3) / 1e12 / peak, 4)
     except (OSError, ValueError):
         pass
     roofline_hbm = {
@@ -164,15 +213,10 @@ def main():
         "algorithmic_bytes_per_pair": 2 * K * s_bytes + s_bytes,
     }
 
-    # ---- sanity: the assembled matrix is the full N x N grid ---------------------------------------
-    E = full[:N].cpu().numpy() if world > 1 else local[:N].cpu().numpy()
-    assert E.shape == (N, N) and np.isfinite(E).all(), "bench produced a non-finite matrix"
-    if args.reg >= 0.05:   # converged entropic costs are symmetric; a bad row interleave would break this
-        assert float(np.abs(E - E.T).max()) < 1e-5, "assembled matrix is not symmetric: bad row interleave?"
-
+    n_gpus = args.gpus
     out = {
         "metric": "W2 patient-pairs/sec (full NxN EMD matrix)", "value": round(value, 1), "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if prec == "fp32" else "f64", "data": "synthetic",
         "config": {"workload": "%s: %d patients x %d cell types x %d PCA dims, Sinkhorn reg=%g "
@@ -180,22 +224,180 @@ def main():
                                % (args.config, N, K, cfg["n_dims"], args.reg),
                    "n_patients": N, "n_cell_types": K, "n_pca": cfg["n_dims"], "reg": args.reg,
                    "pairs_per_step": N * N,
-                   "parallelism": "pair-grid rows dealt round-robin over %d GPU(s)%s"
-                                  % (world, " + 1 RCCL all-gather" if world > 1 else "")},
+                   "parallelism": "pair-grid rows dealt round-robin over %d GPU(s)%s; %s"
+                                  % (n_gpus, " + 1 RCCL all-gather" if n_gpus > 1 else "",
+                                     "one process per GPU (pilot_ot_comm_*)" if world > 1 else
+                                     ("one process, %d devices (pilot_ot_multi_*)" % n_gpus if single_process_multi
+                                      else "single device"))},
         "roofline": roofline, "roofline_hbm": roofline_hbm,
+        "timed_region": "P, M resident in HBM -> N x N matrix resident in HBM (every rank); see value_host_to_host",
     }
+    if per_rank:
+        out["multi_gpu"] = per_rank
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(P, M, args.reg, args.cpu_seconds, E)
+    extras = not args.no_extras
+    if extras:
+        # the shape that scales: every rank takes part, so it is measured at every N
+        out["c4"] = bench_c4(L, rank, world, comm, args, single_process_multi)
+    if rank == 0 and world == 1 and not single_process_multi:
+        if extras:
+            out["value_host_to_host"] = host_to_host(P, M, args.reg, prec)
+            out["reg_sweep"] = reg_sweep(P, M, K)
+            out["exact_emd"] = exact_emd_brief(L, P, M)
+        if not args.no_cpu_baseline:
+            cb, cb_all, upd = cpu_baseline(P, M, args.reg, args.cpu_seconds, E, iters)
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cb, cb_all
+            out["equal_work_note"] = upd
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if single_process_multi:
+        mp.close()
+    else:
+        plan.close()
+    if comm:
+        comm.barrier()
+        d_stage.free(); d_full.free()
+        comm.close()
+
+
+# ---- extras ---------------------------------------------------------------------------------------------------------
+def host_to_host(P, M, reg, prec, reps=10):
+    """numpy in -> numpy out through the host-buffer entry point (H2D of P and M, all kernels, D2H of the matrix):
+    SURVEY.md 8(d)'s definition of t.  PCIe-inclusive; never `value`."""
+    from pilot_amd import engine
+    N = P.shape[0]
+    for _ in range(3):
+        engine.sinkhorn_grid(P, M, reg, precision=prec)
+    t = time.perf_counter()
+    for _ in range(reps):
+        engine.sinkhorn_grid(P, M, reg, precision=prec)
+    dt = (time.perf_counter() - t) / reps
+    return {"value": round(N * N / dt, 1), "unit": "pairs/s", "ms_per_call": round(1e3 * dt, 4),
+            "what": "engine.sinkhorn_grid(P, M): host numpy arrays in, host numpy matrix out, mean of %d calls" % reps}
+
+
+def reg_sweep(P, M, K, regs=(0.01, 0.1, 1.0), row_step=60):
+    """BASELINE config 3 names the sweep reg 0.01 / 0.1 / 1.0: per reg the step time with precision='auto', what AUTO
+    picked, and parity against the oracle on rows 0, 60, 120, ... (10 rows x 600 columns)."""
+    from oracle import oracle as O
+    from pilot_amd import _lib, engine
+    N = P.shape[0]
+    rows = []
+    plan = engine.DevicePlan(P, M)
+    for reg in regs:
+        t = time.perf_counter()                 # the oracle leg below leaves the GPU idle: warm the clocks back up
+        while time.perf_counter() - t < 0.3:
+            plan.run(reg, precision="auto")
+            plan.sync()
+        reps = 3 if reg < 0.05 else 20
+        t = time.perf_counter()
+        for _ in range(reps):
+            plan.run(reg, precision="auto")
+        plan.sync()
+        dt = (time.perf_counter() - t) / reps
+        E, info = plan.fetch()
+        Eo, io = O.sinkhorn_grid(P, M, reg, row_step=row_step, n_threads=os.cpu_count() or 1, return_info=True)
+        Es, its, fl = E[::row_step], info["iters"][::row_step], info["flags"][::row_step]
+        last = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((fl & _lib.FLAG_ABSORB_LAST) > 0)
+        same = its == io["iters"]
+        d = np.abs(Es - Eo)
+        rows.append({
+            "reg": reg, "ms_per_matrix": round(1e3 * dt, 4), "pairs_per_s": round(N * N / dt, 1),
+            "pairs_f64": int(((info["flags"] & _lib.FLAG_F64) > 0).sum()), "pairs_total": int(E.size),
+            "mean_updates_gpu": round(float(info["iters"].mean()), 2),
+            "sample_pairs": int(Eo.size),
+            "sample_max_abs_diff": float(d[~last].max()),
+            "sample_max_abs_diff_same_update_count": float(d[same & ~last].max()) if (same & ~last).any() else None,
+            "sample_same_update_count": int(same.sum()),
+            "sample_capped_oracle": int((io["iters"] >= 1000).sum()), "sample_capped_gpu": int((its >= 1000).sum()),
+            "sample_absorb_on_last_oracle": int(((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0).sum()),
+            "sample_absorb_on_last_gpu": int(((fl & _lib.FLAG_ABSORB_LAST) > 0).sum()),
+            "sample_mean_updates_oracle": round(float(io["iters"].mean()), 2),
+        })
     plan.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return {"precision": "auto", "sample": "rows 0,%d,.. x all columns" % row_step, "rows": rows}
 
 
-def cpu_baseline(P, M, reg, budget_s, E_gpu):
+def exact_emd_brief(L, P, M, reps=3):
+    """The reference's DEFAULT mode (regularized='unreg', Trajectory.py:507-511) on the same cohort, device-resident."""
+    from pilot_amd import _lib, engine
+    N = P.shape[0]
+    plan = engine.DevicePlan(P, M)
+    sym = 2 if plan.sym else 0             # PILOT_OT_EMD_MIRROR for a symmetric cost
+    def run():
+        _lib.check(L.pilot_ot_emd_grid_dev(plan.plan, plan.dP, plan.dM, sym, 0, N, 1, plan.dE, plan.dIt, None))
+    t = time.perf_counter()
+    while time.perf_counter() - t < 0.2:
+        run(); plan.sync()
+    t = time.perf_counter()
+    for _ in range(reps):
+        run()
+    plan.sync()
+    dt = (time.perf_counter() - t) / reps
+    plan.close()
+    return {"ms_per_matrix": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1), "dtype": "f64",
+            "what": "pilot_ot_emd_grid_dev, all N^2 ordered pairs (symmetric cost: j >= i solved, mirrored)"}
+
+
+def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
+    """BASELINE configs[3]: 2000 patients x 100 cell types, reg 0.1 -- 55 ms of pair grid on one GPU, the shape whose row
+    shards stay long enough to scale (c3's 1.5 ms step is bounded by its slowest pairs' serial chains)."""
+    from pilot_amd import _lib, engine, multi, sharding
+    from pilot_amd.synthetic import CONFIGS, make_problem
+    P, M = make_problem(**CONFIGS["c4"])
+    N = P.shape[0]
+    if single_process_multi:
+        devices = [0] * args.gpus if args.logical_shards else list(range(args.gpus))
+        mp = multi.MultiPlan(P, M, devices=devices)
+        mp.sinkhorn(0.1, precision="fp32"); mp.sync()
+        t = time.perf_counter()
+        for _ in range(steps):
+            mp.sinkhorn(0.1, precision="fp32")
+        mp.sync()
+        dt = (time.perf_counter() - t) / steps
+        g, ga = mp.times_ms()
+        mp.close()
+        return {"workload": "c4: 2000 x 100, reg 0.1, f32", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
+                "grid_ms_per_shard": [round(float(x), 3) for x in g], "gather_ms": round(ga, 3)}
+    rb, re_, rs = sharding.shard_rows(N, rank, world)
+    n_pad = sharding.n_padded_rows(N, world)
+    plan = engine.DevicePlan(P, M, n_rows_max=n_pad)
+    plan.enable_timing(True)
+    if comm:
+        d_stage, d_full = DevBuf(L, 8 * world * n_pad * N), DevBuf(L, 8 * N * N)
+        _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, np.zeros(n_pad * N).ctypes.data, 8 * n_pad * N))
+
+    def step():
+        plan.run(0.1, row_begin=rb, row_end=re_, row_step=rs, precision="fp32")
+        if comm:
+            comm.all_gather_rows(plan.dE, n_pad, N, d_stage.p, d_full.p)
+
+    def fence():
+        if comm:
+            comm.barrier()
+        plan.sync()
+    step(); fence()
+    t = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = (time.perf_counter() - t) / steps
+    if comm:
+        dt = comm.all_reduce_max(dt)
+    main_ms, _ = plan.kernel_times_ms(max_n=steps)
+    res = {"workload": "c4: 2000 x 100, reg 0.1, f32", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
+           "rank0_kernel_ms": round(float(np.mean(main_ms)), 3)}
+    if world == 1:
+        _, info = plan.fetch(n_rows=N)
+        fl = algorithmic_flops(info["iters"], P.shape[1])
+        res["roofline_frac_f32_mfma"] = round(fl / (float(np.mean(main_ms)) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    plan.close()
+    if comm:
+        d_stage.free(); d_full.free()
+    return res
+
+
+def cpu_baseline(P, M, reg, budget_s, E_gpu, iters_gpu):
     """Time the CPU oracle on a bounded sample of the SAME workload (rows 0, s, 2s, ... x all columns);
     also the checker: the sampled rows must agree with what the GPU produced."""
     from oracle import oracle as O
@@ -206,7 +408,7 @@ def cpu_baseline(P, M, reg, budget_s, E_gpu):
     n_rows = int(max(1, min(N, budget_s / max(per_pair * N, 1e-9))))
     step = max(1, N // n_rows)
     t = time.perf_counter()
-    Eo = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=1)
+    Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=1, return_info=True)
     dt1 = time.perf_counter() - t
     err = float(np.abs(E_gpu[::step] - Eo).max())
     base = {"value": round(Eo.size / dt1, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
@@ -219,7 +421,64 @@ def cpu_baseline(P, M, reg, budget_s, E_gpu):
     dt2 = time.perf_counter() - t
     allc = {"value": round(Eo2.size / dt2, 1), "unit": "pairs/s", "cores": ncpu, "kind": "port",
             "sample": "%d ordered pairs, OpenMP over pairs" % Eo2.size}
-    return base, allc
+    mo, mg = float(io["iters"].mean()), float(iters_gpu[::step].mean())
+    upd = {"oracle_mean_updates_per_pair": round(mo, 2), "gpu_mean_updates_per_pair_same_sample": round(mg, 2),
+           "gpu_over_oracle_updates": round(mg / mo, 4),
+           "note": "the f32 kernel floors POT's stopThr 1e-9 at 8 ulp * ||b||_2 (f32 cannot resolve 1e-9), so a pair stops at "
+                   "the same or an earlier error check than the fp64 oracle: `value` (f32) and `cpu_baseline` (fp64, full "
+                   "update count) are the same pairs but not the same number of updates; roofline.achieved counts only the "
+                   "updates the GPU executed"}
+    return base, allc, upd
+
+
+def bench_emd(args, L, P, M, cfg):
+    """--mode emd: the exact-OT pair grid (reference default), its own line with its own cpu_baseline."""
+    from oracle import oracle as O
+    from pilot_amd import _lib, engine
+    N, K = P.shape
+    plan = engine.DevicePlan(P, M)
+    mode = 2 if plan.sym else 0
+
+    def run():
+        _lib.check(L.pilot_ot_emd_grid_dev(plan.plan, plan.dP, plan.dM, mode, 0, N, 1, plan.dE, plan.dIt, None))
+    for _ in range(args.warmup):
+        run()
+    plan.sync()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    plan.sync()
+    dt = (time.perf_counter() - t) / args.steps
+    E = np.empty((N, N)); n_aug = np.empty((N, N), dtype=np.int32)
+    _lib.check(L.pilot_ot_memcpy_d2h(E.ctypes.data, plan.dE, 8 * N * N))
+    _lib.check(L.pilot_ot_memcpy_d2h(n_aug.ctypes.data, plan.dIt, 4 * N * N))
+    plan.close()
+    out = {
+        "metric": "exact-EMD patient-pairs/sec (full NxN matrix, reference default mode)", "value": round(N * N / dt, 1),
+        "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d patients x %d cell types, exact OT (ot.emd2 semantics), all N^2 ordered pairs"
+                               % (args.config, N, K), "n_patients": N, "n_cell_types": K},
+        "roofline": {"bound": "hbm", "achieved": round(N * N * (2 * K * 8 + 8) / dt / 1e9, 3), "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "frac": round(N * N * (2 * K * 8 + 8) / dt / 1e9 / PEAK_HBM_GBS, 6), "traffic": None,
+                     "note": "latency / instruction-issue-bound augmenting-path search, one wavefront per pair; "
+                             "the streaming-model bytes are what the north star names",
+                     "mean_augmentations_per_solved_pair": round(float(n_aug[np.triu_indices(N)].mean()), 2)},
+    }
+    if not args.no_cpu_baseline:
+        ncpu = os.cpu_count() or 1
+        step = max(1, N // 4)
+        t = time.perf_counter()
+        Eo = O.emd_grid(P, M, row_step=step, n_threads=1)
+        dt1 = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": round(Eo.size / dt1, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": "rows 0,%d,.. x all columns (%d pairs), oracle SSP solver (not POT's network simplex); "
+                                         "max|gpu-oracle| = %.2e" % (step, Eo.size, float(np.abs(E[::step] - Eo).max()))}
+        t = time.perf_counter()
+        Eo2 = O.emd_grid(P, M, row_step=max(1, step // 8), n_threads=ncpu)
+        out["cpu_baseline_all_cores"] = {"value": round(Eo2.size / (time.perf_counter() - t), 1), "unit": "pairs/s",
+                                         "cores": ncpu, "kind": "port", "sample": "%d pairs, OpenMP over pairs" % Eo2.size}
+    return out
 
 
 if __name__ == "__main__":

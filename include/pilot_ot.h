@@ -39,7 +39,8 @@ extern "C" {
 #define PILOT_OT_OK 0
 #define PILOT_OT_EINVAL (-1)  /* bad argument                                              */
 #define PILOT_OT_EHIP (-2)    /* HIP runtime error / no gfx950 device                      */
-#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support (K > 128, ...)      */
+#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support                     */
+#define PILOT_OT_ERCCL (-4)   /* RCCL error / librccl missing (multi-GPU entry points only) */
 
 /* precision of the Sinkhorn pair-grid kernel */
 #define PILOT_OT_PREC_AUTO 0 /* f32 when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
@@ -147,6 +148,60 @@ int pilot_ot_emd_grid(const double *P, int N, int K, const double *M, int mode,
 int pilot_ot_emd_grid_dev(pilot_ot_plan *plan, const double *d_P, const double *d_M, int mode,
                           int row_begin, int row_end, int row_step, double *d_emd, int *d_n_aug,
                           void *stream);
+
+/* fill the strictly-lower triangle of the N x N device matrix from the upper one (what PILOT_OT_EMD_MIRROR runs) */
+int pilot_ot_mirror_upper_dev(double *d_emd, int N, void *stream);
+
+/* ---- multi-GPU: the pair grid row-sharded over the GPUs of one node ---------------------------------------------------
+ * The N^2 pair problems of Trajectory.py:505-515 are independent given the replicated proportions and cost, so the
+ * grid is partitioned, never exchanged: shard s of G solves rows s, s+G, s+2G, ... against all N columns; the only
+ * exchange step is ONE all-gather of the row blocks (RCCL over xGMI) followed by a device-side row interleave.  A pair
+ * is solved by the same kernel with the same arithmetic whichever shard owns it: the assembled matrix is bit-identical
+ * to the single-device one.  librccl is loaded (dlopen) by the first call that needs it.
+ *
+ * (1) one process drives G devices: pilot_ot_multi_*  (ncclCommInitAll, one plan + one stream per device, grouped
+ *     ncclAllGather).  devices[s] is the HIP device of shard s.  gather: PILOT_OT_GATHER_RCCL needs G distinct devices
+ *     and leaves the full matrix on EVERY device; PILOT_OT_GATHER_COPY assembles it on the device of shard 0 with
+ *     peer copies and also accepts repeated device ids (logical shards on one GPU); PILOT_OT_GATHER_AUTO picks RCCL
+ *     when the devices are distinct.  All calls are asynchronous on the shards' own streams until _sync / _fetch. */
+#define PILOT_OT_GATHER_AUTO 0
+#define PILOT_OT_GATHER_RCCL 1
+#define PILOT_OT_GATHER_COPY 2
+typedef struct pilot_ot_multi pilot_ot_multi;
+int pilot_ot_multi_create(int N, int K, const int *devices, int n_shards, int gather, pilot_ot_multi **m);
+int pilot_ot_multi_destroy(pilot_ot_multi *m);
+int pilot_ot_multi_set_inputs(pilot_ot_multi *m, const double *P, const double *M);   /* host -> every device */
+int pilot_ot_multi_sinkhorn(pilot_ot_multi *m, double reg, int num_iter_max, double stop_thr, double tau,
+                            int check_period, int precision, double f32_floor_ulps, int cost_is_symmetric);
+int pilot_ot_multi_emd(pilot_ot_multi *m, int cost_is_symmetric);  /* symmetric: columns >= row solved, mirrored after the gather */
+int pilot_ot_multi_sync(pilot_ot_multi *m);
+/* emd: N x N from the device of shard 0; iters / err / flags (nullable; exact mode: iters = n_aug) are fetched shard by
+ * shard and interleaved on the host */
+int pilot_ot_multi_fetch(pilot_ot_multi *m, double *emd, int *iters, double *err, int *flags);
+int pilot_ot_multi_device_matrix(pilot_ot_multi *m, int shard, double **d_full);      /* the assembled matrix in HBM */
+/* HIP-event times of the last call: grid_ms[s] = shard s's kernels; gather_ms = end of the slowest shard -> matrix assembled */
+int pilot_ot_multi_times(pilot_ot_multi *m, float *grid_ms, float *gather_ms);
+/* host-buffer forms (context cached per calling thread, released by pilot_ot_shutdown) */
+int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const double *M, double reg, int num_iter_max,
+                                 double stop_thr, double tau, int check_period, int precision, double f32_floor_ulps,
+                                 int cost_is_symmetric, const int *devices, int n_devices, int gather,
+                                 double *emd, int *iters, double *err, int *flags);
+int pilot_ot_emd_grid_multi(const double *P, int N, int K, const double *M, int cost_is_symmetric,
+                            const int *devices, int n_devices, int gather, double *emd, int *n_aug);
+
+/* (2) one process PER device (a launcher starts G of them): every rank calls the single-device *_dev entry points on
+ *     its own rows (row_begin = rank, row_step = n_ranks) and assembles the matrix with pilot_ot_comm_all_gather_rows.
+ *     Rank 0 creates the id and hands its 128 bytes to the others by whatever means the host language has. */
+#define PILOT_OT_UNIQUE_ID_BYTES 128
+typedef struct pilot_ot_comm pilot_ot_comm;
+int pilot_ot_comm_unique_id(char *uid);                                   /* PILOT_OT_UNIQUE_ID_BYTES bytes out */
+int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pilot_ot_comm **comm);   /* on the current device */
+int pilot_ot_comm_destroy(pilot_ot_comm *comm);
+/* d_local: n_pad x N row block of this rank (n_pad = ceil(N / n_ranks), unused rows zero); d_stage: n_ranks * n_pad x N
+ * scratch; d_full: N x N result on every rank.  Enqueued on `stream`. */
+int pilot_ot_comm_all_gather_rows(pilot_ot_comm *comm, const double *d_local, int n_pad, int N, double *d_stage,
+                                  double *d_full, void *stream);
+int pilot_ot_comm_all_reduce_max(pilot_ot_comm *comm, double *d_vals, int n, void *stream);  /* in place; also the barrier */
 
 /* ---- cell-level W2 pair grid (EXTENSION: not in the reference; BASELINE config 5) ------ */
 /* Compares patients by their raw cell clouds instead of cell-type proportions.  X: n_cells x D float32 embedding

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpilot_ot.so")
 
-OK, EINVAL, EHIP, ENOTSUP = 0, -1, -2, -3
+OK, EINVAL, EHIP, ENOTSUP, ERCCL = 0, -1, -2, -3, -4
 PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2}
 METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5}
 
@@ -29,7 +29,15 @@ SYMBOLS = [
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_centroid_medians", "pilot_ot_cell_w2_grid",
+    "pilot_ot_mirror_upper_dev",
+    "pilot_ot_multi_create", "pilot_ot_multi_destroy", "pilot_ot_multi_set_inputs", "pilot_ot_multi_sinkhorn",
+    "pilot_ot_multi_emd", "pilot_ot_multi_sync", "pilot_ot_multi_fetch", "pilot_ot_multi_device_matrix",
+    "pilot_ot_multi_times", "pilot_ot_sinkhorn_grid_multi", "pilot_ot_emd_grid_multi",
+    "pilot_ot_comm_unique_id", "pilot_ot_comm_init_rank", "pilot_ot_comm_destroy",
+    "pilot_ot_comm_all_gather_rows", "pilot_ot_comm_all_reduce_max",
 ]
+GATHER = {"auto": 0, "rccl": 1, "copy": 2}
+UNIQUE_ID_BYTES = 128
 
 _lib = None
 
@@ -78,6 +86,25 @@ def load() -> ctypes.CDLL:
                                         dp, ip, dp]
     L.pilot_ot_emd_grid.argtypes = [dp, c_int, c_int, dp, c_int, c_int, c_int, c_int, dp, ip]
     L.pilot_ot_emd_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.pilot_ot_mirror_upper_dev.argtypes = [c_vp, c_int, c_vp]
+    L.pilot_ot_multi_create.argtypes = [c_int, c_int, ip, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_multi_destroy.argtypes = [c_vp]
+    L.pilot_ot_multi_set_inputs.argtypes = [c_vp, dp, dp]
+    L.pilot_ot_multi_sinkhorn.argtypes = [c_vp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl, c_int]
+    L.pilot_ot_multi_emd.argtypes = [c_vp, c_int]
+    L.pilot_ot_multi_sync.argtypes = [c_vp]
+    L.pilot_ot_multi_fetch.argtypes = [c_vp, dp, ip, dp, ip]
+    L.pilot_ot_multi_device_matrix.argtypes = [c_vp, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_multi_times.argtypes = [c_vp, fp, fp]
+    L.pilot_ot_sinkhorn_grid_multi.argtypes = [dp, c_int, c_int, dp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl,
+                                               c_int, ip, c_int, c_int, dp, ip, dp, ip]
+    L.pilot_ot_emd_grid_multi.argtypes = [dp, c_int, c_int, dp, c_int, ip, c_int, c_int, dp, ip]
+    L.pilot_ot_comm_unique_id.argtypes = [ctypes.c_char_p]
+    L.pilot_ot_comm_init_rank.argtypes = [ctypes.c_char_p, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_comm_destroy.argtypes = [c_vp]
+    L.pilot_ot_comm_all_gather_rows.argtypes = [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]
+    L.pilot_ot_comm_all_reduce_max.argtypes = [c_vp, c_vp, c_int, c_vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name != "pilot_ot_last_error":
@@ -94,6 +121,8 @@ def check(rc: int) -> None:
         raise ValueError("pilot_ot: " + msg)
     if rc == ENOTSUP:
         raise NotImplementedError("pilot_ot: " + msg)
+    if rc == ERCCL:
+        raise PilotOTError("pilot_ot (RCCL): " + msg)
     raise PilotOTError("pilot_ot (HIP): " + msg)
 
 

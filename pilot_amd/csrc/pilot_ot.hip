@@ -11,33 +11,29 @@
 #include <cstring>
 #include <new>
 
-#include "../../include/pilot_ot.h"
+#include "abi_common.hpp"
 #include "sinkhorn_launch.hpp"
 #include "emd_kernels.hpp"
 #include "prepass_kernels.hpp"
 #include "cellw2_kernels.hpp"
 
-#define PILOT_API extern "C" __attribute__((visibility("default")))
-
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char *fmt, ...) {
+namespace pilot {
+int abi_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
+}  // namespace pilot
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(PILOT_OT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                                   \
-    } while (0)
+namespace {
+
+#define fail(...) pilot::abi_fail(__VA_ARGS__)
 
 // ------------------------------------------------------------------------------------------------
 // K1: centroid cost matrix (scipy pdist + squareform, Trajectory.py:468-469).  K <= a few hundred,
@@ -606,6 +602,7 @@ int host_fetch(const Fetch *f, int n) {
 
 PILOT_API int pilot_ot_shutdown(void) {
     g_host.release();
+    pilot::abi_multi_release();
     return PILOT_OT_OK;
 }
 
@@ -681,6 +678,13 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         hipLaunchKernelGGL(pilot::emd_mirror_kernel, dim3(1024), dim3(256), 0, s, d_emd, N);
         HIP_TRY(hipGetLastError());
     }
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_mirror_upper_dev(double *d_emd, int N, void *stream) {
+    if (!d_emd || N <= 0) return fail(PILOT_OT_EINVAL, "bad argument");
+    hipLaunchKernelGGL(pilot::emd_mirror_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), d_emd, N);
+    HIP_TRY(hipGetLastError());
     return PILOT_OT_OK;
 }
 

@@ -1,0 +1,487 @@
+// Multi-GPU forms of the pair-grid entry points (include/pilot_ot.h, section "multi-GPU").
+//
+// The N^2 pair problems of pilotpy/tools/Trajectory.py:505-515 are independent given the replicated N x K proportions and
+// K x K cost, so the grid is PARTITIONED, never exchanged: shard s of G solves rows s, s+G, s+2G, ... (round-robin: the
+// per-pair update counts are ragged and, in exact mode with a symmetric cost, only columns >= row are solved, so cyclic
+// rows balance both) against all N columns.  The only exchange step is assembling the finished matrix: ONE all-gather
+// of the row blocks over RCCL (xGMI), then a device-side row interleave.
+//
+// Two ways to run it, same kernels and same bytes either way:
+//   * pilot_ot_multi_*: ONE process drives G devices (ncclCommInitAll, one plan + one stream per device, grouped
+//     ncclAllGather) -- what tl.wasserstein_distance(engine_options={"n_devices": G}) uses;
+//   * pilot_ot_comm_*: one process PER device (ncclCommInitRank with a unique id the host language passes around),
+//     each calling the single-device *_dev entry points on its own rows -- what bench.py uses under a launcher.
+// librccl is loaded lazily (dlopen) by the first call that needs it, so single-GPU users never pay for it.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "abi_common.hpp"
+
+namespace {
+
+#define fail(...) pilot::abi_fail(__VA_ARGS__)
+
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.h) return PILOT_OT_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(PILOT_OT_ERCCL, "librccl not found: %s", dlerror());
+    RcclApi a;
+    a.h = h;
+#define PILOT_SYM(field, name)                                                                   \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                               \
+    if (!a.field) { dlclose(h); return fail(PILOT_OT_ERCCL, "librccl lacks %s", name); }
+    PILOT_SYM(GetUniqueId, "ncclGetUniqueId")
+    PILOT_SYM(CommInitRank, "ncclCommInitRank")
+    PILOT_SYM(CommInitAll, "ncclCommInitAll")
+    PILOT_SYM(CommDestroy, "ncclCommDestroy")
+    PILOT_SYM(AllGather, "ncclAllGather")
+    PILOT_SYM(AllReduce, "ncclAllReduce")
+    PILOT_SYM(GroupStart, "ncclGroupStart")
+    PILOT_SYM(GroupEnd, "ncclGroupEnd")
+    PILOT_SYM(GetErrorString, "ncclGetErrorString")
+#undef PILOT_SYM
+    g_rccl = a;
+    return PILOT_OT_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess)                                                                               \
+            return fail(PILOT_OT_ERCCL, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, \
+                        __LINE__);                                                                           \
+    } while (0)
+
+// rank-major stage (G blocks of n_pad rows; block w row t = grid row w + t*G)  ->  full N x N matrix
+__global__ void interleave_rows_kernel(const double *__restrict__ stage, int G, int n_pad, int N,
+                                       double *__restrict__ full) {
+    const long total = (long)N * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / N), col = (int)(idx % N);
+        full[idx] = stage[((size_t)(row % G) * n_pad + row / G) * N + col];
+    }
+}
+
+int launch_interleave(const double *stage, int G, int n_pad, int N, double *full, hipStream_t s) {
+    long blocks = ((long)N * N + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(interleave_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, stage, G, n_pad, N, full);
+    HIP_TRY(hipGetLastError());
+    return PILOT_OT_OK;
+}
+
+struct DeviceGuard {   // restores the calling thread's current device
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
+}  // namespace
+
+// ================================================================================================
+// one process per device
+struct pilot_ot_comm {
+    ncclComm_t comm;
+    int n_ranks, rank, device;
+};
+
+PILOT_API int pilot_ot_comm_unique_id(char *uid) {
+    if (!uid) return fail(PILOT_OT_EINVAL, "uid is NULL");
+    static_assert(sizeof(ncclUniqueId) == PILOT_OT_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    int rc = rccl_load();
+    if (rc != PILOT_OT_OK) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(uid, &id, sizeof(id));
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pilot_ot_comm **comm) {
+    if (!uid || !comm) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(PILOT_OT_EINVAL, "rank %d of %d", rank, n_ranks);
+    int rc = rccl_load();
+    if (rc != PILOT_OT_OK) return rc;
+    pilot_ot_comm *c = new (std::nothrow) pilot_ot_comm();
+    if (!c) return fail(PILOT_OT_EINVAL, "out of host memory");
+    c->n_ranks = n_ranks; c->rank = rank; c->comm = nullptr;
+    hipError_t e = hipGetDevice(&c->device);
+    if (e != hipSuccess) { delete c; return fail(PILOT_OT_EHIP, "hipGetDevice: %s", hipGetErrorString(e)); }
+    ncclUniqueId id;
+    memcpy(&id, uid, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(PILOT_OT_ERCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    *comm = c;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_comm_destroy(pilot_ot_comm *c) {
+    if (!c) return PILOT_OT_OK;
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_comm_all_gather_rows(pilot_ot_comm *c, const double *d_local, int n_pad, int N, double *d_stage,
+                                            double *d_full, void *stream) {
+    if (!c || !d_local || !d_stage || !d_full) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (N <= 0 || n_pad != (N + c->n_ranks - 1) / c->n_ranks)
+        return fail(PILOT_OT_EINVAL, "n_pad=%d must be ceil(N / n_ranks) = %d", n_pad, (N + c->n_ranks - 1) / c->n_ranks);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RCCL_TRY(g_rccl.AllGather(d_local, d_stage, (size_t)n_pad * N, ncclDouble, c->comm, s));
+    return launch_interleave(d_stage, c->n_ranks, n_pad, N, d_full, s);
+}
+
+PILOT_API int pilot_ot_comm_all_reduce_max(pilot_ot_comm *c, double *d_vals, int n, void *stream) {
+    if (!c || !d_vals || n < 1) return fail(PILOT_OT_EINVAL, "bad argument");
+    RCCL_TRY(g_rccl.AllReduce(d_vals, d_vals, (size_t)n, ncclDouble, ncclMax, c->comm, static_cast<hipStream_t>(stream)));
+    return PILOT_OT_OK;
+}
+
+// ================================================================================================
+// one process, G devices
+namespace {
+struct Shard {
+    int device = 0, n_local = 0;
+    pilot_ot_plan *plan = nullptr;
+    hipStream_t stream = nullptr;
+    double *dP = nullptr, *dM = nullptr, *dLocal = nullptr, *dErr = nullptr, *dStage = nullptr, *dFull = nullptr;
+    int *dIt = nullptr, *dFl = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_grid = nullptr, ev_end = nullptr;
+    ncclComm_t comm = nullptr;
+};
+}  // namespace
+
+struct pilot_ot_multi {
+    int N = 0, K = 0, G = 0, n_pad = 0, gather = 0;
+    std::vector<Shard> sh;
+    bool ran = false, exact = false;
+};
+
+namespace {
+void multi_free(pilot_ot_multi *m) {
+    if (!m) return;
+    DeviceGuard guard;
+    for (Shard &s : m->sh) {
+        (void)hipSetDevice(s.device);
+        if (s.comm) (void)g_rccl.CommDestroy(s.comm);
+        if (s.plan) (void)pilot_ot_plan_destroy(s.plan);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        for (void *p : {(void *)s.dP, (void *)s.dM, (void *)s.dLocal, (void *)s.dErr, (void *)s.dStage, (void *)s.dFull,
+                        (void *)s.dIt, (void *)s.dFl})
+            if (p) (void)hipFree(p);
+        for (hipEvent_t e : {s.ev_begin, s.ev_grid, s.ev_end})
+            if (e) (void)hipEventDestroy(e);
+    }
+    delete m;
+}
+}  // namespace
+
+PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shards, int gather, pilot_ot_multi **mp) {
+    if (!mp || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (N <= 0 || K <= 0 || n_shards < 1 || n_shards > 64) return fail(PILOT_OT_EINVAL, "N=%d K=%d n_shards=%d out of range", N, K, n_shards);
+    if (gather < PILOT_OT_GATHER_AUTO || gather > PILOT_OT_GATHER_COPY) return fail(PILOT_OT_EINVAL, "unknown gather mode %d", gather);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    bool distinct = true;
+    for (int s = 0; s < n_shards; ++s) {
+        if (devices[s] < 0 || devices[s] >= n_dev) return fail(PILOT_OT_EINVAL, "device %d not visible (%d devices)", devices[s], n_dev);
+        for (int t = 0; t < s; ++t) distinct = distinct && devices[t] != devices[s];
+    }
+    if (gather == PILOT_OT_GATHER_AUTO) gather = distinct ? PILOT_OT_GATHER_RCCL : PILOT_OT_GATHER_COPY;
+    if (gather == PILOT_OT_GATHER_RCCL && !distinct)
+        return fail(PILOT_OT_EINVAL, "RCCL needs one distinct device per shard (use PILOT_OT_GATHER_COPY for logical shards)");
+    pilot_ot_multi *m = new (std::nothrow) pilot_ot_multi();
+    if (!m) return fail(PILOT_OT_EINVAL, "out of host memory");
+    m->N = N; m->K = K; m->G = n_shards; m->n_pad = (N + n_shards - 1) / n_shards; m->gather = gather;
+    m->sh.resize(n_shards);
+    DeviceGuard guard;
+    const size_t n_loc = (size_t)m->n_pad * N;
+    int rc = PILOT_OT_OK;
+    for (int s = 0; s < n_shards && rc == PILOT_OT_OK; ++s) {
+        Shard &h = m->sh[s];
+        h.device = devices[s];
+        h.n_local = (N - s + n_shards - 1) / n_shards;
+        hipError_t e = hipSetDevice(h.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&h.dP, sizeof(double) * (size_t)N * K);
+        if (e == hipSuccess) e = hipMalloc(&h.dM, sizeof(double) * (size_t)K * K);
+        if (e == hipSuccess) e = hipMalloc(&h.dLocal, sizeof(double) * n_loc);
+        if (e == hipSuccess) e = hipMalloc(&h.dErr, sizeof(double) * n_loc);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h.dIt), sizeof(int) * n_loc);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h.dFl), sizeof(int) * n_loc);
+        if (e == hipSuccess) e = hipMemset(h.dLocal, 0, sizeof(double) * n_loc);     // padding rows stay 0
+        if (e == hipSuccess && (gather == PILOT_OT_GATHER_RCCL || s == 0)) {
+            e = hipMalloc(&h.dStage, sizeof(double) * n_loc * n_shards);
+            if (e == hipSuccess) e = hipMalloc(&h.dFull, sizeof(double) * (size_t)N * N);
+        }
+        if (e == hipSuccess) e = hipEventCreate(&h.ev_begin);
+        if (e == hipSuccess) e = hipEventCreate(&h.ev_grid);
+        if (e == hipSuccess) e = hipEventCreate(&h.ev_end);
+        if (e != hipSuccess) { rc = fail(PILOT_OT_EHIP, "shard %d on device %d: %s", s, h.device, hipGetErrorString(e)); break; }
+        rc = pilot_ot_plan_create(N, K, &h.plan);
+    }
+    if (rc == PILOT_OT_OK && gather == PILOT_OT_GATHER_RCCL) {
+        rc = rccl_load();
+        if (rc == PILOT_OT_OK) {
+            std::vector<ncclComm_t> comms(n_shards, nullptr);
+            ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_shards, devices);
+            if (r != ncclSuccess) rc = fail(PILOT_OT_ERCCL, "ncclCommInitAll over %d devices: %s", n_shards, g_rccl.GetErrorString(r));
+            else for (int s = 0; s < n_shards; ++s) m->sh[s].comm = comms[s];
+        }
+    }
+    if (rc != PILOT_OT_OK) { multi_free(m); return rc; }
+    *mp = m;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_multi_destroy(pilot_ot_multi *m) {
+    multi_free(m);
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_multi_set_inputs(pilot_ot_multi *m, const double *P, const double *M) {
+    if (!m || !P || !M) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    DeviceGuard guard;
+    for (Shard &h : m->sh) {
+        HIP_TRY(hipSetDevice(h.device));
+        HIP_TRY(hipMemcpyAsync(h.dP, P, sizeof(double) * (size_t)m->N * m->K, hipMemcpyHostToDevice, h.stream));
+        HIP_TRY(hipMemcpyAsync(h.dM, M, sizeof(double) * (size_t)m->K * m->K, hipMemcpyHostToDevice, h.stream));
+    }
+    for (Shard &h : m->sh) {
+        HIP_TRY(hipSetDevice(h.device));
+        HIP_TRY(hipStreamSynchronize(h.stream));      // the caller's buffers are free again on return
+    }
+    return PILOT_OT_OK;
+}
+
+namespace {
+// assemble the row blocks: full N x N on every device (RCCL) or on the device of shard 0 (peer copies)
+int multi_gather(pilot_ot_multi *m, bool mirror) {
+    const size_t n_loc = (size_t)m->n_pad * m->N;
+    if (m->gather == PILOT_OT_GATHER_RCCL) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (Shard &h : m->sh) {
+            ncclResult_t r = g_rccl.AllGather(h.dLocal, h.dStage, n_loc, ncclDouble, h.comm, h.stream);
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(PILOT_OT_ERCCL, "ncclAllGather: %s", g_rccl.GetErrorString(r)); }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        for (Shard &h : m->sh) {
+            HIP_TRY(hipSetDevice(h.device));
+            int rc = launch_interleave(h.dStage, m->G, m->n_pad, m->N, h.dFull, h.stream);
+            if (rc == PILOT_OT_OK && mirror) rc = pilot_ot_mirror_upper_dev(h.dFull, m->N, h.stream);
+            if (rc != PILOT_OT_OK) return rc;
+            HIP_TRY(hipEventRecord(h.ev_end, h.stream));
+        }
+        return PILOT_OT_OK;
+    }
+    Shard &h0 = m->sh[0];
+    HIP_TRY(hipSetDevice(h0.device));
+    for (int s = 0; s < m->G; ++s) {
+        Shard &h = m->sh[s];
+        if (s > 0) HIP_TRY(hipStreamWaitEvent(h0.stream, h.ev_grid, 0));
+        if (h.device == h0.device)
+            HIP_TRY(hipMemcpyAsync(h0.dStage + s * n_loc, h.dLocal, sizeof(double) * n_loc, hipMemcpyDeviceToDevice, h0.stream));
+        else
+            HIP_TRY(hipMemcpyPeerAsync(h0.dStage + s * n_loc, h0.device, h.dLocal, h.device, sizeof(double) * n_loc, h0.stream));
+    }
+    int rc = launch_interleave(h0.dStage, m->G, m->n_pad, m->N, h0.dFull, h0.stream);
+    if (rc == PILOT_OT_OK && mirror) rc = pilot_ot_mirror_upper_dev(h0.dFull, m->N, h0.stream);
+    if (rc != PILOT_OT_OK) return rc;
+    HIP_TRY(hipEventRecord(h0.ev_end, h0.stream));
+    return PILOT_OT_OK;
+}
+}  // namespace
+
+PILOT_API int pilot_ot_multi_sinkhorn(pilot_ot_multi *m, double reg, int num_iter_max, double stop_thr, double tau,
+                                      int check_period, int precision, double f32_floor_ulps, int cost_is_symmetric) {
+    if (!m) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    DeviceGuard guard;
+    for (int s = 0; s < m->G; ++s) {
+        Shard &h = m->sh[s];
+        HIP_TRY(hipSetDevice(h.device));
+        HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
+        int rc = pilot_ot_sinkhorn_grid_dev(h.plan, h.dP, h.dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
+                                            f32_floor_ulps, cost_is_symmetric, s, m->N, m->G, h.dLocal, h.dIt, h.dErr,
+                                            h.dFl, h.stream);
+        if (rc != PILOT_OT_OK) return rc;
+        HIP_TRY(hipEventRecord(h.ev_grid, h.stream));
+    }
+    m->ran = true; m->exact = false;
+    return multi_gather(m, false);
+}
+
+PILOT_API int pilot_ot_multi_emd(pilot_ot_multi *m, int cost_is_symmetric) {
+    if (!m) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    DeviceGuard guard;
+    const size_t n_loc = (size_t)m->n_pad * m->N;
+    for (int s = 0; s < m->G; ++s) {
+        Shard &h = m->sh[s];
+        HIP_TRY(hipSetDevice(h.device));
+        HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
+        HIP_TRY(hipMemsetAsync(h.dLocal, 0, sizeof(double) * n_loc, h.stream));
+        HIP_TRY(hipMemsetAsync(h.dIt, 0, sizeof(int) * n_loc, h.stream));
+        int rc = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, cost_is_symmetric ? PILOT_OT_EMD_UPPER : PILOT_OT_EMD_ALL, s, m->N,
+                                       m->G, h.dLocal, h.dIt, h.stream);
+        if (rc != PILOT_OT_OK) return rc;
+        HIP_TRY(hipEventRecord(h.ev_grid, h.stream));
+    }
+    m->ran = true; m->exact = true;
+    return multi_gather(m, cost_is_symmetric != 0);
+}
+
+PILOT_API int pilot_ot_multi_sync(pilot_ot_multi *m) {
+    if (!m) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    DeviceGuard guard;
+    for (Shard &h : m->sh) {
+        HIP_TRY(hipSetDevice(h.device));
+        HIP_TRY(hipStreamSynchronize(h.stream));
+    }
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_multi_fetch(pilot_ot_multi *m, double *emd, int *iters, double *err, int *flags) {
+    if (!m || !emd) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (!m->ran) return fail(PILOT_OT_EINVAL, "nothing has been computed on this multi-GPU plan yet");
+    int rc = pilot_ot_multi_sync(m);
+    if (rc != PILOT_OT_OK) return rc;
+    DeviceGuard guard;
+    const int N = m->N, G = m->G;
+    HIP_TRY(hipSetDevice(m->sh[0].device));
+    HIP_TRY(hipMemcpy(emd, m->sh[0].dFull, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost));
+    if (!iters && !err && !flags) return PILOT_OT_OK;
+    // per-pair diagnostics are not part of the assembled matrix: fetched shard by shard, interleaved on the host
+    const size_t n_loc = (size_t)m->n_pad * N;
+    std::vector<int> ti(iters || flags ? n_loc : 0);
+    std::vector<double> te(err ? n_loc : 0);
+    for (int s = 0; s < G; ++s) {
+        Shard &h = m->sh[s];
+        HIP_TRY(hipSetDevice(h.device));
+        const size_t n_got = (size_t)h.n_local * N;
+        auto scatter_i = [&](int *dst) { for (int t = 0; t < h.n_local; ++t) memcpy(dst + (size_t)(s + t * G) * N, ti.data() + (size_t)t * N, sizeof(int) * N); };
+        if (iters) { HIP_TRY(hipMemcpy(ti.data(), h.dIt, sizeof(int) * n_got, hipMemcpyDeviceToHost)); scatter_i(iters); }
+        if (flags && !m->exact) { HIP_TRY(hipMemcpy(ti.data(), h.dFl, sizeof(int) * n_got, hipMemcpyDeviceToHost)); scatter_i(flags); }
+        if (err && !m->exact) {
+            HIP_TRY(hipMemcpy(te.data(), h.dErr, sizeof(double) * n_got, hipMemcpyDeviceToHost));
+            for (int t = 0; t < h.n_local; ++t) memcpy(err + (size_t)(s + t * G) * N, te.data() + (size_t)t * N, sizeof(double) * N);
+        }
+    }
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_multi_device_matrix(pilot_ot_multi *m, int shard, double **d_full) {
+    if (!m || !d_full || shard < 0 || shard >= m->G) return fail(PILOT_OT_EINVAL, "bad argument");
+    if (!m->sh[shard].dFull) return fail(PILOT_OT_EINVAL, "with PILOT_OT_GATHER_COPY only shard 0 holds the assembled matrix");
+    *d_full = m->sh[shard].dFull;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_multi_times(pilot_ot_multi *m, float *grid_ms, float *gather_ms) {
+    if (!m || !grid_ms || !gather_ms) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (!m->ran) return fail(PILOT_OT_EINVAL, "nothing has been computed on this multi-GPU plan yet");
+    int rc = pilot_ot_multi_sync(m);
+    if (rc != PILOT_OT_OK) return rc;
+    DeviceGuard guard;
+    for (int s = 0; s < m->G; ++s) {
+        HIP_TRY(hipSetDevice(m->sh[s].device));
+        HIP_TRY(hipEventElapsedTime(&grid_ms[s], m->sh[s].ev_begin, m->sh[s].ev_grid));
+    }
+    // the gather ends when shard 0's matrix is assembled; it can start only when the slowest shard is done
+    HIP_TRY(hipSetDevice(m->sh[0].device));
+    float total = 0.f;
+    HIP_TRY(hipEventElapsedTime(&total, m->sh[0].ev_begin, m->sh[0].ev_end));
+    float slowest = 0.f;
+    for (int s = 0; s < m->G; ++s) slowest = grid_ms[s] > slowest ? grid_ms[s] : slowest;
+    *gather_ms = total - slowest;
+    return PILOT_OT_OK;
+}
+
+// ================================================================================================
+// host-buffer convenience: numpy in, numpy out, over several devices (per-thread cached context)
+namespace {
+struct MultiCtx {
+    pilot_ot_multi *m = nullptr;
+    std::vector<int> devices;
+    int gather = 0;
+};
+thread_local MultiCtx g_multi;
+
+int multi_ctx(int N, int K, const int *devices, int n_devices, int gather, pilot_ot_multi **out) {
+    MultiCtx &c = g_multi;
+    const bool same = c.m && c.m->N == N && c.m->K == K && c.gather == gather && (int)c.devices.size() == n_devices &&
+                      memcmp(c.devices.data(), devices, sizeof(int) * n_devices) == 0;
+    if (!same) {
+        if (c.m) multi_free(c.m);
+        c.m = nullptr;
+        int rc = pilot_ot_multi_create(N, K, devices, n_devices, gather, &c.m);
+        if (rc != PILOT_OT_OK) return rc;
+        c.devices.assign(devices, devices + n_devices);
+        c.gather = gather;
+    }
+    *out = c.m;
+    return PILOT_OT_OK;
+}
+}  // namespace
+
+namespace pilot {
+void abi_multi_release() {
+    if (g_multi.m) multi_free(g_multi.m);
+    g_multi.m = nullptr;
+    g_multi.devices.clear();
+}
+}  // namespace pilot
+
+PILOT_API int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const double *M, double reg, int num_iter_max,
+                                           double stop_thr, double tau, int check_period, int precision,
+                                           double f32_floor_ulps, int cost_is_symmetric, const int *devices,
+                                           int n_devices, int gather, double *emd, int *iters, double *err, int *flags) {
+    if (!P || !M || !emd || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (precision == PILOT_OT_PREC_AUTO) {          // decide once, on the host, so every shard runs the same kernels
+        double mx = 0.0;
+        for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
+        precision = pilot_ot_auto_precision(mx / reg);
+    }
+    pilot_ot_multi *m = nullptr;
+    int rc = multi_ctx(N, K, devices, n_devices, gather, &m);
+    if (rc == PILOT_OT_OK) rc = pilot_ot_multi_set_inputs(m, P, M);
+    if (rc == PILOT_OT_OK)
+        rc = pilot_ot_multi_sinkhorn(m, reg, num_iter_max, stop_thr, tau, check_period, precision, f32_floor_ulps,
+                                     cost_is_symmetric);
+    if (rc == PILOT_OT_OK) rc = pilot_ot_multi_fetch(m, emd, iters, err, flags);
+    return rc;
+}
+
+PILOT_API int pilot_ot_emd_grid_multi(const double *P, int N, int K, const double *M, int cost_is_symmetric,
+                                      const int *devices, int n_devices, int gather, double *emd, int *n_aug) {
+    if (!P || !M || !emd || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    pilot_ot_multi *m = nullptr;
+    int rc = multi_ctx(N, K, devices, n_devices, gather, &m);
+    if (rc == PILOT_OT_OK) rc = pilot_ot_multi_set_inputs(m, P, M);
+    if (rc == PILOT_OT_OK) rc = pilot_ot_multi_emd(m, cost_is_symmetric);
+    if (rc == PILOT_OT_OK) rc = pilot_ot_multi_fetch(m, emd, n_aug, nullptr, nullptr);
+    return rc;
+}

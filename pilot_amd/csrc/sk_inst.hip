@@ -61,12 +61,14 @@ hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const
     const int tiles = n_rows > 0 ? ((N + ORDER_JW - 1) / ORDER_JW) * ((n_rows + ORDER_RI - 1) / ORDER_RI) : 0;
     const int K4 = (K + 3) & ~3;
     const size_t lds = sizeof(float) * ((size_t)K4 * (ORDER_JW + 1) + (size_t)ORDER_RI * K4) + sizeof(int) * ORDER_NB;
-    static bool attr_set = false;     // more than 64 KB of dynamic LDS (K > 112) needs the opt-in; once per process
-    if (!attr_set) {
+    static bool attr_set[64] = {};    // more than 64 KB of dynamic LDS (K > 112) needs the opt-in; once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sinkhorn_prep_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(sinkhorn_prep_kernel<C>, dim3(tiles + PREP_SETUP_BLOCKS), dim3(256), lds, s, M, K, RT, reg, static_cast<T *>(img), P,
                        static_cast<T *>(Pslot), N, write_tail, stop_thr, floor_ulps, tiles, n_rows, row_begin, row_step, bucket, hist, collapse);

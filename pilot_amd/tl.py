@@ -139,7 +139,15 @@ def wasserstein_d(Clu_rep, cost, regularized="unreg", reg=0.1, engine_options=No
     else:
         P = np.stack([np.asarray(Clu_rep[s], dtype=np.float64) for s in samples_id])
         cost = np.asarray(cost, dtype=np.float64)
-        if regularized == "unreg":
+        multi = {k: opts.pop(k) for k in ("devices", "n_devices", "gather") if k in opts}
+        if multi.get("devices") is not None or (multi.get("n_devices") or 1) > 1:
+            # the pair grid row-sharded over several GPUs of this node, one RCCL all-gather (pilot_amd.multi)
+            from . import multi as _multi
+            if regularized == "unreg":
+                EMD = _multi.emd_grid_multi(P, cost, **multi)
+            else:
+                EMD = _multi.sinkhorn_grid_multi(P, cost, reg, **multi, **opts)
+        elif regularized == "unreg":
             EMD = engine.emd_grid(P, cost)
         else:
             EMD = engine.sinkhorn_grid(P, cost, reg, **opts)
@@ -170,7 +178,8 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     ``data, annot, proportions, cost, EMD_df, EMD, real_labels``.
 
     ``engine_options`` (not in the reference): dict forwarded to the device engine, e.g.
-    ``{"precision": "fp64"}``.
+    ``{"precision": "fp64"}``; ``{"n_devices": G}`` (or ``{"devices": [0, 1, ...]}``) row-shards the pair grid over G GPUs
+    of this node with one RCCL all-gather -- same bits as the single-GPU matrix.
     """
     if data_type == "scRNA":
         data, annot = extract_data_anno_scRNA_from_h5ad(adata, emb_matrix=emb_matrix, clusters_col=clusters_col,

@@ -72,12 +72,18 @@ def test_c3_reg001_twenty_rows_f32(c3_small_reg_oracle):
     print("c3 reg 0.01 f32, %d pairs: capped oracle %d / gpu %d, absorb-on-last oracle %d / gpu %d, same update count %d"
           % (Eo.size, capped_o.sum(), capped_g.sum(), last_o.sum(), last_g.sum(), same.sum()))
     ok = ~last_o & ~last_g
-    assert np.abs(Eg - Eo)[ok & same].max() <= TOL32
-    # a pair that stops a check early (f32 threshold floor) or whose absorption falls one update apart moves by
-    # at most the residual marginal error of an unconverged plan
-    assert np.abs(Eg - Eo)[ok].max() <= 1e-4
+    d = np.abs(Eg - Eo)
+    early = ok & ~same
+    print("max|gpu - oracle|: same update count %.3e, stopped at an earlier check %.3e (of which oracle-capped %.3e)"
+          % (d[ok & same].max(), d[early].max() if early.any() else 0.0,
+             d[early & capped_o].max() if (early & capped_o).any() else 0.0))
+    assert d[ok & same].max() <= TOL32
+    # About half of the oracle's capped pairs sit between f32's resolution and POT's stopThr = 1e-9 for hundreds of
+    # updates: the f32 kernel (threshold floored at 8 ulp * ||b||_2) declares them converged at an earlier check.  The
+    # cost moves by at most the residual marginal error of that plan.
+    assert np.all(ig["iters"] <= io["iters"])
+    assert d[ok].max() <= 1e-4
     assert np.all(ig["iters"][~capped_g] % 20 == 1)
-    assert abs(int(capped_g.sum()) - int(capped_o.sum())) <= 0.02 * Eo.size
 
 
 def test_c4_eight_rows_both_precisions():

@@ -1,0 +1,125 @@
+"""Multi-GPU entry points of libpilot_ot.so on a 1-GPU box: RCCL with one rank (ncclCommInitAll / ncclCommInitRank,
+ncclAllGather, ncclAllReduce all execute), and 2 / 3 / 8 logical shards on device 0 with the peer-copy gather.  In every
+form the assembled matrix must equal the single-device matrix BIT FOR BIT (same kernel, same pair -> same arithmetic)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from pilot_amd import _lib, engine, multi, tl
+from pilot_amd.synthetic import CONFIGS, make_cells, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2():
+    P, M = make_problem(**CONFIGS["c2"])
+    E, info = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", return_info=True)
+    X = engine.emd_grid(P, M)
+    return P, M, E, info, X
+
+
+@pytest.mark.parametrize("devices,gather", [([0], "rccl"), ([0], "copy"), ([0, 0], "auto"), ([0, 0, 0], "copy"),
+                                            ([0] * 8, "copy")])
+def test_sharded_matrix_is_bit_identical_to_the_single_device_one(c2, devices, gather):
+    P, M, E, info, X = c2
+    Em, im = multi.sinkhorn_grid_multi(P, M, 0.1, devices=devices, gather=gather, precision="fp32", return_info=True)
+    np.testing.assert_array_equal(Em, E)
+    np.testing.assert_array_equal(im["iters"], info["iters"])
+    np.testing.assert_array_equal(im["flags"], info["flags"])
+    np.testing.assert_array_equal(im["err"], info["err"])
+    Xm, xi = multi.emd_grid_multi(P, M, devices=devices, gather=gather, return_info=True)
+    np.testing.assert_array_equal(Xm, X)                 # upper triangle solved per shard, mirrored after the gather
+
+
+def test_rccl_with_repeated_devices_is_refused():
+    P, M = make_problem(**CONFIGS["c1"])
+    with pytest.raises(ValueError, match="distinct"):
+        multi.sinkhorn_grid_multi(P, M, 0.1, devices=[0, 0], gather="rccl")
+    with pytest.raises(ValueError, match="not visible"):
+        multi.sinkhorn_grid_multi(P, M, 0.1, devices=[0, 63])
+
+
+def test_multi_plan_resident_and_timed():
+    P, M = make_problem(**CONFIGS["c3"])
+    ref = engine.sinkhorn_grid(P, M, 0.1, precision="fp32")
+    mp = multi.MultiPlan(P, M, devices=[0, 0, 0, 0])
+    for _ in range(2):
+        mp.sinkhorn(0.1)
+    E = mp.fetch()
+    np.testing.assert_array_equal(E, ref)
+    grid_ms, gather_ms = mp.times_ms()
+    assert grid_ms.shape == (4,) and (grid_ms > 0).all() and gather_ms > -0.5
+    mp.emd()
+    np.testing.assert_array_equal(mp.fetch(), engine.emd_grid(P, M))
+    mp.close()
+    # non-symmetric cost, N not a multiple of the shard count
+    rng = np.random.default_rng(0)
+    P, _ = make_problem(37, 20, 6, seed=3, cells_per_patient=300)
+    M = rng.random((20, 20)); M /= M.max()
+    for prec in ("fp32", "fp64"):
+        np.testing.assert_array_equal(multi.sinkhorn_grid_multi(P, M, 0.2, devices=[0, 0, 0], precision=prec),
+                                      engine.sinkhorn_grid(P, M, 0.2, precision=prec))
+    np.testing.assert_array_equal(multi.emd_grid_multi(P, M, devices=[0, 0, 0]), engine.emd_grid(P, M))
+
+
+def test_comm_one_rank_all_gather_and_all_reduce():
+    """The one-process-per-GPU form with a world of one: ncclCommInitRank, ncclAllGather, ncclAllReduce really run."""
+    L = _lib.load()
+    comm = multi.Comm(0, 1, key="pytest_%d" % os.getpid())
+    assert comm.all_reduce_max(3.25) == 3.25
+    N = 11
+    A = np.arange(N * N, dtype=np.float64).reshape(N, N)
+    bufs = []
+    for _ in range(3):
+        p = ctypes.c_void_p()
+        _lib.check(L.pilot_ot_dev_alloc(ctypes.byref(p), 8 * N * N))
+        bufs.append(p)
+    _lib.check(L.pilot_ot_memcpy_h2d(bufs[0], A.ctypes.data, A.nbytes))
+    comm.all_gather_rows(bufs[0], N, N, bufs[1], bufs[2])
+    comm.barrier()
+    out = np.zeros_like(A)
+    _lib.check(L.pilot_ot_memcpy_d2h(out.ctypes.data, bufs[2], A.nbytes))
+    np.testing.assert_array_equal(out, A)
+    with pytest.raises(ValueError, match="n_pad"):
+        comm.all_gather_rows(bufs[0], N - 1, N, bufs[1], bufs[2])
+    for p in bufs:
+        L.pilot_ot_dev_free(p)
+    comm.close()
+
+
+def test_tl_wasserstein_distance_over_shards(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    ad = make_cells(20, 10, 10, seed=0, cells_per_patient=200)
+    outs = {}
+    for name, opts in (("one", None), ("rccl1", {"n_devices": 1, "gather": "rccl"}), ("shards3", {"devices": [0, 0, 0]})):
+        for mode in ("unreg", "reg"):
+            ad.uns = {}
+            tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized=mode, reg=0.1, engine_options=opts)
+            outs[name, mode] = ad.uns["EMD"].copy()
+    for mode in ("unreg", "reg"):
+        np.testing.assert_array_equal(outs["rccl1", mode], outs["one", mode])
+        np.testing.assert_array_equal(outs["shards3", mode], outs["one", mode])
+
+
+def test_bench_multi_paths_on_one_gpu():
+    """bench.py --gpus 2 as ONE process over two logical shards, and under a 1-rank 'launcher' environment."""
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--logical-shards", "--steps", "3",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 1e7 and len(line["multi_gpu"]["grid_ms_per_shard"]) == 2
+    # one-process-per-GPU path with a world of one: RCCL communicator through the temp-file rendezvous, all-gather, max
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-comm", "--steps", "3",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e7 and "rank0_kernel_ms" in line["multi_gpu"]
