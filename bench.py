@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", help="synthetic config (c2 | c3 | c4)")
     ap.add_argument("--reg", type=float, default=0.1)
-    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64", "bf16x3"])
     ap.add_argument("--mode", default="sinkhorn", choices=["sinkhorn", "emd"],
                     help="emd: time the exact-OT pair grid (the reference's default mode) instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,14 +178,14 @@ def main():
         assert float(np.abs(E - E.T).max()) < 1e-5, "assembled matrix is not symmetric: bad row interleave?"
 
     # ---- roofline of the dominant kernel (this rank's launches inside the timed region) -------------------------------
-    peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F64_MFMA_TFLOPS
+    peak = PEAK_F64_MFMA_TFLOPS if prec == "fp64" else PEAK_F32_MFMA_TFLOPS
     flops_launch = algorithmic_flops(iters, K) * (1.0 if not single_process_multi else 1.0 / args.gpus)
     achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
-    s_bytes = 4 if prec == "fp32" else 8
+    s_bytes = 8 if prec == "fp64" else 4
     pairs_launch = iters.size if not single_process_multi else iters.size // args.gpus
     bytes_launch = float(pairs_launch) * (2 * K * s_bytes + s_bytes)     # 2*K*s + s per pair
     roofline = {
-        "bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % ("float" if prec == "fp32" else "double"),
+        "bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % {"fp32": "CfgF32x16", "fp64": "CfgF64x16", "bf16x3": "CfgS32x16"}[prec],
         "achieved": round(achieved_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
         "traffic": None,
         "kernel_ms": round(kern_ms, 4), "kernel_ms_source": "HIP events on the launch stream, mean over the timed steps",
@@ -218,7 +218,8 @@ def main():
         "metric": "W2 patient-pairs/sec (full NxN EMD matrix)", "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if prec == "fp32" else "f64", "data": "synthetic",
+        "dtype": {"fp32": "f32", "fp64": "f64", "bf16x3": "f32 (products as exact 3-way bf16 splits on the bf16 MFMA, f32 accumulate)"}[prec],
+        "data": "synthetic",
         "config": {"workload": "%s: %d patients x %d cell types x %d PCA dims, Sinkhorn reg=%g "
                                "(POT sinkhorn_stabilized semantics), all N^2 ordered pairs"
                                % (args.config, N, K, cfg["n_dims"], args.reg),

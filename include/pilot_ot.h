@@ -44,8 +44,11 @@ extern "C" {
 
 /* precision of the Sinkhorn pair-grid kernel */
 #define PILOT_OT_PREC_AUTO 0 /* f32 when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
-#define PILOT_OT_PREC_F32 1
+#define PILOT_OT_PREC_F32 1    /* f32 values, products on the f32-input MFMA (v_mfma_f32_16x16x4_f32): IEEE f32 FMA chains */
 #define PILOT_OT_PREC_F64 2
+#define PILOT_OT_PREC_BF16X3 3 /* f32 values, products on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits
+                                * (six piece products per term, f32 accumulation): f32-level rounding, not bit-identical
+                                * to PREC_F32, ~2x its speed */
 
 /* per-pair flag bits (flags output) */
 #define PILOT_OT_FLAG_CONVERGED 1      /* stopped on err <= stop_thr                              */

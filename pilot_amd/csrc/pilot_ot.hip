@@ -121,15 +121,11 @@ struct pilot_ot_plan {
     void *p_slot;      // N x KP proportions in accumulator-slot order (f32 or f64; sized for f64)
     int *track_list;   // N x N
     int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch,
-                       // [3] queue head of the solo waves, [4..7] split of the ordered list: n_top, (unused copy), queue head of
-                       // the cooperative tiles (= n_dup), n_dup = number of leading exact-duplicate pairs
-    hipStream_t side;  // the cooperative kernel runs beside the main one
-    hipEvent_t ev_fork, ev_join;
+                       // [3] queue head of the solo waves, [4..7] split of the ordered list: n_top, (unused copy), n_dup,
+                       // n_dup = number of leading exact-duplicate pairs
     int *order_list;   // N x N: longest-first work order of the fast launch
     unsigned char *order_bucket;  // N x N
     int *order_hist;   // 2 * ORDER_NB: histogram + scatter cursors
-    void *scratch;     // parked (u, v) records of the Sinkhorn stream kernel, grown on demand
-    size_t scratch_bytes;
     int *flags_ws;     // per-pair flags when the caller passes none
     size_t flags_ws_n;
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
@@ -242,8 +238,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
-    pl->side = nullptr; pl->ev_fork = nullptr; pl->ev_join = nullptr;
-    pl->scratch = nullptr; pl->scratch_bytes = 0; pl->flags_ws = nullptr; pl->flags_ws_n = 0;
+    pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) pl->ev[i][j] = nullptr;
     hipError_t e = hipGetDevice(&pl->device);
@@ -253,13 +248,17 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
             pl->n_cu = n_cu;
     }
     const int kp = ((K + 31) / 32) * 32;
-    if (e == hipSuccess) e = hipMalloc(&pl->img, sizeof(double) * (3 * (size_t)kp * kp + kp + 2 * 2 * (size_t)(kp / 4) * 64 * 2 + 2 * 64 * 64));   // + tail-row weights + plain tables
+    {
+        const int rt = (K + 15) / 16;
+        size_t img_bytes = pilot::img_elems(pilot::CFG_F64, rt) * sizeof(double);
+        const size_t b32 = pilot::img_elems(pilot::CFG_F32, rt) * sizeof(float), bs = pilot::img_elems(pilot::CFG_S32, rt) * sizeof(float);
+        if (b32 > img_bytes) img_bytes = b32;
+        if (bs > img_bytes) img_bytes = bs;
+        if (e == hipSuccess) e = hipMalloc(&pl->img, img_bytes);
+    }
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * ((size_t)N * kp + N));   // + one stop threshold per patient
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (8 + 2 * pilot::ORDER_NB) * sizeof(int));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
@@ -280,12 +279,8 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->p_slot) (void)hipFree(pl->p_slot);
     if (pl->track_list) (void)hipFree(pl->track_list);
     if (pl->track_count) (void)hipFree(pl->track_count);
-    if (pl->side) (void)hipStreamDestroy(pl->side);
-    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
-    if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     if (pl->order_list) (void)hipFree(pl->order_list);
     if (pl->order_bucket) (void)hipFree(pl->order_bucket);
-    if (pl->scratch) (void)hipFree(pl->scratch);
     if (pl->flags_ws) (void)hipFree(pl->flags_ws);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
     if (pl->f_slab) (void)hipFree(pl->f_slab);
@@ -304,7 +299,7 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     if (check_period < 1) return fail(PILOT_OT_EINVAL, "check_period=%d must be >= 1", check_period);
     if (!(stop_thr >= 0.0) || !(stop_thr < 1.0)) return fail(PILOT_OT_EINVAL, "stop_thr=%g must be in [0, 1)", stop_thr);
     if (!(tau > 1.0)) return fail(PILOT_OT_EINVAL, "tau=%g must be > 1", tau);
-    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_F64)
+    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_BF16X3)
         return fail(PILOT_OT_EINVAL, "unknown precision id %d", precision);
     if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
         return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
@@ -313,51 +308,68 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 }
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
-int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv) {
+int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split) {
     const int na = RT * 4 * RT * w;
-    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) +
-                     ((sym && na <= 64) ? na + 2 * tv * ((RT - 1) * 4 + 1) * w : 0);
+    const bool greg = !split && sym && na <= 64;
+    const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) + (split ? 3 * ((RT + 1) / 2) * 4 + 24 : 0) +
+                     (greg ? na + 2 * tv * ((RT - 1) * 4 + 1) * w : 0);
     return regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
 }
 // mirrors pilot::solo_in_stream: does the fast launch of this configuration carry the one-wave-per-pair path?
-bool stream_has_solo(int w, int RT, bool sym, int tv) {
-    const int mw = stream_min_waves(w, RT, sym, false, tv);
+bool stream_has_solo(int w, int RT, bool sym, int tv, bool split) {
+    const int mw = stream_min_waves(w, RT, sym, false, tv, split);
     const int budget = mw >= 4 ? 128 : (mw == 3 ? 168 : 256);
     return sym && RT <= 4 && (64 + 45) * w <= budget;
 }
-int stream_wgs_per_cu(int w, int RT, bool sym, bool track, int tv, size_t lds) {
-    int occ = stream_min_waves(w, RT, sym, track, tv);
-    const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
-    if (by_lds < occ) occ = by_lds;
-    return occ < 1 ? 1 : occ;
+
+// LDS of one stream-kernel workgroup: operand image(s) + first-product table + tail weights + one ring of finished pairs
+// per wave.  The ring gets as many slots (<= 16) as fit while `want` workgroups stay resident per CU; at least 4.
+struct StreamLds { size_t bytes; int ring, wgs_per_cu; };
+StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want) {
+    StreamLds r;
+    for (;;) {
+        const size_t budget = LDS_BYTES / (size_t)want;
+        long ring = budget > fixed ? (long)((budget - fixed) / ((size_t)pilot::WAVES_PER_WG * slot_bytes)) : 0;
+        if (ring >= 4 || want == 1) {
+            if (ring > pilot::RING_MAX) ring = pilot::RING_MAX;
+            if (ring < 1) ring = 0;
+            r.ring = (int)ring; r.wgs_per_cu = want;
+            r.bytes = fixed + (size_t)pilot::WAVES_PER_WG * slot_bytes * (size_t)ring;
+            return r;
+        }
+        --want;
+    }
 }
 
-// cfg: pilot::CFG_F32 / CFG_F64 (both 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
+// cfg: pilot::CFG_F32 / CFG_F64 / CFG_S32 (all 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
 int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
              double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
              int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s) {
-    const bool f32 = cfg == pilot::CFG_F32;
-    const size_t ts = f32 ? sizeof(float) : sizeof(double);
+    const bool f64 = cfg == pilot::CFG_F64, split = cfg == pilot::CFG_S32;
+    const size_t ts = f64 ? sizeof(double) : sizeof(float);
     const int w = (int)(ts / 4);
     constexpr int TILE = 16;
     const int N = pl->N, K = pl->K;
     const int RT = (K + TILE - 1) / TILE;
     const int KP = RT * TILE;
-    size_t lds = (size_t)(sym ? 1 : 2) * KP * KP * ts + (size_t)KP * ts;   // operand image(s) + first-product table
+    const char *dbg = getenv("PILOT_OT_DEBUG");
+    const int debug = dbg ? atoi(dbg) : 0;
+    const size_t form = pilot::form_elems_rt(cfg, RT);
+    size_t fixed = (size_t)(sym ? 1 : 2) * form * ts + (size_t)KP * ts;   // operand image(s) + first-product table
     // K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
     int tv = 0;
-    {
-        const char *dbg = getenv("PILOT_OT_DEBUG");
+    if (!split) {
         const int n_tail = K - (RT - 1) * TILE;
         // (RT = 8 variants spill: left on the MFMA path)
-        if (RT >= 2 && RT <= 7 && n_tail <= 4 && !(dbg && (atoi(dbg) & 256))) tv = n_tail <= 2 ? 1 : 2;
+        if (RT >= 2 && RT <= 7 && n_tail <= 4 && !(debug & 256)) tv = n_tail <= 2 ? 1 : 2;
         const size_t tail_lds = (size_t)(sym ? 1 : 2) * tv * ((RT - 1) * 4 + 1) * 64 * 2 * ts;
-        if (tv && lds + tail_lds > LDS_BYTES) tv = 0;       // the weights do not fit beside the images: MFMA path
-        if (tv) lds += tail_lds;
+        if (tv && fixed + tail_lds + 4 * pilot::WAVES_PER_WG * (2 * KP + 4) * ts > LDS_BYTES) tv = 0;   // no room: MFMA path
+        if (tv) fixed += tail_lds;
     }
-    if (lds > LDS_BYTES)
-        return fail(PILOT_OT_ENOTSUP, "K=%d with a non-symmetric cost needs %zu B of LDS (> %zu) in this precision", K, lds,
-                    LDS_BYTES);
+    const size_t slot_bytes = (size_t)(2 * KP + 4) * ts;
+    if (fixed + pilot::WAVES_PER_WG * slot_bytes > LDS_BYTES)
+        return fail(PILOT_OT_ENOTSUP, "K=%d with a %ssymmetric cost needs %zu B of LDS (> %zu) in this precision", K, sym ? "" : "non-",
+                    fixed + pilot::WAVES_PER_WG * slot_bytes, LDS_BYTES);
     pl->order_hist = pl->track_count + 8;     // one control block, one memset per call
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, (8 + 2 * pilot::ORDER_NB) * sizeof(int), s));
     void *img = pl->img;
@@ -365,15 +377,6 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if (n_rows == 0) return PILOT_OT_OK;
 
     const int n_pairs = n_rows * N;
-    // device workspace that scales with the number of pairs: grown on demand (first call at a new size
-    // allocates; later calls at the same or a smaller size do not, so they stay graph-capturable)
-    const size_t scr_bytes = (size_t)n_pairs * (2 * KP + 4) * ts;
-    if (scr_bytes > pl->scratch_bytes) {
-        if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
-        pl->scratch = nullptr; pl->scratch_bytes = 0;
-        HIP_TRY(hipMalloc(&pl->scratch, scr_bytes));
-        pl->scratch_bytes = scr_bytes;
-    }
     if (!d_flags) {
         if ((size_t)n_pairs > pl->flags_ws_n) {
             if (pl->flags_ws) HIP_TRY(hipFree(pl->flags_ws));
@@ -385,7 +388,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     }
 
     pilot::GridParams p;
-    p.P = Pt; p.img = img; p.scratch = pl->scratch; p.N = N; p.K = K;
+    p.P = Pt; p.img = img; p.N = N; p.K = K;
     p.n_pairs = n_pairs;
     p.list = nullptr; p.list_len = nullptr;
     p.solo_len = nullptr; p.solo_head = nullptr; p.solo_blocks = 0;
@@ -394,91 +397,61 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
     p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
-    {
-        const char *dbg = getenv("PILOT_OT_DEBUG");
-        p.debug = dbg ? atoi(dbg) : 0;
-    }
+    p.ring = 0;
+    p.debug = debug;
     const int tiles = (n_pairs + TILE - 1) / TILE;
-    // longest-first work order (see order_bucket_kernel); the head of the list (the slowest pairs) goes to the
-    // cooperative kernel, which runs beside the main kernel on the plan's side stream
-    bool coop = false;
     // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
-    const bool solo = stream_has_solo(w, RT, sym, tv) && !(p.debug & 512);
+    const bool solo = stream_has_solo(w, RT, sym, tv, split) && !(p.debug & 512);
     int solo_blocks = 0;
     {
-        // the cooperative kernel pays (two cross-stream event hops, shared CUs) only when the launch is bounded by the
-        // serial chains of its slowest pairs, i.e. when the grid refills the resident waves just a few times
-        const long in_flight = (long)pl->n_cu * 2 * pilot::WAVES_PER_WG * TILE;
-        coop = RT >= 2 && !(p.debug & (64 | 2)) && ((long)n_pairs <= 3 * in_flight || (p.debug & 128));
-        if (tv && !f32 && RT > 4) coop = false;     // f64 tail weights + panels do not fit the cooperative kernel's registers
-        if (solo && !(p.debug & 128)) coop = false; // with the duplicates on their own waves the tile version gains nothing (measured)
+        // longest-first work order (see order_bucket_kernel)
         int ob = (n_pairs + 1023) / 1024;
         if (ob > pl->n_cu) ob = pl->n_cu;
-        int *split = pl->track_count + 4;
-        const int mode = (coop ? 1 : 0) | (solo ? 2 : 0) | ((p.debug & 2) ? 4 : 0);   // bit 2: natural order (experiment)
-        HIP_TRY(f32 ? pilot::launch_prep_f32(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, stop_thr, floor_ulps, n_rows, row_begin, row_step,
-                                             pl->order_bucket, pl->order_hist, pl->order_list, split, pl->track_count + 1, mode, ob, s)
-                    : pilot::launch_prep_f64(d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, stop_thr, floor_ulps, n_rows, row_begin, row_step,
-                                             pl->order_bucket, pl->order_hist, pl->order_list, split, pl->track_count + 1, mode, ob, s));
+        int *split_ctl = pl->track_count + 4;
+        const int mode = (solo ? 2 : 0) | ((p.debug & 2) ? 4 : 0);   // bit 2: natural order (experiment)
+        HIP_TRY(pilot::launch_prep(cfg, d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, stop_thr, floor_ulps, n_rows, row_begin, row_step,
+                                   pl->order_bucket, pl->order_hist, pl->order_list, split_ctl, pl->track_count + 1, mode, ob, s));
         p.list = pl->order_list;
         if (solo) {
             solo_blocks = (n_rows + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;     // the diagonal; more duplicates queue up
             if (solo_blocks > pl->n_cu) solo_blocks = pl->n_cu;
-            p.solo_len = split + 3; p.solo_head = pl->track_count + 3; p.solo_blocks = solo_blocks;
-        }
-        if (coop) {
-            // (the main kernel's queue starts behind the cooperative head: order_scatter_kernel wrote n_top into it)
-            HIP_TRY(hipEventRecord(pl->ev_fork, s));
-            HIP_TRY(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
-            pilot::GridParams pc = p;
-            pc.list_len = split;           // n_items of the cooperative launch = n_top (device side)
-            pc.queue_head = split + 2;     // starts behind the duplicates
-            pc.solo_blocks = 0;
-            int cw = (n_pairs / 256 + 15) / 16 + 1;       // enough workgroups for the capped head, at most one per 2 CUs
-            if (cw > pl->n_cu / 2) cw = pl->n_cu / 2;
-            if (cw < 1) cw = 1;
-            HIP_TRY(tv ? pilot::launch_coop_tv(cfg, tv, RT, sym, cw, pl->side, pc)
-                       : (f32 ? pilot::launch_coop_f32(RT, sym, cw, pl->side, pc) : pilot::launch_coop_f64(RT, sym, cw, pl->side, pc)));
-            HIP_TRY(hipEventRecord(pl->ev_join, pl->side));
+            p.solo_len = split_ctl + 3; p.solo_head = pl->track_count + 3; p.solo_blocks = solo_blocks;
         }
     }
     hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
+    auto launch = [&](int tvv, bool track, int wgs, const StreamLds &L) -> hipError_t {
+        p.ring = L.ring;
+        if (tvv) return pilot::launch_stream_tv(cfg, tvv, RT, sym, track, dim3(wgs), L.bytes, s, p);
+        if (split) return pilot::launch_stream_s32(RT, sym, track, dim3(wgs), L.bytes, s, p);
+        return f64 ? pilot::launch_stream_f64(RT, sym, track, dim3(wgs), L.bytes, s, p)
+                   : pilot::launch_stream_f32(RT, sym, track, dim3(wgs), L.bytes, s, p);
+    };
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
     {
-        int wgs = pl->n_cu * stream_wgs_per_cu(w, RT, sym, false, tv, lds);
-        if ((p.debug >> 4) & 7) wgs = pl->n_cu * ((p.debug >> 4) & 7);   // experiment: resident workgroups per CU
+        int want = stream_min_waves(w, RT, sym, false, tv, split);
+        if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
+        const StreamLds L = stream_lds(fixed, slot_bytes, want);
+        int wgs = pl->n_cu * L.wgs_per_cu;
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs > need) wgs = need;
         wgs += solo_blocks;
-        HIP_TRY(tv ? pilot::launch_stream_tv(cfg, tv, RT, sym, false, dim3(wgs), lds, s, p)
-                   : (f32 ? pilot::launch_stream_f32(RT, sym, false, dim3(wgs), lds, s, p)
-                          : pilot::launch_stream_f64(RT, sym, false, dim3(wgs), lds, s, p)));
+        HIP_TRY(launch(tv, false, wgs, L));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
-    if (coop) HIP_TRY(hipStreamWaitEvent(s, pl->ev_join, 0));
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
     p.solo_blocks = 0;
     {
         // (the tracking kernel's result need not match the fast kernels' bits: a pair is always solved by one of them)
         const int tv_t = RT <= 4 ? tv : 0;          // larger tracking variants spill with the tail rows
-        int wgs_t = pl->n_cu * stream_wgs_per_cu(w, RT, sym, true, tv_t, lds);
+        const StreamLds L = stream_lds(fixed, slot_bytes, stream_min_waves(w, RT, sym, true, tv_t, split));
+        int wgs_t = pl->n_cu * L.wgs_per_cu;
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs_t > need) wgs_t = need;
-        HIP_TRY(tv_t ? pilot::launch_stream_tv(cfg, tv_t, RT, sym, true, dim3(wgs_t), lds, s, p)
-                   : (f32 ? pilot::launch_stream_f32(RT, sym, true, dim3(wgs_t), lds, s, p)
-                          : pilot::launch_stream_f64(RT, sym, true, dim3(wgs_t), lds, s, p)));
+        HIP_TRY(launch(tv_t, true, wgs_t, L));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
-    // third pass: cost <Gamma, M> of every pair from its parked scalings
-    p.list = nullptr; p.list_len = nullptr;
-    {
-        int wgs_v = pl->n_cu * 8;
-        const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
-        if (wgs_v > need) wgs_v = need;
-        HIP_TRY(f32 ? pilot::launch_value_f32(RT, dim3(wgs_v), s, p) : pilot::launch_value_f64(RT, dim3(wgs_v), s, p));
-    }
     return PILOT_OT_OK;
 }
 
@@ -497,7 +470,8 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return run_grid(precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : pilot::CFG_F64, pl, d_P, d_M, reg, num_iter_max,
+    const int cfg = precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : pilot::CFG_F64);
+    return run_grid(cfg, pl, d_P, d_M, reg, num_iter_max,
                     stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0, row_begin, n_rows, row_step,
                     d_emd, d_iters, d_err, d_flags, s);
 }

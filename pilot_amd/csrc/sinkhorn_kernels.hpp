@@ -18,10 +18,12 @@
 //     cross-lane xor-shuffles (the lane groups holding the same column);
 //   * pairs converge after very different numbers of updates (41 ... 1000), so waves are PERSISTENT and
 //     every column is a slot: the moment a pair stops (POT's rule: error checked when ii % period == 0,
-//     cap at num_iter_max) its scalings are parked in an HBM scratch record and the slot is refilled
+//     cap at num_iter_max) its scalings are parked in a wave-private LDS ring and the slot is refilled
 //     with the next pair of the wave's queue -- columns of an MFMA are independent, so a pair's
 //     arithmetic does not depend on its slot mates;
-//   * a second, short kernel turns the parked (u, v) into the cost <Gamma, M> = u^T (G o M) v.
+//   * whenever the ring holds a tile's worth of finished pairs the wave turns them into costs
+//     <Gamma, M> = u^T (G o M) v with ONE more panel product (1/16 of a product per pair) and writes the
+//     scalars: no scratch in HBM, no second kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -42,6 +44,7 @@ constexpr int FLAG_CONVERGED = 1, FLAG_NAN = 2, FLAG_ABSORB_LAST = 4, FLAG_ABSOR
 
 struct CfgF32x32 {   // v_mfma_f32_32x32x2_f32: hardware row of register r in group g = (r&3) + 8*(r>>2) + 4*g
     using T = float;
+    static constexpr bool SPLIT = false;
     static constexpr int TILE = 32, NREG = 16, NGRP = 2, VEC = 4;
     using acc_t = float __attribute__((ext_vector_type(16)));
     using vec4_t = float __attribute__((ext_vector_type(4)));
@@ -58,6 +61,7 @@ struct CfgF32x32 {   // v_mfma_f32_32x32x2_f32: hardware row of register r in gr
 
 struct CfgF32x16 {   // v_mfma_f32_16x16x4_f32: hardware row of register r in group g = 4*g + r
     using T = float;
+    static constexpr bool SPLIT = false;
     static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 4;
     using acc_t = float __attribute__((ext_vector_type(4)));
     using vec4_t = float __attribute__((ext_vector_type(4)));
@@ -70,8 +74,26 @@ struct CfgF32x16 {   // v_mfma_f32_16x16x4_f32: hardware row of register r in gr
     __device__ static inline float eps() { return 1.1920929e-07f; }
 };
 
+// f32 values with every product on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits (see
+// panel_product_split): same accumulator layout and slot dealing as CfgF32x16, so all element-wise code is shared.
+struct CfgS32x16 {
+    using T = float;
+    static constexpr bool SPLIT = true;
+    static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 4;
+    using acc_t = float __attribute__((ext_vector_type(4)));
+    using vec4_t = float __attribute__((ext_vector_type(4)));
+    __host__ __device__ static constexpr int lidx(int t, int r, int g) { return 4 * (4 * t + r) + g; }
+    __host__ __device__ static constexpr int lidx_of_row(int t, int p) { return lidx(t, p & 3, p >> 2); }
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) {     // (the f32 MFMA: only the selector of tail_rows, unused here)
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    __device__ static inline float eps() { return 1.1920929e-07f; }
+};
+
 struct CfgF64x16 {   // v_mfma_f64_16x16x4_f64 has its own C/D map: hardware row = (lane>>4) + 4*reg (k-step order)
     using T = double;
+    static constexpr bool SPLIT = false;
     static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 2;
     using acc_t = double __attribute__((ext_vector_type(4)));
     using vec4_t = double __attribute__((ext_vector_type(2)));
@@ -89,8 +111,11 @@ template <class C>
 __host__ __device__ constexpr int img_index(int RT, int tp, int r, int t, int lane) {
     return (((tp * C::NREG + r) * RT + t) * WAVE) + lane;
 }
-// per-item scratch record: u panel, v panel (KP values each, [tile][group][reg] order), then 4 extras
-template <class C> __host__ __device__ constexpr int scratch_stride(int RT) { return 2 * RT * C::TILE + 4; }
+// finished pairs wait in a wave-private LDS ring for their cost product: per slot the u panel and the v panel (KP values
+// each, [tile][group][reg] order) + 4 elements of padding (a lane's 16-byte reads of consecutive slots then fall on
+// different banks); ring_meta: per slot the output index, the flags and POT's plan scale (1, or 1/K^2)
+template <class C> __host__ __device__ constexpr int ring_slot_stride(int RT) { return 2 * RT * C::TILE + 4; }
+constexpr int RING_MAX = 16;
 
 // Cross-lane exchanges between the lane groups of a column (lanes l, l^16, l^32, l^48) with gfx950's
 // v_permlane32_swap / v_permlane16_swap: VALU-rate, no LDS crossbar round trip (ds_bpermute costs ~100+ cycles of
@@ -317,11 +342,99 @@ template <class C> __device__ inline void load_regs(const typename C::T *src, ty
     }
 }
 
+// ---- bf16-split products (configuration CfgS32x16) ---------------------------------------------------------------------------
+// gfx950's f32-input MFMA runs at the f32 VECTOR rate and shares the SIMD's f32 lanes with every other VALU instruction
+// (measured: SQ_VALU_MFMA_COEXEC_CYCLES = 0), while v_mfma_f32_16x16x32_bf16 does 8x the contraction depth in half the
+// cycles on the matrix pipe proper and lets VALU work issue beside it.  A product of f32 operands is therefore taken
+// apart into bf16 pieces: x = x1 + x2 + x3 exactly (8 + 8 + 8 significant bits, round-to-nearest residuals), and
+//     sum_k a_k b_k  ~=  sum_k (a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1)_k
+// with every piece product exact and the sums accumulated in f32 by the MFMA (terms of order 2^-24 |a b| dropped: the
+// rounding level of an f32 FMA chain).  The stationary operand G is split once per call by the prep kernel; the scaling
+// panel (the B operand) is split in registers before each product, 5.5 VALU instructions per element.
+// Layout: the 16x16 f32 result tile of 16x16x32 has the same lane/register map as 16x16x4's, and a lane's 8 bf16 B values
+// of k-block kb are exactly its 2 x 4 accumulator registers of row-tiles 2 kb and 2 kb + 1 -- so the result still feeds the
+// next product with no lane movement: k-slot (group g, element e) of block kb <-> cell type lidx(2 kb + e / 4, e % 4, g).
+using bf16x8_t = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x2_t = __bf16 __attribute__((ext_vector_type(2)));
+using u32x4_t = unsigned int __attribute__((ext_vector_type(4)));
+using f32x2_t = float __attribute__((ext_vector_type(2)));
+
+__device__ inline unsigned int cvt_pk_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32, round to nearest even
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+// (x0, x1) -> three packed bf16 pairs with hi + mid + lo == x exactly (each residual is exactly representable)
+struct Split3 { unsigned int hi, mid, lo; };
+__device__ inline Split3 split3(float x0, float x1) {
+    Split3 o;
+    o.hi = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(o.hi << 16), r1 = x1 - __uint_as_float(o.hi & 0xffff0000u);
+    o.mid = cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(o.mid << 16);
+    r1 -= __uint_as_float(o.mid & 0xffff0000u);
+    o.lo = cvt_pk_bf16(r0, r1);
+    return o;
+}
+__host__ __device__ constexpr int split_kblocks(int RT) { return (RT + 1) / 2; }
+
+// the scaling panel as bf16 B operands: p[part][k-block] = the lane's 8 k-slots (accumulator registers of row-tiles 2 kb, 2 kb + 1)
+template <int RT> struct SplitPanel { u32x4_t p[3][split_kblocks(RT)]; };
+template <class C, int RT>
+__device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel<RT> &B) {
+    constexpr int KB = split_kblocks(RT);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {       // element pairs (0,1), (2,3) of row-tile 2 kb, then of row-tile 2 kb + 1
+            const int t = 2 * kb + h / 2;
+            Split3 sp = {0u, 0u, 0u};
+            if (t < RT) sp = split3(IN[t < RT ? t : 0][2 * (h & 1)], IN[t < RT ? t : 0][2 * (h & 1) + 1]);
+            B.p[0][kb][h] = sp.hi; B.p[1][kb][h] = sp.mid; B.p[2][kb][h] = sp.lo;
+        }
+}
+// one 16-row output tile of X * panel; `form` = the [part][k-block][out tile][lane] x 16-byte image of X (LDS or global)
+template <class C, int RT>
+__device__ inline typename C::acc_t split_tile_product(const typename C::T *form, int lane, int t, const SplitPanel<RT> &B,
+                                                       typename C::acc_t acc) {
+    constexpr int KB = split_kblocks(RT);
+    const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form);
+    auto mm = [](u32x4_t a, u32x4_t b, typename C::acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    };
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const u32x4_t a1 = img[((0 * KB + kb) * RT + t) * WAVE + lane];
+        const u32x4_t a2 = img[((1 * KB + kb) * RT + t) * WAVE + lane];
+        const u32x4_t a3 = img[((2 * KB + kb) * RT + t) * WAVE + lane];
+        // smallest terms first
+        acc = mm(a3, B.p[0][kb], acc);
+        acc = mm(a1, B.p[2][kb], acc);
+        acc = mm(a2, B.p[1][kb], acc);
+        acc = mm(a2, B.p[0][kb], acc);
+        acc = mm(a1, B.p[1][kb], acc);
+        acc = mm(a1, B.p[0][kb], acc);
+    }
+    return acc;
+}
+// OUT = X_form * IN for the whole panel
+template <class C, int RT>
+__device__ inline void panel_product_split(const typename C::T *form, int lane, const typename C::acc_t (&IN)[RT],
+                                           typename C::acc_t (&OUT)[RT], const typename C::acc_t &last_init) {
+    SplitPanel<RT> B;
+    split_panel<C, RT>(IN, B);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        typename C::acc_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (t == RT - 1) ? last_init[r] : 0.f;
+        OUT[t] = split_tile_product<C, RT>(form, lane, t, B, acc);
+    }
+}
+
 struct GridParams {
     const void *P;        // N x KP, element type T, every row in accumulator-slot order [tile][group][reg], 0 in padding;
                           // then N stop thresholds (one per column patient)
-    const void *img;      // 3 images of KP*KP elements of T (G^T-form, G-form, (G o M)-form) + KP first-product values
-    void *scratch;        // n_items records of scratch_stride<T>(RT) elements of T
+    const void *img;      // operand block of the call: see img_layout below
     int N, K;
     int n_pairs;          // number of work items
     const int *list;      // nullable: explicit work-item list (indices into the output arrays)
@@ -339,8 +452,22 @@ struct GridParams {
     const int *solo_len;  // fast launch: device-side number of leading list items (exact duplicates a == b) for solo_pairs
     int *solo_head;       //   their queue head
     int solo_blocks;      //   leading workgroups of the launch that run solo_pairs (they start first); 0: none
+    int ring;             // slots of the per-wave LDS ring of finished pairs (1 .. RING_MAX; sized by the host to fit LDS)
     int debug;            // experiment switches (PILOT_OT_DEBUG): bit0 no priority, bit1 no longest-first order
 };
+
+// Operand block of one call in global memory, in elements of T (4-byte units for the bf16-split configuration):
+//   [form 0: G^T][form 1: G][form 2: G o M]   form_elems<C>(RT) each -- the stationary MFMA A operands in lane order
+//   [first-product table: KP]                  (G^T u0)[slot], u0 = 1/K
+//   [tail-row weights]                         2 forms x 2 chains x tail_steps x WAVE pairs (VALU tail rows)
+//   [plain tables: 3 x 64 x WAVE]              G[lane][k], G[k][lane], (G o M)[lane][k] for solo_pairs
+template <class C> __host__ __device__ constexpr int form_elems(int RT) {
+    return C::SPLIT ? 3 * ((RT + 1) / 2) * RT * WAVE * 4 : RT * C::TILE * RT * C::TILE;
+}
+template <class C> __host__ __device__ constexpr int acc0_offset(int RT) { return 3 * form_elems<C>(RT); }
+template <class C> __host__ __device__ constexpr int tail_offset(int RT) { return acc0_offset<C>(RT) + RT * C::TILE; }
+template <class C> __host__ __device__ constexpr int plain_offset(int RT) { return tail_offset<C>(RT) + 2 * 2 * ((RT - 1) * 4 + 1) * WAVE * 2; }
+template <class C> __host__ __device__ constexpr int img_total(int RT) { return plain_offset<C>(RT) + 3 * 64 * WAVE; }
 
 // ---- one wave per pair: the exact duplicates ---------------------------------------------------------------------------
 // Pairs with a == b (the diagonal of the grid, duplicate patients) need the most updates by far (161 .. 381 at c3 against
@@ -366,8 +493,6 @@ template <typename T> __device__ inline T wave_sum(T x) {
     for (int off = 1; off < 16; off <<= 1) x += __shfl_xor(x, off);
     return sum_xor32(sum_xor16(x));
 }
-// elements of the plain tables behind the tail-row weights: [table 0: G[lane][k], 1: G[k][lane]][k < 64][lane < 64]
-__host__ __device__ constexpr int plain_offset(int KP, int RT) { return 3 * KP * KP + KP + 2 * 2 * ((RT - 1) * 4 + 1) * WAVE * 2; }
 
 template <class C, bool SYM>
 __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned char *solo_smem) {
@@ -375,10 +500,8 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
     const int lane = threadIdx.x % WAVE;
     const int K = p.K, N = p.N;
     const T *img = static_cast<const T *>(p.img);
-    const T *plain = img + plain_offset(KP, RT);
+    const T *plain = img + plain_offset<C>(RT);
     const T *Pt = static_cast<const T *>(p.P);
-    T *scratch = static_cast<T *>(p.scratch);
-    const int SCR = 2 * KP + 4;
     T g1[64], g2[SYM ? 1 : 64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
@@ -408,7 +531,7 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
     const bool live = lane < K;
     const int pos = ((lane / 16) * 4 + (lane % 4)) * 4 + (lane % 16) / 4;     // accumulator slot of cell type `lane`
     const bool inrec = lane < KP;
-    const T acc0 = inrec ? img[3 * KP * KP + pos] : T(1);
+    const T acc0 = inrec ? img[acc0_offset<C>(RT) + pos] : T(1);
     const T tau = T(p.tau);
     const int n_items = *p.solo_len;
     for (;;) {
@@ -446,10 +569,23 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
                     else if (e != e) { fin = true; flags |= FLAG_NAN; }
                 }
                 if (fin) {
-                    T *rec = scratch + (size_t)q * SCR;
-                    if (inrec) { rec[pos] = u; rec[KP + pos] = v; }
+                    // cost <Gamma, M> = u^T (G o M) v: the rows of G o M take the place of G's for one product
+                    xline[lane] = v;
+                    T val = T(0);
+                    {
+                        const T *gm = plain + 2 * 64 * WAVE + lane;
+                        for (int k0 = 0; k0 < K; k0 += 8) {       // 8 coalesced row loads in flight
+                            T gk[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) gk[e] = gm[(k0 + e) * WAVE];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) val = fma(gk[e], xline[k0 + e], val);
+                        }
+                    }
+                    val = wave_sum(live ? u * val : T(0));
                     if (lane == 0) {
-                        rec[2 * KP] = T(1);
+                        if (val != val) flags |= FLAG_NAN;
+                        p.emd[q] = double(val);
                         if (p.iters) p.iters[q] = ii;
                         if (p.err) p.err[q] = double(errv);
                         p.flags[q] = flags;
@@ -461,14 +597,92 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
     }
 }
 
+// Finished pairs in a wave's ring -> costs <Gamma, M> = u^T (G o M) v: ONE panel product for up to TILE pairs, one output
+// row-tile at a time.  Deliberately NOT inlined: it runs once per 16 finished pairs, and as a call its register needs
+// (the v panel, an accumulator tile, operands in flight) are paid at the call site instead of raising the pressure of
+// the update loop around it.
+template <class C, int RT>
+__device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, const typename C::T *img_gm, int K, int cnt,
+                                                     double *emd, int *flags_out) {
+    using M = C;
+    using T = typename C::T;
+    using acc_t = typename C::acc_t;
+    constexpr int TILE = C::TILE, NREG = C::NREG, NGRP = C::NGRP;
+    constexpr int KP = RT * TILE;
+    constexpr int RSTRIDE = ring_slot_stride<C>(RT);
+    const int lane = threadIdx.x % WAVE;
+    const int col = lane % TILE, grp = lane / TILE;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int s = col < cnt ? col : cnt - 1;        // columns beyond the fill level redo the last slot, unused
+            const T *rec = ring + s * RSTRIDE;
+            const T scale = rec[2 * KP];
+            // one output row-tile at a time: only the v panel (or its bf16 pieces) is live beside the iteration state
+            T val = T(0);
+            if constexpr (C::SPLIT) {
+                SplitPanel<RT> Bv;
+                {
+                    acc_t Vr[RT];
+    #pragma unroll
+                    for (int t = 0; t < RT; ++t) load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, Vr[t]);
+                    split_panel<C, RT>(Vr, Bv);
+                }
+    #pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    acc_t w;
+    #pragma unroll
+                    for (int r = 0; r < NREG; ++r) w[r] = T(0);
+                    w = split_tile_product<C, RT>(img_gm, lane, t, Bv, w);
+                    acc_t ur;
+                    load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
+    #pragma unroll
+                    for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
+                }
+            } else {
+                acc_t Vr[RT];
+    #pragma unroll
+                for (int t = 0; t < RT; ++t) load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, Vr[t]);
+                const int n_last = (K - M::lidx(RT - 1, 0, 0) + NGRP - 1) / NGRP;     // live k-steps of the last row-tile
+    #pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    acc_t w;
+    #pragma unroll
+                    for (int r = 0; r < NREG; ++r) w[r] = T(0);
+    #pragma unroll
+                    for (int tp = 0; tp < RT; ++tp)
+    #pragma unroll
+                        for (int r = 0; r < NREG; ++r)
+                            if (tp < RT - 1 || r < n_last)        // wave-uniform
+                                w = M::mfma(img_gm[((tp * NREG + r) * RT + t) * WAVE + lane], Vr[tp][r], w);
+                    acc_t ur;
+                    load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
+    #pragma unroll
+                    for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
+                }
+            }
+            val = group_sum<C>(val) * scale;
+            if (grp == 0 && col < cnt) {
+                const int *meta = reinterpret_cast<const int *>(rec + 2 * KP + 1);
+                const int qq = meta[0];
+                int fl = meta[1];
+                if (val != val) fl |= FLAG_NAN;
+                emd[qq] = double(val);
+                flags_out[qq] = fl;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slots are reused only after every lane has read them
+            __builtin_amdgcn_wave_barrier();
+}
+
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
 template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
-    return SYM && RT * C::NREG * RT * int(sizeof(typename C::T) / 4) <= 64;
+    return !C::SPLIT && SYM && RT * C::NREG * RT * int(sizeof(typename C::T) / 4) <= 64;
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel_regs() {
     return (TRACK ? 7 : 5) * RT * C::NREG * int(sizeof(typename C::T) / 4) + C::NREG * int(sizeof(typename C::T) / 4) + 56 +
            (TV > 0 ? 24 * int(sizeof(typename C::T) / 4) : 0) +     // tail accumulators, broadcast pairs, weights in flight
+           (C::SPLIT ? 3 * ((RT + 1) / 2) * 4 + 24 : 0) +           // split panel parts + operand parts in flight
            (operands_in_regs<C, RT, SYM>() ? (RT * C::NREG * RT + 2 * TV * tail_steps<RT>()) * int(sizeof(typename C::T) / 4) : 0);
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
@@ -495,7 +709,8 @@ sinkhorn_stream_kernel(GridParams p) {
     using acc_t = typename M::acc_t;
     constexpr int TILE = M::TILE, NREG = M::NREG, NGRP = M::NGRP;
     constexpr int KP = RT * TILE;
-    constexpr int SCR = scratch_stride<C>(RT);
+    constexpr int FORM = form_elems<C>(RT);
+    constexpr int RSTRIDE = ring_slot_stride<C>(RT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *lds = reinterpret_cast<T *>(smem_raw);
 
@@ -510,14 +725,15 @@ sinkhorn_stream_kernel(GridParams p) {
     if (block * WAVES_PER_WG * TILE >= n_items) return;  // more workgroups than work (tracking launch)
 
     // stage the stationary operand: image 0 (and image 1 unless G is symmetric) + first-product table
+    constexpr int n_img = (SYM ? 1 : 2) * FORM;
+    constexpr int n_tail = TV > 0 ? (SYM ? 1 : 2) * TV * tail_steps<RT>() * WAVE * 2 : 0;
     {
         const T *g = static_cast<const T *>(p.img);
-        constexpr int n_img = (SYM ? 1 : 2) * KP * KP;
         for (int i = threadIdx.x; i < n_img; i += WAVE * WAVES_PER_WG) lds[i] = g[i];
-        for (int i = threadIdx.x; i < KP; i += WAVE * WAVES_PER_WG) lds[n_img + i] = g[3 * KP * KP + i];
+        for (int i = threadIdx.x; i < KP; i += WAVE * WAVES_PER_WG) lds[n_img + i] = g[acc0_offset<C>(RT) + i];
         if constexpr (TV > 0) {   // tail-row weights (chains 0 .. TV-1 of form 0, and of form 1 unless symmetric)
             constexpr int n_form = TV * tail_steps<RT>() * WAVE * 2;           // floats per form actually used
-            const T *tg = g + 3 * KP * KP + KP;
+            const T *tg = g + tail_offset<C>(RT);
             for (int i = threadIdx.x; i < n_form; i += WAVE * WAVES_PER_WG) {
                 lds[n_img + KP + i] = tg[i];
                 if constexpr (!SYM) lds[n_img + KP + n_form + i] = tg[2 * tail_form_stride<RT>() + i];
@@ -526,7 +742,10 @@ sinkhorn_stream_kernel(GridParams p) {
     }
     __syncthreads();
     const T *img_gt = lds;                                         // out = G^T in
-    const T *img_g = SYM ? lds : lds + KP * KP;                    // out = G in
+    const T *img_g = SYM ? lds : lds + FORM;                       // out = G in
+    const T *img_gm = static_cast<const T *>(p.img) + 2 * FORM;    // out = (G o M) in: read from L2 once per 16 finished pairs
+    // wave-private ring of finished pairs (u, v panels + scale / output index / flags in the slot's padding)
+    T *ring = lds + n_img + KP + n_tail + (threadIdx.x / WAVE) * p.ring * RSTRIDE;
     // small symmetric problems keep the whole operand image in registers (no LDS access in the loop)
     constexpr int NA = RT * NREG * RT;
     constexpr bool GREG = operands_in_regs<C, RT, SYM>();
@@ -536,7 +755,7 @@ sinkhorn_stream_kernel(GridParams p) {
         for (int i = 0; i < NA; ++i) areg.a[i] = lds[i * WAVE + lane];
     }
     const AFromImage<C> a_gt{img_gt, lane}, a_g{img_g, lane};
-    const T *acc0 = lds + (SYM ? 1 : 2) * KP * KP;                 // G^T u0, u0 = 1/K (a new pair's first product)
+    const T *acc0 = lds + n_img;                                   // G^T u0, u0 = 1/K (a new pair's first product)
     const int col = lane % TILE, grp = lane / TILE;
     // tail-row weights: LDS images, or registers next to the register-resident operand image
     constexpr int NTF = (TV > 0 ? TV : 1) * tail_steps<RT>() * WAVE;            // pairs per form in LDS
@@ -551,7 +770,9 @@ sinkhorn_stream_kernel(GridParams p) {
     auto dead = [](int t, int r) { return TV > 0 && t == RT - 1 && r > 0; };
     auto product = [&](const AFromImage<C> &a_img, const TailFromImage<T, RT> &w_img, const acc_t (&IN)[RT], acc_t (&OUT)[RT],
                        const acc_t &init) {
-        if constexpr (TV > 0) {
+        if constexpr (C::SPLIT) {
+            panel_product_split<C, RT>(a_img.img, lane, IN, OUT, init);
+        } else if constexpr (TV > 0) {
             if constexpr (GREG) panel_product_tail<C, RT, TV>(areg, wreg, IN, OUT, init, grp);
             else panel_product_tail<C, RT, TV>(a_img, w_img, IN, OUT, init, grp);
         } else {
@@ -562,7 +783,6 @@ sinkhorn_stream_kernel(GridParams p) {
 
     const int K = p.K, N = p.N;
     const T *Pt = static_cast<const T *>(p.P);
-    T *scratch = static_cast<T *>(p.scratch);
     const T uinit = T(1) / T(K);
     const T tau = T(p.tau);
     const T kk = T(K) * T(K);
@@ -587,6 +807,9 @@ sinkhorn_stream_kernel(GridParams p) {
             ACC[t][r] = T(1);
             if constexpr (TRACK) { RU[t][r] = RV[t][r] = T(0); }
         }
+
+    int ring_cnt = 0;
+    auto flush = [&](int cnt) { ring_flush<C, RT>(ring, img_gm, p.K, cnt, p.emd, p.flags); };
 
     // work queue: waves draw batches of TILE items from one device-wide counter, so a wave that got
     // long-running pairs simply draws fewer batches
@@ -685,7 +908,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 flags |= FLAG_ABSORBED;
             }
         } else {
-            // hand the pair to the tracking kernel (it restarts the pair from scratch)
+            // hand the pair to the tracking kernel (it restarts the pair from its first update)
             if (omask) {
                 int base = 0;
                 if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(omask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -710,7 +933,7 @@ sinkhorn_stream_kernel(GridParams p) {
             T e2 = T(0);
             T sc = T(1);
             if constexpr (TRACK) sc = (abs_at == ii - 1) ? T(1) / kk : T(1);  // u, v were just reset to 1/K each
-            // per-tile partial sums added in tile order: the association the cooperative kernel reproduces
+            // per-tile partial sums added in tile order
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 T et = T(0);
@@ -732,286 +955,52 @@ sinkhorn_stream_kernel(GridParams p) {
                 if (e <= thr) { fin = true; flags |= FLAG_CONVERGED; }
                 else if (e != e) { fin = true; flags |= FLAG_NAN; }   // POT: "Numerical errors at iteration"
             }
-            // ---- retire finished pairs: outputs + parked scalings; the slot asks for the next pair ----
-            if (fin) {
+            // ---- retire finished pairs: (u, v) go to the wave's ring, the slot asks for the next pair ----
+            unsigned long long fmask = __ballot(fin) & colmask;
+            if (fmask) {
                 T scale = T(1);
                 if constexpr (TRACK) {
-                    if (abs_at >= 0 && abs_at == ii - 1) { scale = T(1) / kk; flags |= FLAG_ABSORB_LAST; }
+                    if (fin && abs_at >= 0 && abs_at == ii - 1) { scale = T(1) / kk; flags |= FLAG_ABSORB_LAST; }
                 }
                 if constexpr (sizeof(T) == 8) flags |= FLAG_F64;
-                T *rec = scratch + (size_t)q * SCR;
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    store_regs<C>(rec + (t * NGRP + grp) * NREG, U[t]);
-                    store_regs<C>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
-                }
-                if (grp == 0) {
-                    rec[2 * KP] = scale;
+                if (fin && grp == 0) {
                     if (p.iters) p.iters[q] = ii;
                     if (p.err) p.err[q] = double(errv);
-                    p.flags[q] = flags;
                 }
-                active = false;
-                want = true;
-            }
-        }
-    }
-}
-
-// ---- cooperative kernel for the slowest pairs ----------------------------------------------------------------------
-// A pair's updates are a serial chain, and the pairs at the head of the longest-first list (near-duplicate histograms;
-// the diagonal a == b needs 160-380 updates at reg = 0.1 against a mean of 39) set the minimum duration of a launch --
-// 0.69 ms of the 1.7 ms at 600 patients, and all of it once the grid is sharded over 8 GPUs.  Here a tile of 16 such
-// pairs is iterated by a WORKGROUP of RT waves instead of one wave: wave w owns output row-tile w of both products
-// (ceil(K/4) MFMAs instead of RT*ceil(K/4)) and the element-wise work on those 16 rows; the K x 16 scaling panel is
-// exchanged through LDS twice per update.  Every accumulation chain, every element-wise operation and the order of the
-// partial sums are those of sinkhorn_stream_kernel, so a pair's result is bit-identical whichever kernel solves it.
-template <class C, int RT, bool SYM, int TV = 0>
-__global__ void __launch_bounds__(WAVE * RT) sinkhorn_coop_kernel(GridParams p) {
-    using T = typename C::T;
-    using acc_t = typename C::acc_t;
-    constexpr int TILE = C::TILE, NREG = C::NREG, NGRP = C::NGRP;
-    constexpr int KP = RT * TILE;
-    constexpr int SCR = scratch_stride<C>(RT);
-    constexpr int NSTEP = RT * NREG;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *PB = reinterpret_cast<T *>(smem_raw);                 // [2][RT][WAVE][NREG] panel exchange (0: v, 1: u)
-    T *XB = PB + 2 * RT * WAVE * NREG;                         // [2][RT][WAVE] partials (0: squared error, 1: max)
-    int *QB = reinterpret_cast<int *>(XB + 2 * RT * WAVE);     // [1] batch base broadcast
-
-    const int n_items = *p.list_len;
-    if (blockIdx.x * TILE >= n_items) return;
-    const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    const int col = lane % TILE, grp = lane / TILE;
-    const int K = p.K, N = p.N;
-    const T *Pt = static_cast<const T *>(p.P);
-    const T *img = static_cast<const T *>(p.img);
-    const T *acc0g = img + 3 * KP * KP;
-    T *scratch = static_cast<T *>(p.scratch);
-    const T uinit = T(1) / T(K);
-    const T tau = T(p.tau);
-    const unsigned long long colmask = (1ull << TILE) - 1ull;
-
-    // stationary operands of this wave's output tile (registers): k-step (tp, r) -> image index ((tp*NREG + r)*RT + w)
-    T GT[NSTEP], GG[SYM ? 1 : NSTEP];
+                while (fmask) {     // wave-uniform: usually one pass; a second one when the ring fills up in between
+                    const int space = p.ring - ring_cnt;
+                    const int rank = (int)__popcll(fmask & ((1ull << col) - 1ull));
+                    const bool put = fin && ((fmask >> col) & 1ull) && rank < space;
+                    if (put) {
+                        T *rec = ring + (ring_cnt + rank) * RSTRIDE;
 #pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-        GT[st] = img[(st * RT + w) * WAVE + lane];
-        if constexpr (!SYM) GG[st] = img[KP * KP + (st * RT + w) * WAVE + lane];
-    }
-    // TV > 0: the wave that owns the last row-tile computes it on the VALU (tail_rows, as the stream kernel does)
-    TailFromRegs<T, RT, TV> WT, WG;
-    if constexpr (TV > 0) {
-        const pair_of<T> *tg = reinterpret_cast<const pair_of<T> *>(img + 3 * KP * KP + KP);
-#pragma unroll
-        for (int i = 0; i < TV * tail_steps<RT>(); ++i) {
-            WT.a[i] = tg[i * WAVE + lane];
-            WG.a[i] = SYM ? WT.a[i] : tg[tail_form_stride<RT>() + i * WAVE + lane];
-        }
-    }
-    acc_t PADC, UINIT;
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-        const bool pad = C::lidx(w, r, grp) >= K;
-        PADC[r] = pad ? T(1) : T(0);
-        UINIT[r] = pad ? T(0) : uinit;
-    }
-
-    acc_t A, B, U, V, VN, ACC;
-    bool active = false, want = true;
-    int q = 0, ii = 0, chk = 1, flags = 0;
-    T errv = T(1), thr = T(0);
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) { A[r] = B[r] = U[r] = V[r] = VN[r] = T(0); ACC[r] = T(1); }
-    int res_next = 0, res_end = 0;
-    bool exhausted = false;
-
-    // own output tile of  X_img * IN  (IN = the full panel, one acc_t per row-tile); same chain order as panel_product
-    auto product = [&](const T (&G)[NSTEP], const TailFromRegs<T, RT, TV> &W, const acc_t (&IN)[RT]) {
-        acc_t out = PADC;
-        if constexpr (TV > 0) {
-            if (w == RT - 1) {       // wave-uniform
-                return tail_rows<C, RT, TV>(W, IN, PADC, grp);
-            }
-        }
-#pragma unroll
-        for (int tp = 0; tp < RT; ++tp)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r)
-                if (tp < RT - 1 || C::lidx(tp, r, 0) < K)          // wave-uniform: skip k-steps that only hold padding
-                    out = C::mfma(G[tp * NREG + r], IN[tp][r], out);
-        return out;
-    };
-
-    for (;;) {
-        // ---- (re)fill: identical decisions in every wave (column state is replicated) -----------------------------
-        const unsigned long long wmask = __ballot(want) & colmask;
-        if (wmask) {
-            if (res_next >= res_end && !exhausted) {
-                if (w == 0 && lane == 0) QB[0] = __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                const int base = __builtin_amdgcn_readfirstlane(QB[0]);
-                __syncthreads();
-                exhausted = base >= n_items;
-                res_next = exhausted ? n_items : base;
-                res_end = (base + TILE < n_items) ? base + TILE : n_items;
-                if (exhausted) res_end = n_items;
-            }
-            const int avail = res_end - res_next;
-            const int n_want = (int)__popcll(wmask);
-            const int rank = (int)__popcll(wmask & ((1ull << col) - 1ull));
-            const int item = res_next + rank;
-            const bool take = want && rank < avail;
-            res_next = __builtin_amdgcn_readfirstlane(res_next + (n_want < avail ? n_want : avail));
-            if (want && !take && exhausted) {
-                want = false;
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) { A[r] = B[r] = U[r] = V[r] = T(0); ACC[r] = T(1); }
-            }
-            if (take) {
-                want = false;
-                active = true;
-                q = p.list[item];
-                const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
-                load_regs<C>(Pt + (size_t)i * KP + (w * NGRP + grp) * NREG, A);
-                load_regs<C>(Pt + (size_t)j * KP + (w * NGRP + grp) * NREG, B);
-                acc_t a0;
-                load_regs<C>(acc0g + (w * NGRP + grp) * NREG, a0);
-                thr = Pt[(size_t)N * KP + j];
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) { U[r] = UINIT[r]; V[r] = B[r] * C::rcp(a0[r]); }   // first v-update
-                ii = 0; chk = 1; flags = 0; errv = T(1);
-            }
-        }
-        if (__ballot(active || want) == 0ull) break;
-
-        // ---- exchange v; ACC = (G v)[own tile]; u = a / ACC ----------------------------------------------------
-        acc_t IN[RT];
-        store_regs<C>(PB + ((0 * RT + w) * WAVE + lane) * NREG, V);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < RT; ++t) load_regs<C>(PB + ((0 * RT + t) * WAVE + lane) * NREG, IN[t]);
-        if constexpr (SYM) ACC = product(GT, WT, IN); else ACC = product(GG, WG, IN);
-        T mxl = T(0);
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-            const T un = A[r] * C::rcp(ACC[r]);
-            U[r] = un;
-            mxl = fmax(fmax(mxl, un), V[r]);
-        }
-        ++ii;
-        // ---- exchange u (+ the partial max); tau hand-off; ACC = (G^T u)[own tile] --------------------------------
-        store_regs<C>(PB + ((1 * RT + w) * WAVE + lane) * NREG, U);
-        XB[(1 * RT + w) * WAVE + lane] = mxl;
-        __syncthreads();
-        T mx = T(0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            load_regs<C>(PB + ((1 * RT + t) * WAVE + lane) * NREG, IN[t]);
-            mx = fmax(mx, XB[(1 * RT + t) * WAVE + lane]);
-        }
-        {
-            const unsigned long long omask = column_any_mask<C>(active && mx > tau);
-            if (omask) {   // hand the pair to the tracking kernel
-                if (w == 0) {
-                    int base = 0;
-                    if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(omask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (((omask >> col) & 1ull) && grp == 0) p.track_list[base + __popcll(omask & ((1ull << col) - 1ull))] = q;
+                        for (int t = 0; t < RT; ++t) {
+                            store_regs<C>(rec + (t * NGRP + grp) * NREG, U[t]);
+                            store_regs<C>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
+                        }
+                        if (grp == 0) {
+                            rec[2 * KP] = scale;
+                            int *meta = reinterpret_cast<int *>(rec + 2 * KP + 1);
+                            meta[0] = q;
+                            meta[1] = flags;
+                        }
+                    }
+                    const unsigned long long taken = __ballot(put) & colmask;
+                    fmask &= ~taken;
+                    ring_cnt = __builtin_amdgcn_readfirstlane(ring_cnt + (int)__popcll(taken));
+                    if (ring_cnt >= p.ring) { flush(ring_cnt); ring_cnt = 0; }
                 }
-                if ((omask >> col) & 1ull) { active = false; want = true; }
+                if (fin) { active = false; want = true; }
             }
-        }
-        ACC = product(GT, WT, IN);
-        // ---- stopping test of this update; next v kept aside (a pair that stops parks the v of THIS update) ---------
-        T el = T(0);
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-            const T d = V[r] * ACC[r] - B[r];
-            el += d * d;
-            VN[r] = B[r] * C::rcp(ACC[r]);
-        }
-        const bool pending = active && ii == chk;
-        if (pending) chk += p.period;
-        const bool capped = active && ii >= p.max_iter;
-        if (__ballot(pending || capped)) {
-            XB[(0 * RT + w) * WAVE + lane] = el;
-            __syncthreads();
-            T e2 = T(0);
-#pragma unroll
-            for (int t = 0; t < RT; ++t) e2 += XB[(0 * RT + t) * WAVE + lane];     // tile order, like the stream kernel
-            e2 = group_sum<C>(e2);
-            const T e = sqrt(e2);
-            bool fin = capped;
-            if (pending) {
-                errv = e;
-                if (e <= thr) { fin = true; flags |= FLAG_CONVERGED; }
-                else if (e != e) { fin = true; flags |= FLAG_NAN; }
-            }
-            if (fin) {
-                if constexpr (sizeof(T) == 8) flags |= FLAG_F64;
-                T *rec = scratch + (size_t)q * SCR;
-                store_regs<C>(rec + (w * NGRP + grp) * NREG, U);
-                store_regs<C>(rec + KP + (w * NGRP + grp) * NREG, V);
-                if (w == 0 && grp == 0) {
-                    rec[2 * KP] = T(1);
-                    if (p.iters) p.iters[q] = ii;
-                    if (p.err) p.err[q] = double(errv);
-                    p.flags[q] = flags;
-                }
-                active = false;
-                want = true;
-            }
-        }
-        V = VN;
-    }
-}
-
-// cost <Gamma, M> = u^T (G o M) v for every parked item (ot.sinkhorn2 returns sum(M * Gamma))
-template <class C, int RT>
-__global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_value_kernel(GridParams p) {
-    using M = C;
-    using T = typename C::T;
-    using acc_t = typename M::acc_t;
-    constexpr int TILE = M::TILE, NREG = M::NREG, NGRP = M::NGRP;
-    constexpr int KP = RT * TILE;
-    constexpr int SCR = scratch_stride<C>(RT);
-    const int n_items = p.n_pairs;
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    const int col = lane % TILE, grp = lane / TILE;
-    const T *img_gm = static_cast<const T *>(p.img) + 2 * KP * KP;   // A operands straight from L2 (read once per tile)
-    const T *scratch = static_cast<const T *>(p.scratch);
-    for (long tile = (long)blockIdx.x * WAVES_PER_WG + wave; tile * TILE < n_items;
-         tile += (long)gridDim.x * WAVES_PER_WG) {
-        long item = tile * TILE + col;
-        const bool live = item < n_items;
-        if (!live) item = n_items - 1;
-        const T *rec = scratch + (size_t)item * SCR;
-        acc_t U[RT], V[RT], ACC[RT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            load_regs<C>(rec + (t * NGRP + grp) * NREG, U[t]);
-            load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
-        }
-        const T scale = rec[2 * KP];
-        acc_t zero;
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) zero[r] = T(0);
-        panel_product<C, RT>(AFromImage<C>{img_gm, lane}, V, ACC, p.K, zero);
-        T val = T(0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r) val += U[t][r] * ACC[t][r];
-        val = group_sum<C>(val) * scale;
-        if (live && grp == 0) {
-            p.emd[item] = double(val);
-            if (val != val) p.flags[item] |= FLAG_NAN;
         }
     }
+    if (ring_cnt > 0) flush(ring_cnt);
 }
 
 // One-launch setup: Gibbs kernel images in MFMA operand order, first-product table, P converted to T.
+__device__ inline unsigned short bf16_bits(float x) {
+    return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
+}
 template <class C>
 __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT, double reg,
                                   typename C::T *__restrict__ img, const double *__restrict__ Psrc,
@@ -1020,7 +1009,40 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
     using M = C;
     using T = typename C::T;
     const int KP = RT * M::TILE;
-    const int nimg = KP * KP;
+    const int nimg = form_elems<C>(RT);
+    if constexpr (C::SPLIT) {
+        // [part][k-block][out tile][lane][8 bf16]: hi / mid / lo pieces of the three operand forms (exact 3-way split of the
+        // f32 value, the same rounding chain as split3)
+        const int KB = split_kblocks(RT);
+        unsigned short *im16 = reinterpret_cast<unsigned short *>(img);
+        for (int idx = tid; idx < KB * RT * WAVE * 8; idx += nthr) {
+            const int e = idx % 8;
+            int rest = idx / 8;
+            const int lane = rest % WAVE; rest /= WAVE;
+            const int t = rest % RT;
+            const int kb = rest / RT;
+            const int orow = M::lidx_of_row(t, lane % M::TILE);
+            const int kt = 2 * kb + e / 4;                            // row-tile whose accumulator register e % 4 is this k-slot
+            const int k = kt < RT ? M::lidx(kt, e % 4, lane / M::TILE) : K;
+            float f[3] = {0.f, 0.f, 0.f};
+            if (orow < K && k < K) {
+                const double m_ko = Msrc[(size_t)k * K + orow], m_ok = Msrc[(size_t)orow * K + k];
+                f[0] = float(exp(-m_ko / reg));
+                f[1] = float(exp(-m_ok / reg));
+                f[2] = float(exp(-m_ok / reg) * m_ok);
+            }
+#pragma unroll
+            for (int form = 0; form < 3; ++form) {
+                float x = f[form];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    const unsigned short hb = bf16_bits(x);
+                    im16[(size_t)form * nimg * 2 + ((((size_t)part * KB + kb) * RT + t) * WAVE + lane) * 8 + e] = hb;
+                    x -= __uint_as_float((unsigned int)hb << 16);
+                }
+            }
+        }
+    } else {
     for (int idx = tid; idx < nimg; idx += nthr) {
         const int lane = idx % WAVE;
         int rest = idx / WAVE;
@@ -1040,6 +1062,7 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
         img[nimg + idx] = T(g);
         img[2 * nimg + idx] = T(gm);
     }
+    }
     // first product of every pair: (G^T u0)[j] = (1/K) * sum_k G[k][j], in accumulator-slot order
     for (int idx = tid; idx < KP; idx += nthr) {
         const int r = idx % M::NREG;                              // slot order [tile][group][reg]
@@ -1049,21 +1072,25 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
         double s = 0.0;
         if (j < K)
             for (int k = 0; k < K; ++k) s += exp(-Msrc[(size_t)k * K + j] / reg);
-        img[3 * nimg + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
+        img[acc0_offset<C>(RT) + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
     }
     // tail-row weights for the VALU variant (see tail_rows): [form][chain][k-step][lane] pairs behind the table
-    if (write_tail & 2) {     // plain tables of solo_pairs
-        T *plain = img + plain_offset(KP, RT);
-        for (int idx = tid; idx < 2 * 64 * WAVE; idx += nthr) {
+    if (write_tail & 2) {     // plain tables of solo_pairs: G[lane][k], G[k][lane], (G o M)[lane][k]
+        T *plain = img + plain_offset<C>(RT);
+        for (int idx = tid; idx < 3 * 64 * WAVE; idx += nthr) {
             const int lane = idx % WAVE, k = (idx / WAVE) % 64, tbl = idx / (64 * WAVE);
             double v = 0.0;
-            if (k < K && lane < K) v = tbl == 0 ? exp(-Msrc[(size_t)lane * K + k] / reg) : exp(-Msrc[(size_t)k * K + lane] / reg);
+            if (k < K && lane < K) {
+                if (tbl == 1) v = exp(-Msrc[(size_t)k * K + lane] / reg);
+                else v = exp(-Msrc[(size_t)lane * K + k] / reg);
+                if (tbl == 2) v *= Msrc[(size_t)lane * K + k];
+            }
             plain[idx] = T(v);
         }
     }
     if (write_tail & 1) {
         const int nst = (RT - 1) * 4 + 1;
-        T *tail = img + 3 * nimg + KP;
+        T *tail = img + tail_offset<C>(RT);
         for (int idx = tid; idx < 2 * 2 * nst * WAVE * 2; idx += nthr) {
             const int h = idx & 1;
             int rest = idx >> 1;

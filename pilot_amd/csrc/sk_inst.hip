@@ -34,23 +34,6 @@ hipError_t stream_any(int RT, bool sym, bool track, dim3 grid, size_t lds, hipSt
     }
 }
 
-template <class C, int RT> hipError_t value_rt(dim3 grid, hipStream_t s, const GridParams &p) {
-    hipLaunchKernelGGL((sinkhorn_value_kernel<C, RT>), grid, dim3(WAVE * WAVES_PER_WG), 0, s, p);
-    return hipGetLastError();
-}
-template <class C> hipError_t value_any(int RT, dim3 grid, hipStream_t s, const GridParams &p) {
-    switch (RT) {
-    case 1: return value_rt<C, 1>(grid, s, p);
-    case 2: return value_rt<C, 2>(grid, s, p);
-    case 3: return value_rt<C, 3>(grid, s, p);
-    case 4: return value_rt<C, 4>(grid, s, p);
-    case 5: return value_rt<C, 5>(grid, s, p);
-    case 6: return value_rt<C, 6>(grid, s, p);
-    case 7: return value_rt<C, 7>(grid, s, p);
-    case 8: return value_rt<C, 8>(grid, s, p);
-    default: return hipErrorInvalidValue;
-    }
-}
 // prepare a call: operand images / tables / slot-ordered proportions + the longest-first order keys, then the scatter
 template <class C>
 hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
@@ -77,66 +60,64 @@ hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const
                            main_queue_head, mode & 3);
     return hipGetLastError();
 }
-template <class C, int RT, bool SYM, int TV = 0>
-hipError_t coop_one(int n_wgs, hipStream_t s, const GridParams &p) {
-    using T = typename C::T;
-    auto kern = sinkhorn_coop_kernel<C, RT, SYM, TV>;
-    const size_t lds = sizeof(T) * (2 * RT * WAVE * C::NREG + 2 * RT * WAVE) + 16;
-    hipLaunchKernelGGL(kern, dim3(n_wgs), dim3(WAVE * RT), lds, s, p);
-    return hipGetLastError();
-}
-template <class C, int TV = 0>
-hipError_t coop_any(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
-    switch (RT) {
-    case 2: return sym ? coop_one<C, 2, true, TV>(n_wgs, s, p) : coop_one<C, 2, false, TV>(n_wgs, s, p);
-    case 3: return sym ? coop_one<C, 3, true, TV>(n_wgs, s, p) : coop_one<C, 3, false, TV>(n_wgs, s, p);
-    case 4: return sym ? coop_one<C, 4, true, TV>(n_wgs, s, p) : coop_one<C, 4, false, TV>(n_wgs, s, p);
-    case 5: return sym ? coop_one<C, 5, true, TV>(n_wgs, s, p) : coop_one<C, 5, false, TV>(n_wgs, s, p);
-    case 6: return sym ? coop_one<C, 6, true, TV>(n_wgs, s, p) : coop_one<C, 6, false, TV>(n_wgs, s, p);
-    case 7: return sym ? coop_one<C, 7, true, TV>(n_wgs, s, p) : coop_one<C, 7, false, TV>(n_wgs, s, p);
-    case 8: return sym ? coop_one<C, 8, true, TV>(n_wgs, s, p) : coop_one<C, 8, false, TV>(n_wgs, s, p);
-    default: return hipErrorInvalidValue;
-    }
-}
 }  // namespace
 
 #if SK_PART == 0
 hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<CfgF32x16>(RT, sym, track, grid, lds, s, p);
 }
-hipError_t launch_value_f32(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF32x16>(RT, grid, s, p); }
-hipError_t launch_prep_f32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
                            double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
-                           int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s);
+hipError_t launch_prep_s32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s);
+hipError_t launch_prep(int cfg, const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                       double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                       int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
+    if (cfg == CFG_F64)
+        return launch_prep_f64(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
+    if (cfg == CFG_S32)
+        return launch_prep_s32(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
     return prep_any<CfgF32x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
                                main_queue_head, mode, n_blocks, s);
 }
-hipError_t launch_coop_f32(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF32x16>(RT, sym, n_wgs, s, p); }
+size_t form_elems_rt(int cfg, int RT) {
+    return cfg == CFG_S32 ? (size_t)form_elems<CfgS32x16>(RT) : (cfg == CFG_F64 ? (size_t)form_elems<CfgF64x16>(RT) : (size_t)form_elems<CfgF32x16>(RT));
+}
+size_t img_elems(int cfg, int RT) {
+    return cfg == CFG_S32 ? (size_t)img_total<CfgS32x16>(RT) : (cfg == CFG_F64 ? (size_t)img_total<CfgF64x16>(RT) : (size_t)img_total<CfgF32x16>(RT));
+}
 #define PILOT_TV_DECL(NAME) \
-    hipError_t launch_stream_##NAME(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p); \
-    hipError_t launch_coop_##NAME(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p);
+    hipError_t launch_stream_##NAME(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 PILOT_TV_DECL(f32_tv1) PILOT_TV_DECL(f32_tv2) PILOT_TV_DECL(f64_tv1) PILOT_TV_DECL(f64_tv2)
 #undef PILOT_TV_DECL
 hipError_t launch_stream_tv(int cfg, int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     if (cfg == CFG_F32) return tv == 1 ? launch_stream_f32_tv1(RT, sym, track, grid, lds, s, p) : launch_stream_f32_tv2(RT, sym, track, grid, lds, s, p);
     return tv == 1 ? launch_stream_f64_tv1(RT, sym, track, grid, lds, s, p) : launch_stream_f64_tv2(RT, sym, track, grid, lds, s, p);
 }
-hipError_t launch_coop_tv(int cfg, int tv, int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
-    if (cfg == CFG_F32) return tv == 1 ? launch_coop_f32_tv1(RT, sym, n_wgs, s, p) : launch_coop_f32_tv2(RT, sym, n_wgs, s, p);
-    return tv == 1 ? launch_coop_f64_tv1(RT, sym, n_wgs, s, p) : launch_coop_f64_tv2(RT, sym, n_wgs, s, p);
-}
 #elif SK_PART == 1
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<CfgF64x16>(RT, sym, track, grid, lds, s, p);
 }
-hipError_t launch_value_f64(int RT, dim3 grid, hipStream_t s, const GridParams &p) { return value_any<CfgF64x16>(RT, grid, s, p); }
 hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
                            double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
     return prep_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
                                main_queue_head, mode, n_blocks, s);
 }
-hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) { return coop_any<CfgF64x16>(RT, sym, n_wgs, s, p); }
+#elif SK_PART == 6
+hipError_t launch_stream_s32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<CfgS32x16>(RT, sym, track, grid, lds, s, p);
+}
+hipError_t launch_prep_s32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
+    return prep_any<CfgS32x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
+}
 #else
 #if SK_PART == 2
 #define PILOT_TV_CFG CfgF32x16
@@ -157,9 +138,6 @@ hipError_t launch_coop_f64(int RT, bool sym, int n_wgs, hipStream_t s, const Gri
 #endif
 hipError_t PILOT_TV_NAME(launch_stream_)(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<PILOT_TV_CFG, PILOT_TV_N>(RT, sym, track, grid, lds, s, p);
-}
-hipError_t PILOT_TV_NAME(launch_coop_)(int RT, bool sym, int n_wgs, hipStream_t s, const GridParams &p) {
-    return coop_any<PILOT_TV_CFG, PILOT_TV_N>(RT, sym, n_wgs, s, p);
 }
 #endif
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernels of the Sinkhorn translation units that use scratch memory (register spills): usage tools/spill_report.sh [parts...]
 cd "$(dirname "$0")/../pilot_amd/csrc"
-for part in ${@:-0 1 2 3 4 5}; do
+for part in ${@:-0 1 2 3 4 5 6}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSK_PART=$part -Rpass-analysis=kernel-resource-usage -c -o /dev/null sk_inst.hip 2>&1 | python3 -c "
 import sys,re
 name=None;info={}
