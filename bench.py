@@ -102,7 +102,7 @@ def main():
     N, K = P.shape
     prec = args.precision
     if prec == "auto":
-        prec = "fp32" if L.pilot_ot_auto_precision(float(M.max()) / args.reg) == 1 else "fp64"
+        prec = {1: "fp32", 2: "fp64", 3: "bf16x3"}[L.pilot_ot_auto_precision_for(float(M.max()) / args.reg, K, int(np.array_equal(M, M.T)))]
 
     if args.mode == "emd":
         out = bench_emd(args, L, P, M, cfg)
@@ -350,15 +350,15 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
     if single_process_multi:
         devices = [0] * args.gpus if args.logical_shards else list(range(args.gpus))
         mp = multi.MultiPlan(P, M, devices=devices)
-        mp.sinkhorn(0.1, precision="fp32"); mp.sync()
+        mp.sinkhorn(0.1, precision="auto"); mp.sync()
         t = time.perf_counter()
         for _ in range(steps):
-            mp.sinkhorn(0.1, precision="fp32")
+            mp.sinkhorn(0.1, precision="auto")
         mp.sync()
         dt = (time.perf_counter() - t) / steps
         g, ga = mp.times_ms()
         mp.close()
-        return {"workload": "c4: 2000 x 100, reg 0.1, f32", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
+        return {"workload": "c4: 2000 x 100, reg 0.1, precision auto", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
                 "grid_ms_per_shard": [round(float(x), 3) for x in g], "gather_ms": round(ga, 3)}
     rb, re_, rs = sharding.shard_rows(N, rank, world)
     n_pad = sharding.n_padded_rows(N, world)
@@ -369,7 +369,7 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
         _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, np.zeros(n_pad * N).ctypes.data, 8 * n_pad * N))
 
     def step():
-        plan.run(0.1, row_begin=rb, row_end=re_, row_step=rs, precision="fp32")
+        plan.run(0.1, row_begin=rb, row_end=re_, row_step=rs, precision="auto")
         if comm:
             comm.all_gather_rows(plan.dE, n_pad, N, d_stage.p, d_full.p)
 
@@ -386,7 +386,7 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
     if comm:
         dt = comm.all_reduce_max(dt)
     main_ms, _ = plan.kernel_times_ms(max_n=steps)
-    res = {"workload": "c4: 2000 x 100, reg 0.1, f32", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
+    res = {"workload": "c4: 2000 x 100, reg 0.1, precision auto", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
            "rank0_kernel_ms": round(float(np.mean(main_ms)), 3)}
     if world == 1:
         _, info = plan.fetch(n_rows=N)

@@ -43,7 +43,7 @@ extern "C" {
 #define PILOT_OT_ERCCL (-4)   /* RCCL error / librccl missing (multi-GPU entry points only) */
 
 /* precision of the Sinkhorn pair-grid kernel */
-#define PILOT_OT_PREC_AUTO 0 /* f32 when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
+#define PILOT_OT_PREC_AUTO 0 /* BF16X3 (f32 values) when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
 #define PILOT_OT_PREC_F32 1    /* f32 values, products on the f32-input MFMA (v_mfma_f32_16x16x4_f32): IEEE f32 FMA chains */
 #define PILOT_OT_PREC_F64 2
 #define PILOT_OT_PREC_BF16X3 3 /* f32 values, products on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits
@@ -218,8 +218,10 @@ int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D
                           int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
                           int row_begin, int row_end, int row_step, double *w2, int *iters, double *err);
 
-/* precision actually selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (1 or 2) */
+/* precision selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (PILOT_OT_PREC_BF16X3 or PILOT_OT_PREC_F64; a shape whose
+ * split operand image does not fit LDS runs PILOT_OT_PREC_F32 instead) */
 int pilot_ot_auto_precision(double max_cost_over_reg);
+int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int cost_is_symmetric);   /* with the LDS fit of this K */
 
 #ifdef __cplusplus
 }

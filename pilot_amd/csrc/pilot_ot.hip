@@ -224,7 +224,16 @@ PILOT_API int pilot_ot_auto_precision(double max_cost_over_reg) {
     // f32 keeps every Gibbs-kernel entry exp(-M/reg) a well-scaled normal number only while
     // max(M)/reg stays clear of the f32 exponent range (ln FLT_MIN = -87.3); beyond ~60 the
     // far-transport entries lose bits, so AUTO switches to the f64 kernel.
-    return max_cost_over_reg <= 60.0 ? PILOT_OT_PREC_F32 : PILOT_OT_PREC_F64;
+    // Inside that range the f32 values are iterated with bf16-split products (PILOT_OT_PREC_BF16X3: f32-level rounding on
+    // the bf16 matrix pipe, measured 1.3x the f32-input MFMA path).
+    return max_cost_over_reg <= 60.0 ? PILOT_OT_PREC_BF16X3 : PILOT_OT_PREC_F64;
+}
+
+namespace { bool split_fits_lds(int K, bool sym); }
+PILOT_API int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int cost_is_symmetric) {
+    int prec = pilot_ot_auto_precision(max_cost_over_reg);
+    if (prec == PILOT_OT_PREC_BF16X3 && !split_fits_lds(K, cost_is_symmetric != 0)) prec = PILOT_OT_PREC_F32;
+    return prec;
 }
 
 PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
@@ -309,6 +318,7 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
 int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split) {
+    if (split) return RT <= 6 ? 2 : 1;
     const int na = RT * 4 * RT * w;
     const bool greg = !split && sym && na <= 64;
     const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) + (split ? 3 * ((RT + 1) / 2) * 4 + 24 : 0) +
@@ -341,6 +351,13 @@ StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want) {
     }
 }
 
+// does the bf16-split configuration fit LDS at this K (operand image(s) + table + a minimal ring)?
+bool split_fits_lds(int K, bool sym) {
+    const int RT = (K + 15) / 16, KP = RT * 16;
+    const size_t fixed = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * 4 + (size_t)KP * 4;
+    return fixed + (size_t)4 * pilot::WAVES_PER_WG * (2 * KP + 4) * 4 <= LDS_BYTES;
+}
+
 // cfg: pilot::CFG_F32 / CFG_F64 / CFG_S32 (all 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
 int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
              double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
@@ -358,6 +375,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     size_t fixed = (size_t)(sym ? 1 : 2) * form * ts + (size_t)KP * ts;   // operand image(s) + first-product table
     // K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
     int tv = 0;
+    const int live1 = (split && RT >= 2 && K - (RT - 1) * TILE <= 4) ? 1 : 0;   // split: skip the dead registers of the last tile
     if (!split) {
         const int n_tail = K - (RT - 1) * TILE;
         // (RT = 8 variants spill: left on the MFMA path)
@@ -423,7 +441,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     auto launch = [&](int tvv, bool track, int wgs, const StreamLds &L) -> hipError_t {
         p.ring = L.ring;
         if (tvv) return pilot::launch_stream_tv(cfg, tvv, RT, sym, track, dim3(wgs), L.bytes, s, p);
-        if (split) return pilot::launch_stream_s32(RT, sym, track, dim3(wgs), L.bytes, s, p);
+        if (split) return pilot::launch_stream_s32(RT, sym, track, live1, dim3(wgs), L.bytes, s, p);
         return f64 ? pilot::launch_stream_f64(RT, sym, track, dim3(wgs), L.bytes, s, p)
                    : pilot::launch_stream_f32(RT, sym, track, dim3(wgs), L.bytes, s, p);
     };
@@ -466,7 +484,9 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     int rc = check_grid_args(pl->N, pl->K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin,
                              row_end, row_step);
     if (rc != PILOT_OT_OK) return rc;
-    if (precision == PILOT_OT_PREC_AUTO) precision = pilot_ot_auto_precision(1.0 / reg);  // M is /max (Trajectory.py:101)
+    if (precision == PILOT_OT_PREC_AUTO) {
+        precision = pilot_ot_auto_precision_for(1.0 / reg, pl->K, cost_is_symmetric);  // M is /max (Trajectory.py:101)
+    }
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -591,7 +611,7 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     if (precision == PILOT_OT_PREC_AUTO) {
         double mx = 0.0;
         for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
-        precision = pilot_ot_auto_precision(mx / reg);
+        precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
     }
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     const size_t n_out = (size_t)n_rows * N;

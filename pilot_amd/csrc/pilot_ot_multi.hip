@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +96,21 @@ int launch_interleave(const double *stage, int G, int n_pad, int N, double *full
     return PILOT_OT_OK;
 }
 
+// RCCL prints a version banner to stdout when a communicator is created; a host program whose stdout is a data channel
+// (bench.py prints one JSON line) must not receive it: while the guard lives, fd 1 points at stderr.
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) { dup2(saved, 1); close(saved); }
+    }
+};
+
 struct DeviceGuard {   // restores the calling thread's current device
     int saved = -1;
     DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
@@ -133,7 +149,11 @@ PILOT_API int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pi
     if (e != hipSuccess) { delete c; return fail(PILOT_OT_EHIP, "hipGetDevice: %s", hipGetErrorString(e)); }
     ncclUniqueId id;
     memcpy(&id, uid, sizeof(id));
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+    ncclResult_t r;
+    {
+        StdoutToStderr quiet;
+        r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+    }
     if (r != ncclSuccess) { delete c; return fail(PILOT_OT_ERCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
     *comm = c;
     return PILOT_OT_OK;
@@ -249,7 +269,11 @@ PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shar
         rc = rccl_load();
         if (rc == PILOT_OT_OK) {
             std::vector<ncclComm_t> comms(n_shards, nullptr);
-            ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_shards, devices);
+            ncclResult_t r;
+            {
+                StdoutToStderr quiet;
+                r = g_rccl.CommInitAll(comms.data(), n_shards, devices);
+            }
             if (r != ncclSuccess) rc = fail(PILOT_OT_ERCCL, "ncclCommInitAll over %d devices: %s", n_shards, g_rccl.GetErrorString(r));
             else for (int s = 0; s < n_shards; ++s) m->sh[s].comm = comms[s];
         }
@@ -463,7 +487,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const 
     if (precision == PILOT_OT_PREC_AUTO) {          // decide once, on the host, so every shard runs the same kernels
         double mx = 0.0;
         for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
-        precision = pilot_ot_auto_precision(mx / reg);
+        precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
     }
     pilot_ot_multi *m = nullptr;
     int rc = multi_ctx(N, K, devices, n_devices, gather, &m);

@@ -379,7 +379,8 @@ __host__ __device__ constexpr int split_kblocks(int RT) { return (RT + 1) / 2; }
 
 // the scaling panel as bf16 B operands: p[part][k-block] = the lane's 8 k-slots (accumulator registers of row-tiles 2 kb, 2 kb + 1)
 template <int RT> struct SplitPanel { u32x4_t p[3][split_kblocks(RT)]; };
-template <class C, int RT>
+// LIVE1: only accumulator register 0 of the last row-tile holds cell types (K mod 16 in 1..4); the others are zero
+template <class C, int RT, bool LIVE1 = false>
 __device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel<RT> &B) {
     constexpr int KB = split_kblocks(RT);
 #pragma unroll
@@ -388,7 +389,8 @@ __device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel
         for (int h = 0; h < 4; ++h) {       // element pairs (0,1), (2,3) of row-tile 2 kb, then of row-tile 2 kb + 1
             const int t = 2 * kb + h / 2;
             Split3 sp = {0u, 0u, 0u};
-            if (t < RT) sp = split3(IN[t < RT ? t : 0][2 * (h & 1)], IN[t < RT ? t : 0][2 * (h & 1) + 1]);
+            if (t < RT && !(LIVE1 && t == RT - 1 && (h & 1)))
+                sp = split3(IN[t < RT ? t : 0][2 * (h & 1)], (LIVE1 && t == RT - 1) ? 0.f : IN[t < RT ? t : 0][2 * (h & 1) + 1]);
             B.p[0][kb][h] = sp.hi; B.p[1][kb][h] = sp.mid; B.p[2][kb][h] = sp.lo;
         }
 }
@@ -416,18 +418,45 @@ __device__ inline typename C::acc_t split_tile_product(const typename C::T *form
     }
     return acc;
 }
-// OUT = X_form * IN for the whole panel
-template <class C, int RT>
+// OUT = X_form * IN for the whole panel.  The three operand pieces of step (t, kb + 1) are requested from LDS before the six
+// MFMAs of step (t, kb) are issued, so a wave never sits on an LDS round trip between MFMA groups.
+template <class C, int RT, bool LIVE1 = false>
 __device__ inline void panel_product_split(const typename C::T *form, int lane, const typename C::acc_t (&IN)[RT],
                                            typename C::acc_t (&OUT)[RT], const typename C::acc_t &last_init) {
+    constexpr int KB = split_kblocks(RT);
     SplitPanel<RT> B;
-    split_panel<C, RT>(IN, B);
+    split_panel<C, RT, LIVE1>(IN, B);
+    const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form) + lane;
+    auto mm = [](u32x4_t a, u32x4_t b, typename C::acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    };
+    u32x4_t a1 = img[((0 * KB + 0) * RT + 0) * WAVE], a2 = img[((1 * KB + 0) * RT + 0) * WAVE], a3 = img[((2 * KB + 0) * RT + 0) * WAVE];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         typename C::acc_t acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (t == RT - 1) ? last_init[r] : 0.f;
-        OUT[t] = split_tile_product<C, RT>(form, lane, t, B, acc);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int nt = kb + 1 < KB ? t : t + 1, nkb = kb + 1 < KB ? kb + 1 : 0;      // the step after this one
+            u32x4_t n1 = a1, n2 = a2, n3 = a3;
+            if (nt < RT) {
+                n1 = img[((0 * KB + nkb) * RT + nt) * WAVE];
+                n2 = img[((1 * KB + nkb) * RT + nt) * WAVE];
+                n3 = img[((2 * KB + nkb) * RT + nt) * WAVE];
+            }
+            __builtin_amdgcn_sched_barrier(0x6);        // (VALU / SALU may move across; the LDS reads stay ahead of the MFMAs)
+            // smallest terms first
+            acc = mm(a3, B.p[0][kb], acc);
+            acc = mm(a1, B.p[2][kb], acc);
+            acc = mm(a2, B.p[1][kb], acc);
+            acc = mm(a2, B.p[0][kb], acc);
+            acc = mm(a1, B.p[1][kb], acc);
+            acc = mm(a1, B.p[0][kb], acc);
+            __builtin_amdgcn_sched_barrier(0x6);
+            a1 = n1; a2 = n2; a3 = n3;
+        }
+        OUT[t] = acc;
     }
 }
 
@@ -686,6 +715,7 @@ template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel
            (operands_in_regs<C, RT, SYM>() ? (RT * C::NREG * RT + 2 * TV * tail_steps<RT>()) * int(sizeof(typename C::T) / 4) : 0);
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
+    if (C::SPLIT) return RT <= 6 ? 2 : 1;     // measured register needs of the split variants (3 waves per SIMD at RT <= 4: slower)
     return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
 }
 
@@ -726,12 +756,12 @@ sinkhorn_stream_kernel(GridParams p) {
 
     // stage the stationary operand: image 0 (and image 1 unless G is symmetric) + first-product table
     constexpr int n_img = (SYM ? 1 : 2) * FORM;
-    constexpr int n_tail = TV > 0 ? (SYM ? 1 : 2) * TV * tail_steps<RT>() * WAVE * 2 : 0;
+    constexpr int n_tail = (TV > 0 && !C::SPLIT) ? (SYM ? 1 : 2) * TV * tail_steps<RT>() * WAVE * 2 : 0;
     {
         const T *g = static_cast<const T *>(p.img);
         for (int i = threadIdx.x; i < n_img; i += WAVE * WAVES_PER_WG) lds[i] = g[i];
         for (int i = threadIdx.x; i < KP; i += WAVE * WAVES_PER_WG) lds[n_img + i] = g[acc0_offset<C>(RT) + i];
-        if constexpr (TV > 0) {   // tail-row weights (chains 0 .. TV-1 of form 0, and of form 1 unless symmetric)
+        if constexpr (TV > 0 && !C::SPLIT) {   // tail-row weights (chains 0 .. TV-1 of form 0, and of form 1 unless symmetric)
             constexpr int n_form = TV * tail_steps<RT>() * WAVE * 2;           // floats per form actually used
             const T *tg = g + tail_offset<C>(RT);
             for (int i = threadIdx.x; i < n_form; i += WAVE * WAVES_PER_WG) {
@@ -762,7 +792,7 @@ sinkhorn_stream_kernel(GridParams p) {
     const pair_of<T> *tl_base = reinterpret_cast<const pair_of<T> *>(acc0 + KP);
     const TailFromImage<T, RT> w_gt{tl_base, lane}, w_g{SYM ? tl_base : tl_base + NTF, lane};
     TailFromRegs<T, RT, (GREG && TV > 0) ? TV : 0> wreg;
-    if constexpr (GREG && TV > 0) {
+    if constexpr (GREG && TV > 0 && !C::SPLIT) {
 #pragma unroll
         for (int i = 0; i < TV * tail_steps<RT>(); ++i) wreg.a[i] = tl_base[i * WAVE + lane];
     }
@@ -771,7 +801,7 @@ sinkhorn_stream_kernel(GridParams p) {
     auto product = [&](const AFromImage<C> &a_img, const TailFromImage<T, RT> &w_img, const acc_t (&IN)[RT], acc_t (&OUT)[RT],
                        const acc_t &init) {
         if constexpr (C::SPLIT) {
-            panel_product_split<C, RT>(a_img.img, lane, IN, OUT, init);
+            panel_product_split<C, RT, (TV > 0)>(a_img.img, lane, IN, OUT, init);
         } else if constexpr (TV > 0) {
             if constexpr (GREG) panel_product_tail<C, RT, TV>(areg, wreg, IN, OUT, init, grp);
             else panel_product_tail<C, RT, TV>(a_img, w_img, IN, OUT, init, grp);

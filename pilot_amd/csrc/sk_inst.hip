@@ -108,8 +108,15 @@ hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img
     return prep_any<CfgF64x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
                                main_queue_head, mode, n_blocks, s);
 }
+#elif SK_PART == 7
+// split configuration with only register 0 of the last row-tile live (K mod 16 in 1..4): TV = 1 skips the dead registers
+hipError_t launch_stream_s32_l1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    return stream_any<CfgS32x16, 1>(RT, sym, track, grid, lds, s, p);
+}
 #elif SK_PART == 6
-hipError_t launch_stream_s32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+hipError_t launch_stream_s32_l1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_stream_s32(int RT, bool sym, bool track, int live1, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    if (live1) return launch_stream_s32_l1(RT, sym, track, grid, lds, s, p);
     return stream_any<CfgS32x16>(RT, sym, track, grid, lds, s, p);
 }
 hipError_t launch_prep_s32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,

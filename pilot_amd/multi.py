@@ -59,7 +59,7 @@ class MultiPlan:
         """Enqueue shard grids + the gather on every device (asynchronous)."""
         prec = _lib.PREC[precision]
         if prec == 0:       # decide once so that every shard runs the same kernels
-            prec = self.L.pilot_ot_auto_precision(self.max_cost / float(reg))
+            prec = self.L.pilot_ot_auto_precision_for(self.max_cost / float(reg), self.K, self.sym)
         _lib.check(self.L.pilot_ot_multi_sinkhorn(self.h, float(reg), int(num_iter_max), float(stop_thr), float(tau),
                                                   int(check_period), prec, float(f32_floor_ulps), self.sym))
 

@@ -93,6 +93,8 @@ def test_c4_eight_rows_both_precisions():
     assert Eo.shape == (8, 2000)
     E32, i32 = engine.sinkhorn_grid(P, M, 0.1, precision="fp32", return_info=True, **rows)
     E64, i64 = engine.sinkhorn_grid(P, M, 0.1, precision="fp64", return_info=True, **rows)
+    Es, isp = engine.sinkhorn_grid(P, M, 0.1, precision="auto", return_info=True, **rows)     # bf16-split products
+    assert np.abs(Es - Eo).max() <= TOL32 and np.all(isp["iters"] <= io["iters"])
     assert np.abs(E32 - Eo).max() <= TOL32
     assert np.abs(E64 - Eo).max() <= TOL64
     np.testing.assert_array_equal(i64["iters"], io["iters"])
