@@ -46,6 +46,11 @@ extern "C" {
 #define PILOT_OT_PREC_AUTO 0 /* BF16X3 (f32 values) when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
 #define PILOT_OT_PREC_F32 1    /* f32 values, products on the f32-input MFMA (v_mfma_f32_16x16x4_f32): IEEE f32 FMA chains */
 #define PILOT_OT_PREC_F64 2
+#define PILOT_OT_PREC_AUTO_MIXED 4 /* what AUTO resolves to beyond the f32 range (60 < max(M)/reg <= 140): every pair is iterated in
+                                   * f32 (BF16X3 tau-tracking kernel) with the Gibbs kernel held in TWO EXPONENT BANDS (entries
+                                   * below 2^-110 are kept times 2^128 in a second operand image, so exp(-M/reg) is faithful down
+                                   * to exp(-165)); a pair that still goes NaN / inf is solved again in f64 (PILOT_OT_FLAG_F64
+                                   * tells which).  Falls back to F64 where the images do not fit LDS or max(M)/reg > 140. */
 #define PILOT_OT_PREC_BF16X3 3 /* f32 values, products on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits
                                 * (six piece products per term, f32 accumulation): f32-level rounding, not bit-identical
                                 * to PREC_F32, ~2x its speed */

@@ -101,6 +101,7 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 }
 
 constexpr int MAX_K = 128;
+constexpr int CTRL_INTS = 12;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
@@ -122,7 +123,8 @@ struct pilot_ot_plan {
     int *track_list;   // N x N
     int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch,
                        // [3] queue head of the solo waves, [4..7] split of the ordered list: n_top, (unused copy), n_dup,
-                       // n_dup = number of leading exact-duplicate pairs
+                       // n_dup = number of leading exact-duplicate pairs, [8] length of the f64 fallback list (mixed precision
+                       // at small reg), [9] its queue head
     int *order_list;   // N x N: longest-first work order of the fast launch
     unsigned char *order_bucket;  // N x N
     int *order_hist;   // 2 * ORDER_NB: histogram + scatter cursors
@@ -229,10 +231,10 @@ PILOT_API int pilot_ot_auto_precision(double max_cost_over_reg) {
     return max_cost_over_reg <= 60.0 ? PILOT_OT_PREC_BF16X3 : PILOT_OT_PREC_F64;
 }
 
-namespace { bool split_fits_lds(int K, bool sym); }
+namespace { bool split_fits_lds(int K, bool sym, int bands); }
 PILOT_API int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int cost_is_symmetric) {
     int prec = pilot_ot_auto_precision(max_cost_over_reg);
-    if (prec == PILOT_OT_PREC_BF16X3 && !split_fits_lds(K, cost_is_symmetric != 0)) prec = PILOT_OT_PREC_F32;
+    if (prec == PILOT_OT_PREC_BF16X3 && !split_fits_lds(K, cost_is_symmetric != 0, 1)) prec = PILOT_OT_PREC_F32;
     return prec;
 }
 
@@ -267,7 +269,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     }
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * ((size_t)N * kp + N));   // + one stop threshold per patient
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (8 + 2 * pilot::ORDER_NB) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
@@ -308,7 +310,7 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     if (check_period < 1) return fail(PILOT_OT_EINVAL, "check_period=%d must be >= 1", check_period);
     if (!(stop_thr >= 0.0) || !(stop_thr < 1.0)) return fail(PILOT_OT_EINVAL, "stop_thr=%g must be in [0, 1)", stop_thr);
     if (!(tau > 1.0)) return fail(PILOT_OT_EINVAL, "tau=%g must be > 1", tau);
-    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_BF16X3)
+    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_AUTO_MIXED)
         return fail(PILOT_OT_EINVAL, "unknown precision id %d", precision);
     if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
         return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
@@ -352,16 +354,20 @@ StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want) {
 }
 
 // does the bf16-split configuration fit LDS at this K (operand image(s) + table + a minimal ring)?
-bool split_fits_lds(int K, bool sym) {
+bool split_fits_lds(int K, bool sym, int bands = 1) {
     const int RT = (K + 15) / 16, KP = RT * 16;
-    const size_t fixed = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * 4 + (size_t)KP * 4;
+    const size_t fixed = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * 4 * bands + (size_t)KP * 4;
     return fixed + (size_t)4 * pilot::WAVES_PER_WG * (2 * KP + 4) * 4 <= LDS_BYTES;
 }
 
 // cfg: pilot::CFG_F32 / CFG_F64 / CFG_S32 (all 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
+// mixed (cfg == CFG_S32 only): small reg under PILOT_OT_PREC_AUTO -- every pair is first iterated in f32 (bf16-split
+// products, tau-tracking kernel); pairs whose plan may touch Gibbs entries outside the f32-safe range, or that went NaN, are
+// collected (ring_flush) and solved again by the f64 tracking kernel.
 int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max,
              double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
-             int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s) {
+             int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s,
+             bool mixed = false) {
     const bool f64 = cfg == pilot::CFG_F64, split = cfg == pilot::CFG_S32;
     const size_t ts = f64 ? sizeof(double) : sizeof(float);
     const int w = (int)(ts / 4);
@@ -388,8 +394,8 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if (fixed + pilot::WAVES_PER_WG * slot_bytes > LDS_BYTES)
         return fail(PILOT_OT_ENOTSUP, "K=%d with a %ssymmetric cost needs %zu B of LDS (> %zu) in this precision", K, sym ? "" : "non-",
                     fixed + pilot::WAVES_PER_WG * slot_bytes, LDS_BYTES);
-    pl->order_hist = pl->track_count + 8;     // one control block, one memset per call
-    HIP_TRY(hipMemsetAsync(pl->track_count, 0, (8 + 2 * pilot::ORDER_NB) * sizeof(int), s));
+    pl->order_hist = pl->track_count + CTRL_INTS;     // one control block, one memset per call
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int), s));
     void *img = pl->img;
     void *Pt = pl->p_slot;
     if (n_rows == 0) return PILOT_OT_OK;
@@ -416,10 +422,11 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
     p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
     p.ring = 0;
+    p.fb_list = nullptr; p.fb_count = nullptr; p.bands = 1;
     p.debug = debug;
     const int tiles = (n_pairs + TILE - 1) / TILE;
     // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
-    const bool solo = stream_has_solo(w, RT, sym, tv, split) && !(p.debug & 512);
+    const bool solo = stream_has_solo(w, RT, sym, tv, split) && !(p.debug & 512) && !mixed;
     int solo_blocks = 0;
     {
         // longest-first work order (see order_bucket_kernel)
@@ -427,7 +434,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         if (ob > pl->n_cu) ob = pl->n_cu;
         int *split_ctl = pl->track_count + 4;
         const int mode = (solo ? 2 : 0) | ((p.debug & 2) ? 4 : 0);   // bit 2: natural order (experiment)
-        HIP_TRY(pilot::launch_prep(cfg, d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2, stop_thr, floor_ulps, n_rows, row_begin, row_step,
+        HIP_TRY(pilot::launch_prep(cfg, d_M, K, RT, reg, img, d_P, Pt, N, (tv ? 1 : 0) | 2 | (mixed ? 4 : 0), stop_thr, floor_ulps, n_rows, row_begin, row_step,
                                    pl->order_bucket, pl->order_hist, pl->order_list, split_ctl, pl->track_count + 1, mode, ob, s));
         p.list = pl->order_list;
         if (solo) {
@@ -446,7 +453,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
                    : pilot::launch_stream_f32(RT, sym, track, dim3(wgs), L.bytes, s, p);
     };
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
-    {
+    if (!mixed) {
         int want = stream_min_waves(w, RT, sym, false, tv, split);
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
         const StreamLds L = stream_lds(fixed, slot_bytes, want);
@@ -460,14 +467,44 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
     p.solo_blocks = 0;
+    size_t fixed_t = fixed;
+    if (mixed) {
+        // small reg: EVERY pair goes through the tracking kernel (longest first), with the Gibbs kernel in two exponent
+        // bands; pairs that still leave the f32 range are collected in track_list for the f64 pass
+        p.list = pl->order_list; p.list_len = nullptr;
+        p.bands = 2;
+        p.fb_list = pl->track_list; p.fb_count = pl->track_count + 8;
+        fixed_t = (size_t)(sym ? 1 : 2) * form * ts * 2 + (size_t)KP * ts;
+    }
     {
         // (the tracking kernel's result need not match the fast kernels' bits: a pair is always solved by one of them)
         const int tv_t = RT <= 4 ? tv : 0;          // larger tracking variants spill with the tail rows
-        const StreamLds L = stream_lds(fixed, slot_bytes, stream_min_waves(w, RT, sym, true, tv_t, split));
+        const StreamLds L = stream_lds(fixed_t, slot_bytes, stream_min_waves(w, RT, sym, true, tv_t, split));
         int wgs_t = pl->n_cu * L.wgs_per_cu;
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs_t > need) wgs_t = need;
         HIP_TRY(launch(tv_t, true, wgs_t, L));
+    }
+    if (mixed) {
+        // third pass: the collected pairs in f64 (operand images and proportions rebuilt for the f64 configuration in the
+        // same buffers -- the f32 passes are complete in stream order; no ordering, the list is short)
+        const int RT64 = RT;
+        const size_t form64 = pilot::form_elems_rt(pilot::CFG_F64, RT64);
+        const size_t fixed64 = (size_t)(sym ? 1 : 2) * form64 * sizeof(double) + (size_t)KP * sizeof(double);
+        const size_t slot64 = (size_t)(2 * KP + 4) * sizeof(double);
+        if (fixed64 + pilot::WAVES_PER_WG * slot64 > LDS_BYTES)
+            return fail(PILOT_OT_ENOTSUP, "K=%d: the f64 fallback needs %zu B of LDS", K, fixed64 + pilot::WAVES_PER_WG * slot64);
+        HIP_TRY(pilot::launch_prep(pilot::CFG_F64, d_M, K, RT64, reg, img, d_P, Pt, N, 2, stop_thr, floor_ulps, 0, row_begin, row_step,
+                                   pl->order_bucket, pl->order_hist, pl->order_list, pl->track_count + 4, pl->track_count + 1, 0, 1, s));
+        pilot::GridParams q = p;
+        q.list = pl->track_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9;
+        q.fb_list = nullptr; q.fb_count = nullptr; q.bands = 1;
+        const StreamLds L = stream_lds(fixed64, slot64, stream_min_waves(2, RT64, sym, true, 0, false));
+        q.ring = L.ring;
+        int wgs_t = pl->n_cu * L.wgs_per_cu;
+        const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+        if (wgs_t > need) wgs_t = need;
+        HIP_TRY(pilot::launch_stream_f64(RT64, sym, true, dim3(wgs_t), L.bytes, s, q));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
     return PILOT_OT_OK;
@@ -484,16 +521,24 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     int rc = check_grid_args(pl->N, pl->K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin,
                              row_end, row_step);
     if (rc != PILOT_OT_OK) return rc;
+    bool mixed = false;
     if (precision == PILOT_OT_PREC_AUTO) {
         precision = pilot_ot_auto_precision_for(1.0 / reg, pl->K, cost_is_symmetric);  // M is /max (Trajectory.py:101)
+        mixed = precision == PILOT_OT_PREC_F64;
+    } else if (precision == PILOT_OT_PREC_AUTO_MIXED) {       // (what the host entry point passes after looking at max(M))
+        precision = PILOT_OT_PREC_F64;
+        mixed = true;
     }
+    // beyond the f32 range AUTO still tries f32 first, pair by pair, where the split images fit and POT's defaults hold
+    mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && 1.0 / reg <= 140.0 && !getenv("PILOT_OT_NO_MIXED");
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int cfg = precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : pilot::CFG_F64);
+    const int cfg = mixed ? pilot::CFG_S32
+                          : (precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : pilot::CFG_F64));
     return run_grid(cfg, pl, d_P, d_M, reg, num_iter_max,
                     stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0, row_begin, n_rows, row_step,
-                    d_emd, d_iters, d_err, d_flags, s);
+                    d_emd, d_iters, d_err, d_flags, s, mixed);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -612,6 +657,7 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
         double mx = 0.0;
         for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
         precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
+        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
     }
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     const size_t n_out = (size_t)n_rows * N;

@@ -488,6 +488,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const 
         double mx = 0.0;
         for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
         precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
+        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
     }
     pilot_ot_multi *m = nullptr;
     int rc = multi_ctx(N, K, devices, n_devices, gather, &m);

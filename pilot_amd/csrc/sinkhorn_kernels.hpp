@@ -354,6 +354,9 @@ template <class C> __device__ inline void load_regs(const typename C::T *src, ty
 // Layout: the 16x16 f32 result tile of 16x16x32 has the same lane/register map as 16x16x4's, and a lane's 8 bf16 B values
 // of k-block kb are exactly its 2 x 4 accumulator registers of row-tiles 2 kb and 2 kb + 1 -- so the result still feeds the
 // next product with no lane movement: k-slot (group g, element e) of block kb <-> cell type lidx(2 kb + e / 4, e % 4, g).
+constexpr float SPLIT_SAFE_MIN = 7.70371978e-34f;     // 2^-110: below it the low pieces of a 3-way bf16 split are subnormal
+constexpr float BAND1_DOWN = 2.93873588e-39f;          // 2^-128: scale of the second exponent band (see band1_offset)
+constexpr double BAND1_UP_LN = 88.722839111672999;     // 128 ln 2
 using bf16x8_t = __bf16 __attribute__((ext_vector_type(8)));
 using bf16x2_t = __bf16 __attribute__((ext_vector_type(2)));
 using u32x4_t = unsigned int __attribute__((ext_vector_type(4)));
@@ -420,9 +423,11 @@ __device__ inline typename C::acc_t split_tile_product(const typename C::T *form
 }
 // OUT = X_form * IN for the whole panel.  The three operand pieces of step (t, kb + 1) are requested from LDS before the six
 // MFMAs of step (t, kb) are issued, so a wave never sits on an LDS round trip between MFMA groups.
+// form1 (nullable, wave-uniform): the band-1 image of the same operand; OUT = X0 * IN + 2^-128 (X1 * IN).
 template <class C, int RT, bool LIVE1 = false>
-__device__ inline void panel_product_split(const typename C::T *form, int lane, const typename C::acc_t (&IN)[RT],
-                                           typename C::acc_t (&OUT)[RT], const typename C::acc_t &last_init) {
+__device__ inline void panel_product_split(const typename C::T *form, const typename C::T *form1, int lane,
+                                           const typename C::acc_t (&IN)[RT], typename C::acc_t (&OUT)[RT],
+                                           const typename C::acc_t &last_init) {
     constexpr int KB = split_kblocks(RT);
     SplitPanel<RT> B;
     split_panel<C, RT, LIVE1>(IN, B);
@@ -458,6 +463,17 @@ __device__ inline void panel_product_split(const typename C::T *form, int lane, 
         }
         OUT[t] = acc;
     }
+    if (form1) {        // wave-uniform; a compile-time nullptr in the single-band kernels
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            typename C::acc_t zero;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zero[r] = 0.f;
+            const typename C::acc_t lo = split_tile_product<C, RT>(form1, lane, t, B, zero);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) OUT[t][r] = fmaf(lo[r], BAND1_DOWN, OUT[t][r]);
+        }
+    }
 }
 
 struct GridParams {
@@ -482,6 +498,9 @@ struct GridParams {
     int *solo_head;       //   their queue head
     int solo_blocks;      //   leading workgroups of the launch that run solo_pairs (they start first); 0: none
     int ring;             // slots of the per-wave LDS ring of finished pairs (1 .. RING_MAX; sized by the host to fit LDS)
+    int bands;            // bf16-split tracking kernel: 2 = the Gibbs kernel in two exponent bands (small reg), else 1
+    int *fb_list;         // nullable (bf16-split configuration, small reg): pairs that went NaN / inf in f32 are appended here
+    int *fb_count;        //   instead of being written out, and the f64 kernel solves them again (see ring_flush)
     int debug;            // experiment switches (PILOT_OT_DEBUG): bit0 no priority, bit1 no longest-first order
 };
 
@@ -496,7 +515,15 @@ template <class C> __host__ __device__ constexpr int form_elems(int RT) {
 template <class C> __host__ __device__ constexpr int acc0_offset(int RT) { return 3 * form_elems<C>(RT); }
 template <class C> __host__ __device__ constexpr int tail_offset(int RT) { return acc0_offset<C>(RT) + RT * C::TILE; }
 template <class C> __host__ __device__ constexpr int plain_offset(int RT) { return tail_offset<C>(RT) + 2 * 2 * ((RT - 1) * 4 + 1) * WAVE * 2; }
-template <class C> __host__ __device__ constexpr int img_total(int RT) { return plain_offset<C>(RT) + 3 * 64 * WAVE; }
+// [band-1 forms 0..2] (bf16-split configuration, small reg): the Gibbs kernel in TWO EXPONENT BANDS.  An f32 (or a 3-way
+// bf16 split of it) represents exp(-M/reg) faithfully only above SPLIT_SAFE_MIN; at reg = 0.01 a fifth of the entries of
+// the 600 x 50 benchmark lie below and most optimal plans put 1e-8 .. 1e-2 of their mass on them.  Band 0 keeps the
+// entries >= SPLIT_SAFE_MIN (others 0), band 1 holds the others multiplied by 2^128, and a product is
+// X0 * in + 2^-128 (X1 * in): both partial products are f32-accurate, so entries down to 2^-238 = exp(-165) take part
+// with full precision -- the range POT's log-absorption covers, without a per-pair kernel matrix.
+template <class C> __host__ __device__ constexpr int band1_offset(int RT) { return plain_offset<C>(RT) + 3 * 64 * WAVE; }
+template <class C> __host__ __device__ constexpr int img_total(int RT) { return band1_offset<C>(RT) + (C::SPLIT ? 3 * form_elems<C>(RT) : 0); }
+
 
 // ---- one wave per pair: the exact duplicates ---------------------------------------------------------------------------
 // Pairs with a == b (the diagonal of the grid, duplicate patients) need the most updates by far (161 .. 381 at c3 against
@@ -630,9 +657,11 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
 // row-tile at a time.  Deliberately NOT inlined: it runs once per 16 finished pairs, and as a call its register needs
 // (the v panel, an accumulator tile, operands in flight) are paid at the call site instead of raising the pressure of
 // the update loop around it.
+//
+// Small reg in f32 (bf16-split configuration): with p.bands == 2 the cost product uses both exponent bands of G o M; with
+// p.fb_list set, a pair whose cost is not finite is not written out but appended to fb_list for the f64 kernel.
 template <class C, int RT>
-__device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, const typename C::T *img_gm, int K, int cnt,
-                                                     double *emd, int *flags_out) {
+__device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, const GridParams &p, int cnt) {
     using M = C;
     using T = typename C::T;
     using acc_t = typename C::acc_t;
@@ -641,66 +670,78 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
     constexpr int RSTRIDE = ring_slot_stride<C>(RT);
     const int lane = threadIdx.x % WAVE;
     const int col = lane % TILE, grp = lane / TILE;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int s = col < cnt ? col : cnt - 1;        // columns beyond the fill level redo the last slot, unused
-            const T *rec = ring + s * RSTRIDE;
-            const T scale = rec[2 * KP];
-            // one output row-tile at a time: only the v panel (or its bf16 pieces) is live beside the iteration state
-            T val = T(0);
-            if constexpr (C::SPLIT) {
-                SplitPanel<RT> Bv;
-                {
-                    acc_t Vr[RT];
-    #pragma unroll
-                    for (int t = 0; t < RT; ++t) load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, Vr[t]);
-                    split_panel<C, RT>(Vr, Bv);
-                }
-    #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    acc_t w;
-    #pragma unroll
-                    for (int r = 0; r < NREG; ++r) w[r] = T(0);
-                    w = split_tile_product<C, RT>(img_gm, lane, t, Bv, w);
-                    acc_t ur;
-                    load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
-    #pragma unroll
-                    for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
-                }
-            } else {
-                acc_t Vr[RT];
-    #pragma unroll
-                for (int t = 0; t < RT; ++t) load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, Vr[t]);
-                const int n_last = (K - M::lidx(RT - 1, 0, 0) + NGRP - 1) / NGRP;     // live k-steps of the last row-tile
-    #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    acc_t w;
-    #pragma unroll
-                    for (int r = 0; r < NREG; ++r) w[r] = T(0);
-    #pragma unroll
-                    for (int tp = 0; tp < RT; ++tp)
-    #pragma unroll
-                        for (int r = 0; r < NREG; ++r)
-                            if (tp < RT - 1 || r < n_last)        // wave-uniform
-                                w = M::mfma(img_gm[((tp * NREG + r) * RT + t) * WAVE + lane], Vr[tp][r], w);
-                    acc_t ur;
-                    load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
-    #pragma unroll
-                    for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
-                }
+    const T *img_gm = static_cast<const T *>(p.img) + 2 * form_elems<C>(RT);     // read from L2, once per 16 finished pairs
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int s = col < cnt ? col : cnt - 1;        // columns beyond the fill level redo the last slot, unused
+    const T *rec = ring + s * RSTRIDE;
+    const T scale = rec[2 * KP];
+    // one output row-tile at a time: only the v panel (or its bf16 pieces) is live
+    T val = T(0);
+    if constexpr (C::SPLIT) {
+        SplitPanel<RT> Bv;
+        {
+            acc_t Vr[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, Vr[t]);
+            split_panel<C, RT>(Vr, Bv);
+        }
+        const T *img_gm1 = static_cast<const T *>(p.img) + band1_offset<C>(RT) + 2 * form_elems<C>(RT);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            acc_t zero;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) zero[r] = T(0);
+            acc_t w = split_tile_product<C, RT>(img_gm, lane, t, Bv, zero);
+            if (p.bands == 2) {                       // wave-uniform
+                const acc_t w1 = split_tile_product<C, RT>(img_gm1, lane, t, Bv, zero);
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) w[r] = fmaf(w1[r], BAND1_DOWN, w[r]);
             }
-            val = group_sum<C>(val) * scale;
-            if (grp == 0 && col < cnt) {
-                const int *meta = reinterpret_cast<const int *>(rec + 2 * KP + 1);
-                const int qq = meta[0];
-                int fl = meta[1];
-                if (val != val) fl |= FLAG_NAN;
-                emd[qq] = double(val);
-                flags_out[qq] = fl;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slots are reused only after every lane has read them
-            __builtin_amdgcn_wave_barrier();
+            acc_t ur;
+            load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
+        }
+    } else {
+        acc_t Vr[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) load_regs<C>(rec + KP + (t * NGRP + grp) * NREG, Vr[t]);
+        const int n_last = (p.K - M::lidx(RT - 1, 0, 0) + NGRP - 1) / NGRP;     // live k-steps of the last row-tile
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            acc_t w;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) w[r] = T(0);
+#pragma unroll
+            for (int tp = 0; tp < RT; ++tp)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r)
+                    if (tp < RT - 1 || r < n_last)        // wave-uniform
+                        w = M::mfma(img_gm[((tp * NREG + r) * RT + t) * WAVE + lane], Vr[tp][r], w);
+            acc_t ur;
+            load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
+        }
+    }
+    val = group_sum<C>(val) * scale;
+    const bool redo = p.fb_list && !(val - val == T(0));       // NaN or inf: out of the f32 range somewhere along the way
+    if (grp == 0 && col < cnt) {
+        const int *meta = reinterpret_cast<const int *>(rec + 2 * KP + 1);
+        const int qq = meta[0];
+        int fl = meta[1];
+        if (redo || (p.fb_list && (fl & FLAG_NAN))) {
+            p.fb_list[__hip_atomic_fetch_add(p.fb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
+        } else {
+            if (val != val) fl |= FLAG_NAN;
+            p.emd[qq] = double(val);
+            p.flags[qq] = fl;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slots are reused only after every lane has read them
+    __builtin_amdgcn_wave_barrier();
 }
 
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
@@ -755,11 +796,16 @@ sinkhorn_stream_kernel(GridParams p) {
     if (block * WAVES_PER_WG * TILE >= n_items) return;  // more workgroups than work (tracking launch)
 
     // stage the stationary operand: image 0 (and image 1 unless G is symmetric) + first-product table
-    constexpr int n_img = (SYM ? 1 : 2) * FORM;
+    // (bf16-split tracking kernel with two exponent bands: the band-1 images follow the band-0 ones)
+    const bool two_bands = C::SPLIT && TRACK && p.bands == 2;
+    const int n_img = (SYM ? 1 : 2) * FORM * (two_bands ? 2 : 1);
     constexpr int n_tail = (TV > 0 && !C::SPLIT) ? (SYM ? 1 : 2) * TV * tail_steps<RT>() * WAVE * 2 : 0;
     {
         const T *g = static_cast<const T *>(p.img);
-        for (int i = threadIdx.x; i < n_img; i += WAVE * WAVES_PER_WG) lds[i] = g[i];
+        constexpr int n_b0 = (SYM ? 1 : 2) * FORM;
+        for (int i = threadIdx.x; i < n_b0; i += WAVE * WAVES_PER_WG) lds[i] = g[i];
+        if (two_bands)
+            for (int i = threadIdx.x; i < n_b0; i += WAVE * WAVES_PER_WG) lds[n_b0 + i] = g[band1_offset<C>(RT) + i];
         for (int i = threadIdx.x; i < KP; i += WAVE * WAVES_PER_WG) lds[n_img + i] = g[acc0_offset<C>(RT) + i];
         if constexpr (TV > 0 && !C::SPLIT) {   // tail-row weights (chains 0 .. TV-1 of form 0, and of form 1 unless symmetric)
             constexpr int n_form = TV * tail_steps<RT>() * WAVE * 2;           // floats per form actually used
@@ -773,7 +819,6 @@ sinkhorn_stream_kernel(GridParams p) {
     __syncthreads();
     const T *img_gt = lds;                                         // out = G^T in
     const T *img_g = SYM ? lds : lds + FORM;                       // out = G in
-    const T *img_gm = static_cast<const T *>(p.img) + 2 * FORM;    // out = (G o M) in: read from L2 once per 16 finished pairs
     // wave-private ring of finished pairs (u, v panels + scale / output index / flags in the slot's padding)
     T *ring = lds + n_img + KP + n_tail + (threadIdx.x / WAVE) * p.ring * RSTRIDE;
     // small symmetric problems keep the whole operand image in registers (no LDS access in the loop)
@@ -801,7 +846,8 @@ sinkhorn_stream_kernel(GridParams p) {
     auto product = [&](const AFromImage<C> &a_img, const TailFromImage<T, RT> &w_img, const acc_t (&IN)[RT], acc_t (&OUT)[RT],
                        const acc_t &init) {
         if constexpr (C::SPLIT) {
-            panel_product_split<C, RT, (TV > 0)>(a_img.img, lane, IN, OUT, init);
+            if constexpr (TRACK) panel_product_split<C, RT, (TV > 0)>(a_img.img, two_bands ? a_img.img + (SYM ? 1 : 2) * FORM : nullptr, lane, IN, OUT, init);
+            else panel_product_split<C, RT, (TV > 0)>(a_img.img, nullptr, lane, IN, OUT, init);
         } else if constexpr (TV > 0) {
             if constexpr (GREG) panel_product_tail<C, RT, TV>(areg, wreg, IN, OUT, init, grp);
             else panel_product_tail<C, RT, TV>(a_img, w_img, IN, OUT, init, grp);
@@ -839,7 +885,7 @@ sinkhorn_stream_kernel(GridParams p) {
         }
 
     int ring_cnt = 0;
-    auto flush = [&](int cnt) { ring_flush<C, RT>(ring, img_gm, p.K, cnt, p.emd, p.flags); };
+    auto flush = [&](int cnt) { ring_flush<C, RT>(ring, p, cnt); };
 
     // work queue: waves draw batches of TILE items from one device-wide counter, so a wave that got
     // long-running pairs simply draws fewer batches
@@ -1054,12 +1100,33 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
             const int orow = M::lidx_of_row(t, lane % M::TILE);
             const int kt = 2 * kb + e / 4;                            // row-tile whose accumulator register e % 4 is this k-slot
             const int k = kt < RT ? M::lidx(kt, e % 4, lane / M::TILE) : K;
-            float f[3] = {0.f, 0.f, 0.f};
+            float f[3] = {0.f, 0.f, 0.f}, f1[3] = {0.f, 0.f, 0.f};
             if (orow < K && k < K) {
                 const double m_ko = Msrc[(size_t)k * K + orow], m_ok = Msrc[(size_t)orow * K + k];
                 f[0] = float(exp(-m_ko / reg));
                 f[1] = float(exp(-m_ok / reg));
                 f[2] = float(exp(-m_ok / reg) * m_ok);
+                if (write_tail & 4) {       // two exponent bands: entries below the safe minimum move to band 1, times 2^128
+                    if (f[0] < SPLIT_SAFE_MIN) { f1[0] = float(exp(-m_ko / reg + BAND1_UP_LN)); f[0] = 0.f; }
+                    if (f[1] < SPLIT_SAFE_MIN) {
+                        f1[1] = float(exp(-m_ok / reg + BAND1_UP_LN));
+                        f1[2] = float(exp(-m_ok / reg + BAND1_UP_LN) * m_ok);
+                        f[1] = 0.f; f[2] = 0.f;
+                    }
+                }
+            }
+            if (write_tail & 4) {
+                unsigned short *im1 = reinterpret_cast<unsigned short *>(img + band1_offset<C>(RT));
+#pragma unroll
+                for (int form = 0; form < 3; ++form) {
+                    float x = f1[form];
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) {
+                        const unsigned short hb = bf16_bits(x);
+                        im1[(size_t)form * nimg * 2 + ((((size_t)part * KB + kb) * RT + t) * WAVE + lane) * 8 + e] = hb;
+                        x -= __uint_as_float((unsigned int)hb << 16);
+                    }
+                }
             }
 #pragma unroll
             for (int form = 0; form < 3; ++form) {

@@ -60,6 +60,8 @@ class MultiPlan:
         prec = _lib.PREC[precision]
         if prec == 0:       # decide once so that every shard runs the same kernels
             prec = self.L.pilot_ot_auto_precision_for(self.max_cost / float(reg), self.K, self.sym)
+            if prec == 2:
+                prec = 4        # PILOT_OT_PREC_AUTO_MIXED: f32 first, f64 for the pairs that need it
         _lib.check(self.L.pilot_ot_multi_sinkhorn(self.h, float(reg), int(num_iter_max), float(stop_thr), float(tau),
                                                   int(check_period), prec, float(f32_floor_ulps), self.sym))
 

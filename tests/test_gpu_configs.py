@@ -42,23 +42,30 @@ def test_c3_reg001_twenty_rows_f64_follow_the_oracle_update_for_update(c3_small_
 
 
 def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle):
-    """precision='auto' at max(M)/reg = 100: whatever mix of f32 / f64 the engine picks, the matrix is within the f32
-    tolerance of the oracle on every pair that ran the oracle's update count and did not absorb on its last update
-    (those pairs return the plan / K^2, a POT artefact that only the tracking kernels reproduce)."""
+    """precision='auto' at max(M)/reg = 100 (PILOT_OT_PREC_AUTO_MIXED): f32 values on the bf16-split tracking kernel with the
+    Gibbs kernel in two exponent bands, f64 only for pairs that leave the f32 range.  A fifth of exp(-M/reg) lies below what
+    one f32 band represents and most plans use those entries, so this is the test of the second band: every pair -- capped,
+    converged, absorbed -- must be within the f32 tolerance of the fp64 oracle, except the pairs POT itself returns scaled by
+    1/K^2 (absorption on the final update), which both sides must flag alike."""
     P, M, rows, Eo, io = c3_small_reg_oracle
     Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="auto", return_info=True, **rows)
     assert np.isfinite(Eg).all()
+    f64 = (ig["flags"] & _lib.FLAG_F64) > 0
+    assert f64.mean() < 0.01                                       # the f32 bands carry (nearly) everything
     last_o = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0
     last_g = (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
     same = ig["iters"] == io["iters"]
-    ok = same & ~last_o & ~last_g
-    assert ok.mean() > 0.9
-    assert np.abs(Eg - Eo)[ok].max() <= TOL32
-    # pairs solved in f64 match update for update
-    f64 = (ig["flags"] & _lib.FLAG_F64) > 0
-    if f64.any():
+    print("auto @ reg 0.01: %d of %d pairs in f64, max|gpu - oracle| %.3e (pairs with the oracle's update count: %d, %.3e)"
+          % (f64.sum(), Eg.size, np.abs(Eg - Eo)[~last_o & ~last_g].max(), same.sum(), np.abs(Eg - Eo)[same & ~last_o].max()))
+    assert np.abs(Eg - Eo)[~last_o & ~last_g].max() <= TOL32
+    assert np.all(ig["iters"] <= io["iters"])                      # f32 stop-threshold floor: same or an earlier check
+    np.testing.assert_array_equal(last_g[same], last_o[same])
+    if f64.any():                                                  # pairs solved in f64 match update for update
         np.testing.assert_array_equal(ig["iters"][f64], io["iters"][f64])
         assert np.abs(Eg - Eo)[f64].max() <= 1e-9
+    # one exponent band alone is NOT enough here (what the second band is for)
+    E1 = engine.sinkhorn_grid(P, M, 0.01, precision="bf16x3", **rows)
+    assert np.abs(E1 - Eo)[~last_o].max() > 10 * TOL32
 
 
 def test_c3_reg001_twenty_rows_f32(c3_small_reg_oracle):
