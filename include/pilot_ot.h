@@ -114,6 +114,9 @@ int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric
  * num_iter_max=1000, stop_thr=1e-9, tau=1e3, check_period=20.  In f32 the stop threshold is
  * floored at f32_floor_ulps * FLT_EPSILON * ||b||_2 (pass 0 for the default of 8).
  * cost_is_symmetric: 1 if M == M^T exactly (always true for pdist output), 0 otherwise.
+ * Range: max(M)/reg <= 600 (PILOT_OT_ENOTSUP beyond: the kernels keep total scalings against the fixed exp(-M/reg) instead
+ * of rebuilding POT's absorbed kernel, so the ratio must fit the f64 exponent range).  The device-resident form takes M
+ * already divided by its max (Trajectory.py:101) and checks 1/reg.
  * emd / iters / err / flags: n_rows x N; iters, err, flags may be NULL. */
 int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg,
                            int num_iter_max, double stop_thr, double tau, int check_period,
@@ -210,6 +213,23 @@ int pilot_ot_comm_destroy(pilot_ot_comm *comm);
 int pilot_ot_comm_all_gather_rows(pilot_ot_comm *comm, const double *d_local, int n_pad, int N, double *d_stage,
                                   double *d_full, void *stream);
 int pilot_ot_comm_all_reduce_max(pilot_ot_comm *comm, double *d_vals, int n, void *stream);  /* in place; also the barrier */
+
+/* ---- consumers of the finished matrix: what pilotpy does with adata.uns['EMD'] next, kept on the device ----
+ * The ROWS of the N x N matrix are the data points of pl.trajectory's diffusion map (pilotpy/plot/ploting.py:95-110, after
+ * EMD / EMD.max()) and of the silhouette scores (Sil_computing, pilotpy/tools/Trajectory.py:592-612; ploting.py:324, :425-431).
+ * row_distances: D[i][j] = distance between rows i and j (of E / max(E) when normalize_by_max), Euclidean (scipy cdist) or
+ *                cosine (sklearn cosine_distances: clipped to [0, 2], zero diagonal).
+ * silhouette:    sklearn.metrics.silhouette_score(D, labels, metric="precomputed"); labels in [0, n_clusters);
+ *                samples (nullable, N) receives silhouette_samples.
+ * knn_kernel:    Kmat[i][j] = exp(-D[i][j]^2 / (4 epsilon)) for the k smallest entries of row i (the point itself included,
+ *                like sklearn's kneighbors_graph on the fitted data), 0 elsewhere: the kernel matrix pydiffmap builds. */
+#define PILOT_OT_ROWMETRIC_EUCLIDEAN 0
+#define PILOT_OT_ROWMETRIC_COSINE 1
+int pilot_ot_row_distances(const double *E, int N, int normalize_by_max, int metric, double *D);
+int pilot_ot_row_distances_dev(const double *d_E, int N, int normalize_by_max, int metric, double *d_D,
+                               double *d_max_scratch /* 8 bytes, needed when normalize_by_max */, void *stream);
+int pilot_ot_silhouette(const double *D, const int *labels, int N, int n_clusters, double *score, double *samples);
+int pilot_ot_knn_kernel(const double *D, int N, int k, double epsilon, double *Kmat);
 
 /* ---- cell-level W2 pair grid (EXTENSION: not in the reference; BASELINE config 5) ------ */
 /* Compares patients by their raw cell clouds instead of cell-type proportions.  X: n_cells x D float32 embedding

@@ -30,6 +30,7 @@ SYMBOLS = [
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_centroid_medians", "pilot_ot_cell_w2_grid",
     "pilot_ot_mirror_upper_dev",
+    "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
     "pilot_ot_multi_create", "pilot_ot_multi_destroy", "pilot_ot_multi_set_inputs", "pilot_ot_multi_sinkhorn",
     "pilot_ot_multi_emd", "pilot_ot_multi_sync", "pilot_ot_multi_fetch", "pilot_ot_multi_device_matrix",
     "pilot_ot_multi_times", "pilot_ot_sinkhorn_grid_multi", "pilot_ot_emd_grid_multi",
@@ -37,6 +38,7 @@ SYMBOLS = [
     "pilot_ot_comm_all_gather_rows", "pilot_ot_comm_all_reduce_max",
 ]
 GATHER = {"auto": 0, "rccl": 1, "copy": 2}
+ROW_METRICS = {"euclidean": 0, "cosine": 1}
 UNIQUE_ID_BYTES = 128
 
 _lib = None
@@ -89,6 +91,10 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_emd_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]
     fp = ctypes.POINTER(ctypes.c_float)
     L.pilot_ot_mirror_upper_dev.argtypes = [c_vp, c_int, c_vp]
+    L.pilot_ot_row_distances.argtypes = [dp, c_int, c_int, c_int, dp]
+    L.pilot_ot_row_distances_dev.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]
+    L.pilot_ot_silhouette.argtypes = [dp, ip, c_int, c_int, dp, dp]
+    L.pilot_ot_knn_kernel.argtypes = [dp, c_int, c_int, c_dbl, dp]
     L.pilot_ot_multi_create.argtypes = [c_int, c_int, ip, c_int, c_int, ctypes.POINTER(c_vp)]
     L.pilot_ot_multi_destroy.argtypes = [c_vp]
     L.pilot_ot_multi_set_inputs.argtypes = [c_vp, dp, dp]

@@ -1,0 +1,123 @@
+// Downstream consumers of the finished N x N distance matrix, kept on the device.
+//
+// What the reference does with adata.uns['EMD'] right after wasserstein_distance:
+//   * pl.trajectory         (pilotpy/plot/ploting.py:95-110): EMD / EMD.max(), then pydiffmap's DiffusionMap.from_sklearn(
+//                           epsilon, alpha, k).fit_transform(EMD): the ROWS of the normalised matrix are the data points;
+//                           kernel = exp(-d^2 / (4 epsilon)) on every row's k nearest rows (Euclidean d);
+//   * Sil_computing         (pilotpy/tools/Trajectory.py:592-612, called from ploting.py:324 on EMD / EMD.max()) and
+//     pl.select_best_sil    (ploting.py:425-431): sklearn.metrics.silhouette_score(EMD, labels, metric='cosine'): again the
+//                           rows are the points, under the cosine (default) or Euclidean metric.
+// Three kernels cover the dense part of both: row-to-row distances (an N x N x N contraction), the mean silhouette of a
+// labelling, and the k-nearest-neighbour Gaussian kernel matrix.  All fp64 like scikit-learn.  The contraction is 2.2e8
+// multiply-adds at N = 600 and 8e9 at N = 2000 -- a millisecond or two on the vector units beside a 38 ms pair grid, so it is a
+// plain LDS-tiled kernel, not an MFMA one.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pilot {
+
+// max of a buffer -> out[0] (one workgroup; N*N <= a few million)
+static __global__ void max_reduce_kernel(const double *__restrict__ X, long n, double *__restrict__ out) {
+    __shared__ double part[256];
+    double m = -__builtin_inf();
+    for (long t = threadIdx.x; t < n; t += blockDim.x) m = X[t] > m ? X[t] : m;
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] = part[threadIdx.x] > part[threadIdx.x + s] ? part[threadIdx.x] : part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
+// D[i][j] = distance between rows i and j of X (N x N) * scale, scale = 1 / *inv_scale_src when given (EMD / EMD.max()).
+// metric 0: Euclidean, accumulated as sum (x_ik - x_jk)^2 (no Gram cancellation, matches scipy cdist);
+// metric 1: cosine, 1 - x.y / (|x| |y|), clipped to [0, 2], exact 0 on the diagonal (sklearn cosine_distances).
+// One 16 x 16 output tile per 256-thread workgroup, k swept through LDS in chunks of 32.
+constexpr int RD_TILE = 16, RD_KC = 32;
+static __global__ void __launch_bounds__(RD_TILE * RD_TILE)
+row_distance_kernel(const double *__restrict__ X, int N, int metric, const double *__restrict__ max_src, double *__restrict__ D) {
+    __shared__ double A[RD_TILE][RD_KC + 1], B[RD_TILE][RD_KC + 1];
+    const int ti = threadIdx.x / RD_TILE, tj = threadIdx.x % RD_TILE;
+    const int i0 = blockIdx.y * RD_TILE, j0 = blockIdx.x * RD_TILE;
+    const double scale = max_src ? 1.0 / max_src[0] : 1.0;
+    double acc = 0.0, na = 0.0, nb = 0.0;
+    for (int k0 = 0; k0 < N; k0 += RD_KC) {
+        for (int t = threadIdx.x; t < RD_TILE * RD_KC; t += RD_TILE * RD_TILE) {
+            const int r = t / RD_KC, k = t % RD_KC;
+            A[r][k] = (i0 + r < N && k0 + k < N) ? X[(size_t)(i0 + r) * N + k0 + k] * scale : 0.0;
+            B[r][k] = (j0 + r < N && k0 + k < N) ? X[(size_t)(j0 + r) * N + k0 + k] * scale : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < RD_KC; ++k) {
+            const double a = A[ti][k], b = B[tj][k];
+            if (metric == 0) { const double d = a - b; acc += d * d; }
+            else { acc += a * b; na += a * a; nb += b * b; }
+        }
+        __syncthreads();
+    }
+    const int i = i0 + ti, j = j0 + tj;
+    if (i < N && j < N) {
+        double out;
+        if (metric == 0) out = sqrt(acc);
+        else {
+            out = 1.0 - acc / (sqrt(na) * sqrt(nb));
+            out = out < 0.0 ? 0.0 : (out > 2.0 ? 2.0 : out);
+        }
+        D[(size_t)i * N + j] = i == j ? 0.0 : out;
+    }
+}
+
+// sklearn.metrics.silhouette_samples on a precomputed distance matrix: for sample i, a = mean distance to the other members
+// of its cluster, b = smallest mean distance to another cluster, s = (b - a) / max(a, b), 0 for a singleton cluster.
+// One workgroup per sample; per-cluster sums in LDS (n_clusters <= 4096).  s_out[i] = s_i; the host averages.
+static __global__ void silhouette_kernel(const double *__restrict__ D, const int *__restrict__ labels, const int *__restrict__ sizes,
+                                         int N, int C, double *__restrict__ s_out) {
+    extern __shared__ double csum[];          // C per-cluster distance sums
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) csum[c] = 0.0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += blockDim.x) atomicAdd(&csum[labels[j]], D[(size_t)i * N + j]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int li = labels[i];
+        double s = 0.0;
+        if (sizes[li] > 1) {
+            const double a = csum[li] / (sizes[li] - 1);
+            double b = __builtin_inf();
+            for (int c = 0; c < C; ++c)
+                if (c != li && sizes[c] > 0) { const double m = csum[c] / sizes[c]; b = m < b ? m : b; }
+            const double mx = a > b ? a : b;
+            s = mx > 0.0 ? (b - a) / mx : 0.0;
+        }
+        s_out[i] = s;
+    }
+}
+
+// Row i of the k-nearest-neighbour Gaussian kernel: Kmat[i][j] = exp(-D[i][j]^2 / (4 epsilon)) for the k smallest D[i][.]
+// (the point itself, at distance 0, counts as its own first neighbour, as in sklearn's kneighbors_graph on the fitted
+// data), 0 elsewhere.  One workgroup per row: the k-th smallest value by a bitonic sort of the row in LDS.
+static __global__ void knn_kernel_kernel(const double *__restrict__ D, int N, int NP2, int k, double epsilon, double *__restrict__ Kmat) {
+    extern __shared__ double srt[];           // NP2 (next power of two >= N), padded with +inf
+    const int i = blockIdx.x;
+    for (int t = threadIdx.x; t < NP2; t += blockDim.x) srt[t] = t < N ? D[(size_t)i * N + t] : __builtin_inf();
+    __syncthreads();
+    for (int size = 2; size <= NP2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < NP2 / 2; t += blockDim.x) {
+                const int lo = (t / stride) * 2 * stride + t % stride, hi = lo + stride;
+                const bool up = ((lo / size) & 1) == 0;
+                const double a = srt[lo], b = srt[hi];
+                if ((a > b) == up) { srt[lo] = b; srt[hi] = a; }
+            }
+            __syncthreads();
+        }
+    const double thr = srt[k - 1 < N ? k - 1 : N - 1];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const double d = D[(size_t)i * N + j];
+        Kmat[(size_t)i * N + j] = d <= thr ? exp(-d * d / (4.0 * epsilon)) : 0.0;
+    }
+}
+
+}  // namespace pilot

@@ -318,6 +318,17 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     return PILOT_OT_OK;
 }
 
+// The kernels iterate TOTAL scalings against the fixed Gibbs image exp(-M/reg) (POT's log-absorption is value-neutral and
+// only its bookkeeping is tracked), so max(M)/reg must stay inside the exponent range of the widest type: beyond ~600 an
+// f64 Gibbs entry underflows / a total scaling overflows where POT's absorbed kernel would not.  Refused, not emulated.
+constexpr double MAX_COST_OVER_REG = 600.0;
+int check_reg_range(double max_cost_over_reg) {
+    if (max_cost_over_reg > MAX_COST_OVER_REG)
+        return fail(PILOT_OT_ENOTSUP, "max(M)/reg = %g > %g: exp(-M/reg) leaves the f64 range (use a larger reg or rescale M)",
+                    max_cost_over_reg, MAX_COST_OVER_REG);
+    return PILOT_OT_OK;
+}
+
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
 int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split) {
     if (split) return RT <= 6 ? 2 : 1;
@@ -521,6 +532,8 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     int rc = check_grid_args(pl->N, pl->K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin,
                              row_end, row_step);
     if (rc != PILOT_OT_OK) return rc;
+    rc = check_reg_range(1.0 / reg);        // M is /max (Trajectory.py:101): device-resident callers keep that convention
+    if (rc != PILOT_OT_OK) return rc;
     bool mixed = false;
     if (precision == PILOT_OT_PREC_AUTO) {
         precision = pilot_ot_auto_precision_for(1.0 / reg, pl->K, cost_is_symmetric);  // M is /max (Trajectory.py:101)
@@ -653,9 +666,11 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     int rc = check_grid_args(N, K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin, row_end,
                              row_step);
     if (rc != PILOT_OT_OK) return rc;
+    double mx = 0.0;
+    for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
+    rc = check_reg_range(mx / reg);
+    if (rc != PILOT_OT_OK) return rc;
     if (precision == PILOT_OT_PREC_AUTO) {
-        double mx = 0.0;
-        for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
         precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
         if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
     }

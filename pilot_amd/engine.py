@@ -266,3 +266,46 @@ def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, mode="auto", return_in
     if return_info:
         return emd, dict(n_aug=n_aug)
     return emd
+
+
+# ---- consumers of the finished matrix ------------------------------------------------------------
+def row_distances(E, metric="euclidean", normalize_by_max=False):
+    """Distances between the ROWS of the N x N matrix E (of E / E.max() with ``normalize_by_max``) on the device: the points
+    pilotpy's diffusion map (pilotpy/plot/ploting.py:95-110) and silhouette scores (pilotpy/tools/Trajectory.py:592-612)
+    work with.  metric: "euclidean" (scipy cdist) or "cosine" (sklearn cosine_distances)."""
+    E = _as_f64(E, "E")
+    if E.ndim != 2 or E.shape[0] != E.shape[1]:
+        raise ValueError("E must be square, got %s" % (E.shape,))
+    if metric not in _lib.ROW_METRICS:
+        raise NotImplementedError("row metric %r: the device kernel implements %s" % (metric, sorted(_lib.ROW_METRICS)))
+    D = np.empty_like(E)
+    _lib.check(_lib.load().pilot_ot_row_distances(_lib.dptr(E), E.shape[0], int(bool(normalize_by_max)),
+                                                  _lib.ROW_METRICS[metric], _lib.dptr(D)))
+    return D
+
+
+def silhouette_precomputed(D, labels, return_samples=False):
+    """``sklearn.metrics.silhouette_score(D, labels, metric="precomputed")`` on the device (labels of any hashable type)."""
+    D = _as_f64(D, "D")
+    if D.ndim != 2 or D.shape[0] != D.shape[1]:
+        raise ValueError("D must be square, got %s" % (D.shape,))
+    uniq, codes = np.unique(np.asarray(labels), return_inverse=True)
+    if codes.shape != (D.shape[0],):
+        raise ValueError("one label per sample expected")
+    codes = np.ascontiguousarray(codes, dtype=np.int32)
+    score = ctypes.c_double(0.0)
+    samples = np.empty(D.shape[0], dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_silhouette(_lib.dptr(D), _lib.iptr(codes), D.shape[0], len(uniq), ctypes.byref(score),
+                                               _lib.dptr(samples)))
+    return (score.value, samples) if return_samples else score.value
+
+
+def knn_gaussian_kernel(D, k=64, epsilon=1.0):
+    """Kernel matrix of pydiffmap's ``DiffusionMap.from_sklearn(epsilon=, k=)`` from row distances D: exp(-d^2 / (4 eps)) on
+    every row's k nearest rows (itself included), 0 elsewhere (pilotpy/plot/ploting.py:109-110)."""
+    D = _as_f64(D, "D")
+    if D.ndim != 2 or D.shape[0] != D.shape[1]:
+        raise ValueError("D must be square, got %s" % (D.shape,))
+    Kmat = np.empty_like(D)
+    _lib.check(_lib.load().pilot_ot_knn_kernel(_lib.dptr(D), D.shape[0], int(k), float(epsilon), _lib.dptr(Kmat)))
+    return Kmat

@@ -16,7 +16,9 @@ Cluster_Representations                        Trajectory.py:377-436
 cost_matrix                                    Trajectory.py:441-475
 wasserstein_d                                  Trajectory.py:479-523
 return_real_labels                             Trajectory.py:617-642
+Sil_computing                                  Trajectory.py:592-612
 Precomputed_distance                           Trajectory.py:1687-1727
+diffusion_kernel                               plot/ploting.py:95-110 (the dense part of pl.trajectory)
 =============================================  ==========================================
 """
 from __future__ import annotations
@@ -168,6 +170,22 @@ def return_real_labels(df, category="status", sample_col=1):
     uniq, first = np.unique(scodes[idx], return_index=True)
     first_row[uniq] = idx[first]
     return [cond[r] for r in first_row]
+
+
+def Sil_computing(EMD, real_labels, metric="cosine"):
+    """Silhouette score of a labelling of the samples, the rows of ``EMD`` being the points (Trajectory.py:592-612:
+    ``sklearn.metrics.silhouette_score(EMD, real_labels, metric=metric)``; callers pass ``EMD / EMD.max()``,
+    plot/ploting.py:324).  Row-to-row distances and the score are computed on the device; metric "cosine" or "euclidean"."""
+    D = engine.row_distances(EMD, metric=metric)
+    return engine.silhouette_precomputed(D, real_labels)
+
+
+def diffusion_kernel(adata, epsilon=1, knn=64):
+    """The dense part of ``pl.trajectory`` (plot/ploting.py:95-110): ``EMD / EMD.max()``, Euclidean distances between its
+    rows, and pydiffmap's k-nearest-neighbour Gaussian kernel ``exp(-d^2 / (4 epsilon))``, all on the device.  Returns
+    ``(EMD_normalised_row_distances, kernel_matrix)``; the eigen-decomposition stays with pydiffmap / scipy."""
+    D = engine.row_distances(adata.uns["EMD"], metric="euclidean", normalize_by_max=True)
+    return D, engine.knn_gaussian_kernel(D, k=knn, epsilon=epsilon)
 
 
 def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", sample_col="sampleID",

@@ -65,7 +65,7 @@ def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle):
         assert np.abs(Eg - Eo)[f64].max() <= 1e-9
     # one exponent band alone is NOT enough here (what the second band is for)
     E1 = engine.sinkhorn_grid(P, M, 0.01, precision="bf16x3", **rows)
-    assert np.abs(E1 - Eo)[~last_o].max() > 10 * TOL32
+    assert np.abs(E1 - Eo)[~last_o].max() > 5 * TOL32
 
 
 def test_c3_reg001_twenty_rows_f32(c3_small_reg_oracle):
