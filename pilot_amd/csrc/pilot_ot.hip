@@ -844,8 +844,8 @@ template <typename T>
 int centroid_medians_impl(const void *X, long long C, int D, const int *cell_code, int K, double *centroids) {
     using U = typename pilot::OrderedKey<T>::U;
     using State = pilot::SelectState<U>;
-    const size_t lds = sizeof(unsigned int) * (size_t)D * 2 * 256;
-    if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "D=%d embedding dimensions need %zu B of LDS (> %zu)", D, lds, LDS_BYTES);
+    const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;      // dimensions per histogram launch
+    const size_t lds = sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
     DevBuf dX, dc, dn, doffs, dcur, dperm, dst, dh, dout;
     hipError_t e = dX.alloc(sizeof(T) * (size_t)C * D);
     if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
@@ -879,9 +879,12 @@ int centroid_medians_impl(const void *X, long long C, int D, const int *cell_cod
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::select_hist_kernel<T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int shift = pilot::OrderedKey<T>::BITS - 8; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)splits, (unsigned)K), dim3(256), lds, nullptr,
-                           static_cast<const T *>(dX.p), D, dperm.as<unsigned int>(), doffs.as<unsigned int>(), shift,
-                           dst.as<State>(), dh.as<unsigned int>());
+        for (int dbeg = 0; dbeg < D; dbeg += Dw_max) {           // any D: the dimensions in windows that fit the LDS histograms
+            const int Dw = D - dbeg < Dw_max ? D - dbeg : Dw_max;
+            hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)splits, (unsigned)K), dim3(256),
+                               sizeof(unsigned int) * (size_t)Dw * 2 * 256, nullptr, static_cast<const T *>(dX.p), D, dbeg, Dw,
+                               dperm.as<unsigned int>(), doffs.as<unsigned int>(), shift, dst.as<State>(), dh.as<unsigned int>());
+        }
         hipLaunchKernelGGL(pilot::select_pick_kernel<T>, dim3((nq + 255) / 256), dim3(256), 0, nullptr, K, D, shift,
                            dst.as<State>(), dh.as<unsigned int>());
     }

@@ -115,18 +115,20 @@ __global__ void select_init_kernel(const unsigned int *__restrict__ n_k, int K, 
 }
 
 // one radix pass (8 bits at `shift`): histogram of the digit over the keys matching each query's prefix.
-// grid = (splits, K); every workgroup sweeps a slice of the rows of type k, all D dimensions at once.
+// grid = (splits, K); every workgroup sweeps a slice of the rows of type k, the dimensions [dbeg, dbeg + Dw) at once
+// (the LDS histograms hold Dw <= SELECT_MAX_DIMS dimensions; wider embeddings take several launches per pass).
+constexpr int SELECT_MAX_DIMS = 64;
 template <typename T>
-__global__ void select_hist_kernel(const T *__restrict__ X, int D, const unsigned int *__restrict__ perm,
+__global__ void select_hist_kernel(const T *__restrict__ X, int D, int dbeg, int Dw, const unsigned int *__restrict__ perm,
                                    const unsigned int *__restrict__ offs, int shift,
                                    const SelectState<typename OrderedKey<T>::U> *__restrict__ st,
                                    unsigned int *__restrict__ hist /* K * D * 2 * 256 */) {
     using OK = OrderedKey<T>;
     using U = typename OK::U;
-    extern __shared__ unsigned int lh[];                   // D * 2 * 256
+    extern __shared__ unsigned int lh[];                   // Dw * 2 * 256
     const int k = blockIdx.y;
     const unsigned int beg = offs[k], end = offs[k + 1];
-    const int nbins = D * 2 * 256;
+    const int nbins = Dw * 2 * 256;
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const U himask = (shift + 8 >= OK::BITS) ? U(0) : (~U(0) << (shift + 8));
@@ -134,22 +136,22 @@ __global__ void select_hist_kernel(const T *__restrict__ X, int D, const unsigne
     const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, nwaves = blockDim.x / 64;
     const unsigned int per = (end - beg + gridDim.x - 1) / gridDim.x;
     const unsigned int r0 = beg + blockIdx.x * per, r1 = (r0 + per < end) ? r0 + per : end;
-    for (int d0 = 0; d0 < D; d0 += 64) {
-        const int d = d0 + lane;
+    for (int d0 = 0; d0 < Dw; d0 += 64) {
+        const int dl = d0 + lane, d = dbeg + dl;
         U p0 = 0, p1 = 0;
-        if (d < D) { p0 = st[(k * D + d) * 2 + 0].prefix; p1 = st[(k * D + d) * 2 + 1].prefix; }
+        if (dl < Dw) { p0 = st[(k * D + d) * 2 + 0].prefix; p1 = st[(k * D + d) * 2 + 1].prefix; }
         for (unsigned int r = r0 + wave; r < r1; r += nwaves) {
             const size_t row = perm[r];
-            if (d < D) {
+            if (dl < Dw) {
                 const U key = OK::enc(X[row * D + d]);
                 const unsigned int digit = (unsigned int)(key >> shift) & 255u;
-                if ((key & himask) == p0) atomicAdd(&lh[((d * 2 + 0) << 8) + digit], 1u);
-                if ((key & himask) == p1) atomicAdd(&lh[((d * 2 + 1) << 8) + digit], 1u);
+                if ((key & himask) == p0) atomicAdd(&lh[((dl * 2 + 0) << 8) + digit], 1u);
+                if ((key & himask) == p1) atomicAdd(&lh[((dl * 2 + 1) << 8) + digit], 1u);
             }
         }
     }
     __syncthreads();
-    unsigned int *gh = hist + (size_t)k * nbins;
+    unsigned int *gh = hist + ((size_t)k * D + dbeg) * 2 * 256;
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) if (lh[i]) atomicAdd(&gh[i], lh[i]);
 }
 

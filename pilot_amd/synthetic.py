@@ -91,7 +91,8 @@ def make_problem(n_patients, n_types, n_dims, seed, cells_per_patient=3000, regu
     M = 0.5 * (M + M.T)
     np.fill_diagonal(M, 0.0)
     M = np.clip(M, 0.0, 2.0)
-    return np.ascontiguousarray(P), np.ascontiguousarray(M / M.max())
+    mx = M.max()
+    return np.ascontiguousarray(P), np.ascontiguousarray(M / mx if mx > 0 else M)       # (K = 1: the single zero stays)
 
 
 def make_cell_clouds(n_patients, cells_per_patient, n_dims, seed, n_types=20):

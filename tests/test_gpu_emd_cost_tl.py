@@ -130,7 +130,7 @@ def test_proportions_kernel_large_and_ragged():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("C,D,K", [(1, 1, 1), (7, 3, 2), (1000, 30, 50), (4097, 65, 3), (200_000, 30, 50)])
+@pytest.mark.parametrize("C,D,K", [(1, 1, 1), (7, 3, 2), (1000, 30, 50), (4097, 65, 3), (3000, 150, 4), (500, 400, 2), (200_000, 30, 50)])
 def test_centroid_medians_exact(dtype, C, D, K):
     rng = np.random.default_rng(C + D + K)
     X = (rng.standard_normal((C, D)) * 10).astype(dtype)
