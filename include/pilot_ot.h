@@ -69,6 +69,11 @@ extern "C" {
 #define PILOT_OT_METRIC_CITYBLOCK 3
 #define PILOT_OT_METRIC_CHEBYSHEV 4
 #define PILOT_OT_METRIC_CORRELATION 5
+#define PILOT_OT_METRIC_MINKOWSKI 6   /* p = 2, scipy's default (the reference forwards only the metric name) */
+#define PILOT_OT_METRIC_SEUCLIDEAN 7  /* V = per-dimension variance of the centroids, ddof = 1 (scipy's default) */
+#define PILOT_OT_METRIC_BRAYCURTIS 8
+#define PILOT_OT_METRIC_CANBERRA 9
+#define PILOT_OT_METRIC_HAMMING 10
 
 /* ---- library / device --------------------------------------------------------------------- */
 int pilot_ot_version(void);
@@ -242,6 +247,19 @@ int pilot_ot_knn_kernel(const double *D, int N, int k, double epsilon, double *K
 int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D, double scale, double reg,
                           int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
                           int row_begin, int row_end, int row_step, double *w2, int *iters, double *err);
+/* Device-resident form: a cohort keeps the cells (as bf16 operand pieces) in HBM across calls, so a call moves only the
+ * result rows.  kernel_ms (nullable): HIP-event time of the pair-grid kernel of this call. */
+typedef struct pilot_ot_cell_cohort pilot_ot_cell_cohort;
+int pilot_ot_cell_cohort_create(const float *X, const long long *offsets, int N, int D, pilot_ot_cell_cohort **cohort);
+int pilot_ot_cell_cohort_destroy(pilot_ot_cell_cohort *cohort);
+int pilot_ot_cell_w2_grid_cohort(pilot_ot_cell_cohort *cohort, double scale, double reg, int num_iter_max, double stop_thr,
+                                 int check_period, double f32_floor_ulps, int row_begin, int row_end, int row_step,
+                                 double *w2, int *iters, double *err, float *kernel_ms);
+/* Full N x N grid, rows dealt round-robin over the listed devices (every device holds the cohort; the shards run
+ * concurrently; the result rows are assembled on the host -- there is no device-side exchange step to make). */
+int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offsets, int N, int D, double scale, double reg,
+                                int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
+                                const int *devices, int n_devices, double *w2, int *iters, double *err);
 
 /* precision selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (PILOT_OT_PREC_BF16X3 or PILOT_OT_PREC_F64; a shape whose
  * split operand image does not fit LDS runs PILOT_OT_PREC_F32 instead) */

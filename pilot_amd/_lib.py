@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libpilot_ot.so")
 
 OK, EINVAL, EHIP, ENOTSUP, ERCCL = 0, -1, -2, -3, -4
 PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2, "bf16x3": 3}
-METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5}
+METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5,
+           "minkowski": 6, "seuclidean": 7, "braycurtis": 8, "canberra": 9, "hamming": 10}
 
 EMD_ALL, EMD_UPPER, EMD_MIRROR = 0, 1, 2
 FLAG_CONVERGED, FLAG_NAN, FLAG_ABSORB_LAST, FLAG_ABSORBED, FLAG_F64 = 1, 2, 4, 8, 16
@@ -29,6 +30,7 @@ SYMBOLS = [
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_centroid_medians", "pilot_ot_cell_w2_grid",
+    "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
     "pilot_ot_mirror_upper_dev",
     "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
     "pilot_ot_multi_create", "pilot_ot_multi_destroy", "pilot_ot_multi_set_inputs", "pilot_ot_multi_sinkhorn",
@@ -87,6 +89,11 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_centroid_medians.argtypes = [c_vp, c_int, ctypes.c_longlong, c_int, ip, c_int, dp]
     L.pilot_ot_cell_w2_grid.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, c_int, c_int, c_int,
                                         dp, ip, dp]
+    L.pilot_ot_cell_cohort_create.argtypes = [c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_cell_cohort_destroy.argtypes = [c_vp]
+    L.pilot_ot_cell_w2_grid_cohort.argtypes = [c_vp, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, c_int, c_int, c_int, dp, ip, dp,
+                                               ctypes.POINTER(ctypes.c_float)]
+    L.pilot_ot_cell_w2_grid_multi.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, ip, c_int, dp, ip, dp]
     L.pilot_ot_emd_grid.argtypes = [dp, c_int, c_int, dp, c_int, c_int, c_int, c_int, dp, ip]
     L.pilot_ot_emd_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]
     fp = ctypes.POINTER(ctypes.c_float)

@@ -7,10 +7,15 @@
 // With alpha = 1/(scale*eps) and the shifted potentials hu_i = u_i - alpha|x_i|^2, hv_j = v_j - alpha|y_j|^2 both
 // updates are the same "flash" pass   out_r = LSE_c( 2 alpha <A_r, B_c> + h_c ):   hv = log b - out(A=Y, B=X, h=hu),
 // hu = log a - out(A=X, B=Y, h=hv).  The n_p x n_q cost matrix (100 MB at 5000 cells) is never materialised: 16 x 16
-// tiles of dot products come from v_mfma_f32_16x16x4_f32 (points pre-arranged in operand order), the log-sum-exp is
-// kept online per lane (running max + rescaled sum, base 2 so v_exp_f32 / v_log_f32 are used directly) and reduced
-// across the 16 lanes of a row with DPP at the end of a row block.  One workgroup (4 waves) per pair; the potentials
-// of the pair live in LDS.
+// tiles of dot products are recomputed every half-update on the matrix pipe, the log-sum-exp is kept online per lane
+// (running max + rescaled sum, base 2 so v_exp_f32 / v_log_f32 are used directly) and reduced across the 16 lanes of a
+// row with DPP at the end of a row block.  One workgroup (16 waves) per pair; the potentials of the pair live in LDS.
+//
+// Dot products: the exponent 2 alpha <x, y> + h needs f32-level absolute accuracy, but both operands are STATIC (the
+// cells), so each coordinate is split ONCE by the setup kernel into three bf16 pieces (x = x1 + x2 + x3 exactly) and a
+// 16 x 16 x 32 tile is six v_mfma_f32_16x16x32_bf16 (x1y1 + x1y2 + x2y1 + x2y2 + x1y3 + x3y1, f32 accumulation: terms of
+// order 2^-24 dropped) = 96 matrix-pipe cycles instead of the 8 x 32 = 256 of the f32-input MFMA it replaces -- and the
+// bf16 pipe leaves the vector unit free for the exponentials.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,7 +26,7 @@ constexpr int CELL_WG = 1024;   // 16 waves share one pair: the self-pairs conve
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 
 struct CellParams {
-    const float *Xs;        // C x (4*DS) points in MFMA operand order: Xs[c][g*DS + s] = X[c][4*s + g], zero padded
+    const uint4 *Xb;        // C x KB x 3 x 4 pieces of 16 bytes: Xb[((c*KB + kb)*3 + piece)*4 + g] = bf16 piece of X[c][32 kb + 8 g .. + 7]
     const float *nrm;       // C: |x_c|^2
     const long long *offs;  // N + 1: first cell of every patient
     int N;
@@ -38,20 +43,54 @@ struct CellParams {
     int *queue;             // dynamic pair queue
 };
 
-// one pre-pass over the cells: operand-ordered copy + squared norms
-__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int DS, float *__restrict__ Xs,
+// one pre-pass over the cells: the three bf16 pieces of every coordinate in MFMA operand order + squared norms
+__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, unsigned short *__restrict__ Xb,
                                   float *__restrict__ nrm) {
-    const int W = 4 * DS;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * W; idx += (long)gridDim.x * blockDim.x) {
-        const long c = idx / W;
-        const int o = (int)(idx % W), g = o / DS, s = o % DS, d = 4 * s + g;
-        Xs[idx] = d < D ? X[c * D + d] : 0.f;
+    const long per = (long)KB * 3 * 32;            // bf16 values per cell
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * KB * 32; idx += (long)gridDim.x * blockDim.x) {
+        const long c = idx / (KB * 32);
+        const int o = (int)(idx % (KB * 32)), kb = o / 32, d = o;      // coordinate d sits in k-block d / 32, slot d % 32
+        float x = d < D ? X[c * D + d] : 0.f;
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            const unsigned short hb = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
+            Xb[c * per + ((long)kb * 3 + piece) * 32 + (o % 32)] = hb;
+            x -= __uint_as_float((unsigned int)hb << 16);
+        }
     }
     for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int d = 0; d < D; ++d) s += X[c * D + d] * X[c * D + d];
         nrm[c] = s;
     }
+}
+
+using cell_bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using cell_f4 = float __attribute__((ext_vector_type(4)));
+// the lane's operand pieces of one point: p[kb][piece] = 8 bf16 (k-slots 8 g .. 8 g + 7 of k-block kb)
+template <int KB> struct CellOperand { uint4 p[KB][3]; };
+template <int KB> __device__ inline void cell_load(const uint4 *__restrict__ Xb, long point, int g, CellOperand<KB> &o) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) o.p[kb][piece] = Xb[((point * KB + kb) * 3 + piece) * 4 + g];
+}
+// 16 x 16 tile of <A_row, B_col>: six bf16 MFMAs per k-block, smallest terms first
+template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB> &a, const CellOperand<KB> &b) {
+    cell_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto mm = [](const uint4 &x, const uint4 &y, cell_f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cell_bf16x8, x), __builtin_bit_cast(cell_bf16x8, y), c, 0, 0, 0);
+    };
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        acc = mm(a.p[kb][2], b.p[kb][0], acc);
+        acc = mm(a.p[kb][0], b.p[kb][2], acc);
+        acc = mm(a.p[kb][1], b.p[kb][1], acc);
+        acc = mm(a.p[kb][1], b.p[kb][0], acc);
+        acc = mm(a.p[kb][0], b.p[kb][1], acc);
+        acc = mm(a.p[kb][0], b.p[kb][0], acc);
+    }
+    return acc;
 }
 
 template <int CTRL> __device__ inline float dpp_f32(float x) {
@@ -79,19 +118,17 @@ __device__ inline float row16_sum(float x) {
 
 // out2[r] = log2 sum_c 2^( two_alpha2 * <A_r, B_c> + h2[c] )  for every row r of the A side  (base-2 LSE)
 // FN(row, lse2) is called by one lane per row with the result.
-template <int DS, class FN>
-__device__ inline void lse_pass(const float *__restrict__ As, int na, const float *__restrict__ Bs, int nb,
+template <int KB, class FN>
+__device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, long b0, int nb,
                                 const float *h2 /* LDS, nb */, float two_alpha2, int wave, int n_waves, int lane, FN &&fn) {
-    using f4 = float __attribute__((ext_vector_type(4)));
+    using f4 = cell_f4;
     const int col = lane & 15, g = lane >> 4;
-    constexpr int TB = DS >= 16 ? 2 : 4;
+    constexpr int TB = KB >= 2 ? 2 : 4;
     for (int blk = wave; blk * 16 < na; blk += n_waves) {
         int arow = blk * 16 + col;                        // A operand: lane holds row (lane & 15), k-slots of group g
         if (arow >= na) arow = na - 1;
-        float a[DS];
-        const float *ap = As + (size_t)arow * (4 * DS) + g * DS;
-#pragma unroll
-        for (int s = 0; s < DS; ++s) a[s] = ap[s];
+        CellOperand<KB> a;
+        cell_load<KB>(Xb, a0 + arow, g, a);
         float m[4], l[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { m[r] = CELL_NEG_BIG; l[r] = 0.f; }
@@ -104,14 +141,10 @@ __device__ inline void lse_pass(const float *__restrict__ As, int na, const floa
                 int bcol = (tb + u) * 16 + col;
                 const bool okc = bcol < nb;
                 if (!okc) bcol = nb - 1;
-                const float *bp = Bs + (size_t)bcol * (4 * DS) + g * DS;
-                float b[DS];
-#pragma unroll
-                for (int s = 0; s < DS; ++s) b[s] = bp[s];
+                CellOperand<KB> b;
+                cell_load<KB>(Xb, b0 + bcol, g, b);
                 h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
-                acc[u] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < DS; ++s) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc[u], 0, 0, 0);
+                acc[u] = cell_dot_tile<KB>(a, b);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                 // acc[u][r] = <A_{4g+r}, B_col(u)>
@@ -135,21 +168,19 @@ __device__ inline void lse_pass(const float *__restrict__ As, int na, const floa
 }
 
 // sum_ij 2^(two_alpha2 <x_i, y_j> + hu2_i + hv2_j) * C_ij  for the rows handled by this wave (lane-local partial)
-template <int DS>
-__device__ inline float value_pass(const float *__restrict__ As, const float *__restrict__ na2, int na,
-                                   const float *__restrict__ Bs, const float *__restrict__ nb2, int nb,
+template <int KB>
+__device__ inline float value_pass(const uint4 *__restrict__ Xb, long a0, const float *__restrict__ na2, int na,
+                                   long b0, const float *__restrict__ nb2, int nb,
                                    const float *hA2, const float *hB2, float two_alpha2, float inv_scale, int wave,
                                    int n_waves, int lane) {
-    using f4 = float __attribute__((ext_vector_type(4)));
+    using f4 = cell_f4;
     const int col = lane & 15, g = lane >> 4;
     float total = 0.f;
     for (int blk = wave; blk * 16 < na; blk += n_waves) {
         int arow = blk * 16 + col;
         if (arow >= na) arow = na - 1;
-        float a[DS];
-        const float *ap = As + (size_t)arow * (4 * DS) + g * DS;
-#pragma unroll
-        for (int s = 0; s < DS; ++s) a[s] = ap[s];
+        CellOperand<KB> a;
+        cell_load<KB>(Xb, a0 + arow, g, a);
         float hr[4], nr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -162,15 +193,11 @@ __device__ inline float value_pass(const float *__restrict__ As, const float *__
             int bcol = tb * 16 + col;
             const bool okc = bcol < nb;
             if (!okc) bcol = nb - 1;
-            const float *bp = Bs + (size_t)bcol * (4 * DS) + g * DS;
-            float b[DS];
-#pragma unroll
-            for (int s = 0; s < DS; ++s) b[s] = bp[s];
+            CellOperand<KB> b;
+            cell_load<KB>(Xb, b0 + bcol, g, b);
             const float h = okc ? hB2[bcol] : CELL_NEG_BIG;
             const float nc = nb2[bcol];
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < DS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+            const f4 acc = cell_dot_tile<KB>(a, b);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float wgt = __builtin_amdgcn_exp2f(fmaf(acc[r], two_alpha2, h) + hr[r]);   // Gamma_ij
@@ -182,7 +209,7 @@ __device__ inline float value_pass(const float *__restrict__ As, const float *__
     return total;
 }
 
-template <int DS>
+template <int KB>
 __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *hu = reinterpret_cast<float *>(smem_raw);        // [max_n] shifted potentials of the row patient (base 2)
@@ -212,7 +239,6 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
         const long out = (long)r_idx * p.N + j;
         const long o_p = p.offs[i], o_q = p.offs[j];
         const int np = (int)(p.offs[i + 1] - o_p), nq = (int)(p.offs[j + 1] - o_q);
-        const float *Xp = p.Xs + (size_t)o_p * (4 * DS), *Yq = p.Xs + (size_t)o_q * (4 * DS);
         const float *nxp = p.nrm + o_p, *nyq = p.nrm + o_q;
         const float loga2 = -__builtin_amdgcn_logf((float)np), logb2 = -__builtin_amdgcn_logf((float)nq);
         const float bval = 1.f / (float)nq;
@@ -236,7 +262,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             //      after update ii-1 comes for free; if it stops the pair, (hu, hv_old) is exactly the plan POT returns.
             const bool check = ii > 0 && ((ii - 1) % p.period == 0);
             float e2 = 0.f;
-            lse_pass<DS>(Yq, nq, Xp, np, hu, p.two_alpha2, wave, n_waves, lane, [&](int row, float lse2) {
+            lse_pass<KB>(p.Xb, o_q, nq, o_p, np, hu, p.two_alpha2, wave, n_waves, lane, [&](int row, float lse2) {
                 if (check) {
                     const float d = __builtin_amdgcn_exp2f(hv_cur[row] + lse2) - bval;
                     e2 = fmaf(d, d, e2);
@@ -259,13 +285,13 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             }
             { float *t = hv_cur; hv_cur = hv_new; hv_new = t; }
             // ---- u-update:  hu_i = log a - LSE_j(2 alpha <x_i, y_j> + hv_j) -------------------------------------------
-            lse_pass<DS>(Xp, np, Yq, nq, hv_cur, p.two_alpha2, wave, n_waves, lane,
+            lse_pass<KB>(p.Xb, o_p, np, o_q, nq, hv_cur, p.two_alpha2, wave, n_waves, lane,
                          [&](int row, float lse2) { hu[row] = loga2 - lse2; });
             __syncthreads();
             iters = ii + 1;
         }
         // ---- value <Gamma, C> ---------------------------------------------------------------------------------------
-        float part = value_pass<DS>(Xp, nxp, np, Yq, nyq, nq, hu, hv_cur, p.two_alpha2, p.inv_scale, wave, n_waves, lane);
+        float part = value_pass<KB>(p.Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.two_alpha2, p.inv_scale, wave, n_waves, lane);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) red[16 + wave] = part;

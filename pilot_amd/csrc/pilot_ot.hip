@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "abi_common.hpp"
 #include "sinkhorn_launch.hpp"
@@ -41,8 +42,17 @@ namespace {
 // size where an MFMA contraction pays (K*K*D = 75k FMAs at c3).
 __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, int metric,
                                    double *__restrict__ C) {
-    extern __shared__ double stat[];  // per-row norm (cosine) or mean + centred norm (correlation)
-    double *nrm = stat, *mean = stat + K;
+    extern __shared__ double stat[];  // per-row norm (cosine) or mean + centred norm (correlation); per-dimension variance (seuclidean)
+    double *nrm = stat, *mean = stat + K, *var = stat + 2 * K;
+    if (metric == PILOT_OT_METRIC_SEUCLIDEAN)       // scipy: V = np.var(X, axis=0, ddof=1)
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            double m = 0.0;
+            for (int i = 0; i < K; ++i) m += X[(size_t)i * D + d];
+            m /= K;
+            double s = 0.0;
+            for (int i = 0; i < K; ++i) { const double t = X[(size_t)i * D + d] - m; s += t * t; }
+            var[d] = s / (K - 1);
+        }
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         const double *x = X + (size_t)i * D;
         double m = 0.0;
@@ -77,10 +87,38 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
             break;
         }
         case PILOT_OT_METRIC_EUCLIDEAN:
+        case PILOT_OT_METRIC_MINKOWSKI:          // scipy's default p = 2 (the reference forwards only the name)
         case PILOT_OT_METRIC_SQEUCLIDEAN: {
             double s = 0.0;
             for (int d = 0; d < D; ++d) { const double t = u[d] - v[d]; s += t * t; }
-            out = metric == PILOT_OT_METRIC_EUCLIDEAN ? sqrt(s) : s;
+            out = metric == PILOT_OT_METRIC_SQEUCLIDEAN ? s : sqrt(s);
+            break;
+        }
+        case PILOT_OT_METRIC_SEUCLIDEAN: {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) { const double t = u[d] - v[d]; s += t * t / var[d]; }
+            out = sqrt(s);
+            break;
+        }
+        case PILOT_OT_METRIC_BRAYCURTIS: {
+            double s1 = 0.0, s2 = 0.0;
+            for (int d = 0; d < D; ++d) { s1 += fabs(u[d] - v[d]); s2 += fabs(u[d] + v[d]); }
+            out = s1 / s2;
+            break;
+        }
+        case PILOT_OT_METRIC_CANBERRA: {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double den = fabs(u[d]) + fabs(v[d]);
+                if (den > 0.0) s += fabs(u[d] - v[d]) / den;          // 0/0 terms count as 0
+            }
+            out = s;
+            break;
+        }
+        case PILOT_OT_METRIC_HAMMING: {
+            int ne = 0;
+            for (int d = 0; d < D; ++d) ne += u[d] != v[d];
+            out = double(ne) / D;
             break;
         }
         case PILOT_OT_METRIC_CITYBLOCK: {
@@ -194,10 +232,10 @@ PILOT_API int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, 
                                        void *stream) {
     if (!d_centroids || !d_cost) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (K <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "K=%d D=%d must be positive", K, D);
-    if (metric < PILOT_OT_METRIC_COSINE || metric > PILOT_OT_METRIC_CORRELATION)
+    if (metric < PILOT_OT_METRIC_COSINE || metric > PILOT_OT_METRIC_HAMMING)
         return fail(PILOT_OT_EINVAL, "unknown metric id %d", metric);
-    if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 centroids", K);
-    hipLaunchKernelGGL(cost_matrix_kernel, dim3(1), dim3(1024), 2 * sizeof(double) * K,
+    if (K > 4096 || D > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d D=%d: at most 4096 centroids / dimensions", K, D);
+    hipLaunchKernelGGL(cost_matrix_kernel, dim3(1), dim3(1024), sizeof(double) * (2 * K + D),
                        static_cast<hipStream_t>(stream), d_centroids, K, D, metric, d_cost);
     HIP_TRY(hipGetLastError());
     return PILOT_OT_OK;
@@ -908,16 +946,35 @@ PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_ce
 
 // ------------------------------------------------------------------------------------------------
 // cell-level W2 (extension)
-PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D, double scale, double reg,
-                                    int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
-                                    int row_begin, int row_end, int row_step, double *w2, int *iters, double *err) {
-    if (!X || !offsets || !w2) return fail(PILOT_OT_EINVAL, "NULL pointer");
+struct pilot_ot_cell_cohort {
+    int N = 0, D = 0, KB = 1, device = 0, n_cu = 256;
+    long long C = 0, max_n = 0;
+    uint4 *dXb = nullptr;          // bf16 operand pieces of every cell (resident)
+    float *dnrm = nullptr;
+    long long *doffs = nullptr;
+    // per-call outputs / queue, grown on demand
+    double *dW = nullptr, *dErr = nullptr;
+    int *dIt = nullptr, *dQ = nullptr;
+    size_t n_out = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+PILOT_API int pilot_ot_cell_cohort_destroy(pilot_ot_cell_cohort *c) {
+    if (!c) return PILOT_OT_OK;
+    for (void *p : {(void *)c->dXb, (void *)c->dnrm, (void *)c->doffs, (void *)c->dW, (void *)c->dErr, (void *)c->dIt, (void *)c->dQ})
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offsets, int N, int D, pilot_ot_cell_cohort **cohort) {
+    if (!X || !offsets || !cohort) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (N <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "N=%d D=%d must be positive", N, D);
     if (D > 64) return fail(PILOT_OT_ENOTSUP, "D=%d > 64 embedding dimensions", D);
-    if (!(scale > 0.0) || !(reg > 0.0)) return fail(PILOT_OT_EINVAL, "scale=%g reg=%g must be positive", scale, reg);
-    if (num_iter_max < 1 || check_period < 1) return fail(PILOT_OT_EINVAL, "num_iter_max / check_period must be >= 1");
-    if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
-        return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
     long long max_n = 0;
     for (int i = 0; i < N; ++i) {
         const long long n = offsets[i + 1] - offsets[i];
@@ -926,31 +983,59 @@ PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, in
     }
     const size_t lds = sizeof(float) * (3 * (size_t)max_n + 48);
     if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "a patient with %lld cells needs %zu B of LDS (> %zu)", max_n, lds, LDS_BYTES);
-    const long long C = offsets[N];
-    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
-    const size_t n_out = (size_t)n_rows * N;
-    if (n_out == 0) return PILOT_OT_OK;
-    const int DS = D <= 16 ? 4 : (D <= 32 ? 8 : 16);
-    if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
+    pilot_ot_cell_cohort *c = new (std::nothrow) pilot_ot_cell_cohort();
+    if (!c) return fail(PILOT_OT_EINVAL, "out of host memory");
+    c->N = N; c->D = D; c->KB = D <= 32 ? 1 : 2; c->C = offsets[N]; c->max_n = max_n;
+    c->n_cu = current_cu_count();
+    DevBuf dX;
+    hipError_t e = hipGetDevice(&c->device);
+    if (e == hipSuccess) e = dX.alloc(sizeof(float) * (size_t)c->C * D);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dXb), (size_t)c->C * c->KB * 3 * 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dnrm), sizeof(float) * (size_t)c->C);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->doffs), sizeof(long long) * (size_t)(N + 1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dQ), sizeof(int));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMemcpy(dX.p, X, sizeof(float) * (size_t)c->C * D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->doffs, offsets, sizeof(long long) * (size_t)(N + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, dX.as<float>(),
+                           (long)c->C, D, c->KB, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) { pilot_ot_cell_cohort_destroy(c); return fail(PILOT_OT_EHIP, "cell cohort setup failed: %s", hipGetErrorString(e)); }
+    *cohort = c;
+    return PILOT_OT_OK;
+}
 
-    DevBuf dX, dXs, dnrm, doffs, dW, dIt, dErr, dQ;
-    hipError_t e = dX.alloc(sizeof(float) * (size_t)C * D);
-    if (e == hipSuccess) e = dXs.alloc(sizeof(float) * (size_t)C * 4 * DS);
-    if (e == hipSuccess) e = dnrm.alloc(sizeof(float) * (size_t)C);
-    if (e == hipSuccess) e = doffs.alloc(sizeof(long long) * (size_t)(N + 1));
-    if (e == hipSuccess) e = dW.alloc(sizeof(double) * n_out);
-    if (e == hipSuccess) e = dIt.alloc(sizeof(int) * n_out);
-    if (e == hipSuccess) e = dErr.alloc(sizeof(double) * n_out);
-    if (e == hipSuccess) e = dQ.alloc(sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(dX.p, X, sizeof(float) * (size_t)C * D, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(doffs.p, offsets, sizeof(long long) * (size_t)(N + 1), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(dQ.p, 0, sizeof(int));
-    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
-    const int n_cu = current_cu_count();
-    hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(C * 4 * DS, 256, n_cu)), dim3(256), 0, nullptr, dX.as<float>(), (long)C, D,
-                       DS, dXs.as<float>(), dnrm.as<float>());
+namespace {
+// enqueue one pass over the selected rows on the cohort's stream (asynchronous)
+int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_iter_max, double stop_thr, int check_period,
+                    double f32_floor_ulps, int row_begin, int row_end, int row_step, size_t *n_out_p) {
+    if (!c) return fail(PILOT_OT_EINVAL, "cohort is NULL");
+    if (!(scale > 0.0) || !(reg > 0.0)) return fail(PILOT_OT_EINVAL, "scale=%g reg=%g must be positive", scale, reg);
+    if (num_iter_max < 1 || check_period < 1) return fail(PILOT_OT_EINVAL, "num_iter_max / check_period must be >= 1");
+    if (row_step < 1 || row_begin < 0 || row_end > c->N || row_begin > row_end)
+        return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, c->N);
+    const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
+    const size_t n_out = (size_t)n_rows * c->N;
+    *n_out_p = n_out;
+    if (n_out == 0) return PILOT_OT_OK;
+    if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
+    if (n_out > c->n_out) {
+        for (void *p : {(void *)c->dW, (void *)c->dErr, (void *)c->dIt}) if (p) (void)hipFree(p);
+        c->dW = c->dErr = nullptr; c->dIt = nullptr; c->n_out = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->dW), sizeof(double) * n_out);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dErr), sizeof(double) * n_out);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dIt), sizeof(int) * n_out);
+        if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+        c->n_out = n_out;
+    }
+    HIP_TRY(hipMemsetAsync(c->dQ, 0, sizeof(int), c->stream));
     pilot::CellParams p;
-    p.Xs = dXs.as<float>(); p.nrm = dnrm.as<float>(); p.offs = doffs.as<long long>(); p.N = N;
+    p.Xb = c->dXb; p.nrm = c->dnrm; p.offs = c->doffs; p.N = c->N;
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
     const double alpha = 1.0 / (scale * reg);
     p.alpha = (float)alpha;
@@ -958,28 +1043,100 @@ PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, in
     p.inv_scale = (float)(1.0 / scale);
     p.max_iter = num_iter_max; p.period = check_period;
     p.stop_thr = (float)stop_thr; p.floor_ulps = (float)f32_floor_ulps;
-    p.max_n = (int)max_n;
-    p.w2 = dW.as<double>(); p.iters = dIt.as<int>(); p.err = dErr.as<double>(); p.queue = dQ.as<int>();
+    p.max_n = (int)c->max_n;
+    p.w2 = c->dW; p.iters = c->dIt; p.err = c->dErr; p.queue = c->dQ;
+    const size_t lds = sizeof(float) * (3 * (size_t)c->max_n + 48);
     long wgs = (long)n_out;
     long per_cu = (long)(LDS_BYTES / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    if (wgs > n_cu * per_cu) wgs = n_cu * per_cu;
+    if (wgs > c->n_cu * per_cu) wgs = c->n_cu * per_cu;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
     hipError_t le = hipSuccess;
-#define PILOT_CELL_LAUNCH(DSV)                                                                                     \
-    do {                                                                                                           \
-        le = hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::cell_w2_kernel<DSV>),                       \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        if (le == hipSuccess) hipLaunchKernelGGL(pilot::cell_w2_kernel<DSV>, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, nullptr, p); \
-    } while (0)
-    if (DS == 4) PILOT_CELL_LAUNCH(4);
-    else if (DS == 8) PILOT_CELL_LAUNCH(8);
-    else PILOT_CELL_LAUNCH(16);
-#undef PILOT_CELL_LAUNCH
+    if (c->KB == 1) {
+        le = hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::cell_w2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (le == hipSuccess) hipLaunchKernelGGL(pilot::cell_w2_kernel<1>, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);
+    } else {
+        le = hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::cell_w2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (le == hipSuccess) hipLaunchKernelGGL(pilot::cell_w2_kernel<2>, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);
+    }
     HIP_TRY(le);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(w2, dW.p, sizeof(double) * n_out, hipMemcpyDeviceToHost));
-    if (iters) HIP_TRY(hipMemcpy(iters, dIt.p, sizeof(int) * n_out, hipMemcpyDeviceToHost));
-    if (err) HIP_TRY(hipMemcpy(err, dErr.p, sizeof(double) * n_out, hipMemcpyDeviceToHost));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return PILOT_OT_OK;
+}
+int cell_w2_collect(pilot_ot_cell_cohort *c, size_t n_out, double *w2, int *iters, double *err, float *kernel_ms) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_out == 0) return PILOT_OT_OK;
+    HIP_TRY(hipMemcpy(w2, c->dW, sizeof(double) * n_out, hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(hipMemcpy(iters, c->dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost));
+    if (err) HIP_TRY(hipMemcpy(err, c->dErr, sizeof(double) * n_out, hipMemcpyDeviceToHost));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
+    return PILOT_OT_OK;
+}
+}  // namespace
+
+PILOT_API int pilot_ot_cell_w2_grid_cohort(pilot_ot_cell_cohort *c, double scale, double reg, int num_iter_max, double stop_thr,
+                                           int check_period, double f32_floor_ulps, int row_begin, int row_end, int row_step,
+                                           double *w2, int *iters, double *err, float *kernel_ms) {
+    if (!c || !w2) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != c->device) HIP_TRY(hipSetDevice(c->device));
+    size_t n_out = 0;
+    int rc = cell_w2_enqueue(c, scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, row_begin, row_end, row_step, &n_out);
+    if (rc == PILOT_OT_OK) rc = cell_w2_collect(c, n_out, w2, iters, err, kernel_ms);
+    if (dev != c->device) (void)hipSetDevice(dev);
+    return rc;
+}
+
+PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D, double scale, double reg,
+                                    int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
+                                    int row_begin, int row_end, int row_step, double *w2, int *iters, double *err) {
+    if (!X || !offsets || !w2) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    pilot_ot_cell_cohort *c = nullptr;
+    int rc = pilot_ot_cell_cohort_create(X, offsets, N, D, &c);
+    if (rc != PILOT_OT_OK) return rc;
+    rc = pilot_ot_cell_w2_grid_cohort(c, scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, row_begin, row_end,
+                                      row_step, w2, iters, err, nullptr);
+    pilot_ot_cell_cohort_destroy(c);
+    return rc;
+}
+
+// full N x N grid with the rows dealt round-robin over several devices; every device holds the whole cohort, the
+// shards run concurrently on their own streams and the (small) result rows are assembled on the host
+PILOT_API int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offsets, int N, int D, double scale, double reg,
+                                          int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
+                                          const int *devices, int n_devices, double *w2, int *iters, double *err) {
+    if (!X || !offsets || !w2 || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (n_devices < 1 || n_devices > 64) return fail(PILOT_OT_EINVAL, "n_devices=%d out of range", n_devices);
+    int saved = 0;
+    HIP_TRY(hipGetDevice(&saved));
+    std::vector<pilot_ot_cell_cohort *> co(n_devices, nullptr);
+    std::vector<size_t> n_out(n_devices, 0);
+    int rc = PILOT_OT_OK;
+    for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
+        if (hipSetDevice(devices[s]) != hipSuccess) { rc = fail(PILOT_OT_EINVAL, "device %d not visible", devices[s]); break; }
+        rc = pilot_ot_cell_cohort_create(X, offsets, N, D, &co[s]);
+    }
+    for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
+        (void)hipSetDevice(devices[s]);
+        rc = cell_w2_enqueue(co[s], scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, s, N, n_devices, &n_out[s]);
+    }
+    std::vector<double> tw, te;
+    std::vector<int> ti;
+    for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
+        (void)hipSetDevice(devices[s]);
+        tw.resize(n_out[s]); te.resize(n_out[s]); ti.resize(n_out[s]);
+        rc = cell_w2_collect(co[s], n_out[s], tw.data(), ti.data(), te.data(), nullptr);
+        for (size_t t = 0; rc == PILOT_OT_OK && t < n_out[s] / (size_t)N; ++t) {
+            const size_t row = (size_t)s + t * n_devices;
+            memcpy(w2 + row * N, tw.data() + t * N, sizeof(double) * N);
+            if (iters) memcpy(iters + row * N, ti.data() + t * N, sizeof(int) * N);
+            if (err) memcpy(err + row * N, te.data() + t * N, sizeof(double) * N);
+        }
+    }
+    for (int s = 0; s < n_devices; ++s)
+        if (co[s]) { (void)hipSetDevice(devices[s]); pilot_ot_cell_cohort_destroy(co[s]); }
+    (void)hipSetDevice(saved);
+    return rc;
 }

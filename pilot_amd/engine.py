@@ -118,32 +118,87 @@ def centroid_medians(X, cell_code, n_types):
     return out
 
 
-def cell_w2_grid(X, offsets, scale, reg, num_iter_max=1000, stop_thr=1e-9, check_period=10, f32_floor_ulps=0.0,
-                 row_begin=0, row_end=None, row_step=1, return_info=False):
-    """EXTENSION (not in the reference; BASELINE config 5): entropic W2 cost between patients' raw cell clouds.
-
-    X: (C, D) float32 embedding with every patient's cells contiguous; offsets: (N + 1,) row ranges.  Pair (i, j):
-    uniform weights, cost |x - y|^2 / scale, log-domain Sinkhorn with POT ``sinkhorn_log`` control flow; returns the
-    (n_rows, N) matrix of <Gamma, C>."""
+def _cell_inputs(X, offsets):
     X = np.ascontiguousarray(X, dtype=np.float32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     if X.ndim != 2 or offsets.ndim != 1 or offsets.size < 2 or offsets[0] != 0 or offsets[-1] != X.shape[0]:
         raise ValueError("X must be (C, D) and offsets (N + 1,) with offsets[0] = 0, offsets[-1] = C")
     if not np.all(np.isfinite(X)):
         raise ValueError("X contains NaN or inf")
+    return X, offsets
+
+
+class CellCohort:
+    """Device-resident cell clouds for the cell-level W2 extension (``pilot_ot_cell_cohort_*``): the cells stay in HBM as
+    bf16 operand pieces across calls, a call moves only result rows."""
+
+    def __init__(self, X, offsets):
+        X, offsets = _cell_inputs(X, offsets)
+        self.N, self.D = offsets.size - 1, X.shape[1]
+        self.cells_per_patient = np.diff(offsets)
+        self.L = _lib.load()
+        self.h = ctypes.c_void_p()
+        _lib.check(self.L.pilot_ot_cell_cohort_create(ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(offsets.ctypes.data),
+                                                      self.N, self.D, ctypes.byref(self.h)))
+        self.last_kernel_ms = None
+
+    def w2_grid(self, scale, reg, num_iter_max=1000, stop_thr=1e-9, check_period=10, f32_floor_ulps=0.0,
+                row_begin=0, row_end=None, row_step=1, return_info=False):
+        row_end = self.N if row_end is None else int(row_end)
+        n_rows = n_rows_of(self.N, row_begin, row_end, row_step)
+        w2 = np.zeros((n_rows, self.N), dtype=np.float64)
+        iters = np.zeros((n_rows, self.N), dtype=np.int32)
+        err = np.zeros((n_rows, self.N), dtype=np.float64)
+        ms = ctypes.c_float(0.0)
+        _lib.check(self.L.pilot_ot_cell_w2_grid_cohort(self.h, float(scale), float(reg), int(num_iter_max), float(stop_thr),
+                                                       int(check_period), float(f32_floor_ulps), int(row_begin), row_end,
+                                                       int(row_step), _lib.dptr(w2), _lib.iptr(iters), _lib.dptr(err),
+                                                       ctypes.byref(ms)))
+        self.last_kernel_ms = float(ms.value)
+        if return_info:
+            return w2, dict(iters=iters, err=err)
+        return w2
+
+    def close(self):
+        if self.h:
+            self.L.pilot_ot_cell_cohort_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cell_w2_grid(X, offsets, scale, reg, num_iter_max=1000, stop_thr=1e-9, check_period=10, f32_floor_ulps=0.0,
+                 row_begin=0, row_end=None, row_step=1, return_info=False, devices=None):
+    """EXTENSION (not in the reference; BASELINE config 5): entropic W2 cost between patients' raw cell clouds.
+
+    X: (C, D) float32 embedding with every patient's cells contiguous; offsets: (N + 1,) row ranges.  Pair (i, j):
+    uniform weights, cost |x - y|^2 / scale, log-domain Sinkhorn with POT ``sinkhorn_log`` control flow; returns the
+    (n_rows, N) matrix of <Gamma, C>.  ``devices=[...]``: the full grid with its rows dealt round-robin over several GPUs."""
+    X, offsets = _cell_inputs(X, offsets)
     N = offsets.size - 1
-    row_end = N if row_end is None else int(row_end)
-    n_rows = n_rows_of(N, row_begin, row_end, row_step)
-    w2 = np.zeros((n_rows, N), dtype=np.float64)
-    iters = np.zeros((n_rows, N), dtype=np.int32)
-    err = np.zeros((n_rows, N), dtype=np.float64)
-    _lib.check(_lib.load().pilot_ot_cell_w2_grid(
-        ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(offsets.ctypes.data), N, X.shape[1], float(scale), float(reg),
-        int(num_iter_max), float(stop_thr), int(check_period), float(f32_floor_ulps), int(row_begin), row_end, int(row_step),
-        _lib.dptr(w2), _lib.iptr(iters), _lib.dptr(err)))
-    if return_info:
-        return w2, dict(iters=iters, err=err)
-    return w2
+    if devices is not None:
+        if row_begin != 0 or row_end not in (None, N) or row_step != 1:
+            raise ValueError("devices=[...] computes the full grid")
+        dev = np.ascontiguousarray([int(d) for d in devices], dtype=np.int32)
+        w2 = np.zeros((N, N), dtype=np.float64)
+        iters = np.zeros((N, N), dtype=np.int32)
+        err = np.zeros((N, N), dtype=np.float64)
+        _lib.check(_lib.load().pilot_ot_cell_w2_grid_multi(
+            ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(offsets.ctypes.data), N, X.shape[1], float(scale), float(reg),
+            int(num_iter_max), float(stop_thr), int(check_period), float(f32_floor_ulps), _lib.iptr(dev), len(dev),
+            _lib.dptr(w2), _lib.iptr(iters), _lib.dptr(err)))
+        return (w2, dict(iters=iters, err=err)) if return_info else w2
+    co = CellCohort(X, offsets)
+    try:
+        return co.w2_grid(scale, reg, num_iter_max=num_iter_max, stop_thr=stop_thr, check_period=check_period,
+                          f32_floor_ulps=f32_floor_ulps, row_begin=row_begin, row_end=row_end, row_step=row_step,
+                          return_info=return_info)
+    finally:
+        co.close()
 
 
 class DevicePlan:

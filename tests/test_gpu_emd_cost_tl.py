@@ -158,10 +158,13 @@ def test_centroid_medians_match_the_reference_pandas_medians(name):
 
 
 # ------------------------------------------------------------------------------- cost matrix
-@pytest.mark.parametrize("metric", ["cosine", "euclidean", "sqeuclidean", "cityblock", "chebyshev", "correlation"])
+@pytest.mark.parametrize("metric", ["cosine", "euclidean", "sqeuclidean", "cityblock", "chebyshev", "correlation",
+                                    "minkowski", "seuclidean", "braycurtis", "canberra", "hamming"])
 @pytest.mark.parametrize("K,D", [(2, 3), (50, 30), (100, 50), (130, 7)])
 def test_pdist_kernel_vs_scipy(metric, K, D):
     X = np.random.default_rng(K * D).standard_normal((K, D))
+    if metric in ("hamming", "canberra"):
+        X = np.round(X)                              # equal coordinates and 0/0 terms actually occur
     ref = ssd.squareform(ssd.pdist(X, metric=metric))
     got = engine.pdist_square(X, metric=metric)
     np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-14)
