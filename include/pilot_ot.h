@@ -39,7 +39,7 @@ extern "C" {
 #define PILOT_OT_OK 0
 #define PILOT_OT_EINVAL (-1)  /* bad argument                                              */
 #define PILOT_OT_EHIP (-2)    /* HIP runtime error / no gfx950 device                      */
-#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support                     */
+#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support (K > 2048, exact OT with K > 256, ...) */
 #define PILOT_OT_ERCCL (-4)   /* RCCL error / librccl missing (multi-GPU entry points only) */
 
 /* precision of the Sinkhorn pair-grid kernel */
@@ -51,6 +51,10 @@ extern "C" {
                                    * below 2^-110 are kept times 2^128 in a second operand image, so exp(-M/reg) is faithful down
                                    * to exp(-165)); a pair that still goes NaN / inf is solved again in f64 (PILOT_OT_FLAG_F64
                                    * tells which).  Falls back to F64 where the images do not fit LDS or max(M)/reg > 140. */
+#define PILOT_OT_PREC_GENERIC 5 /* reference-semantics fallback: POT's sinkhorn_stabilized loop literally in fp64, one workgroup per
+                                * pair, absorbed kernel exp(-(M - alpha - beta)/reg) rebuilt at every tau-absorption.  Taken
+                                * automatically when K > 128 or max(M)/reg > 600 (where the fixed Gibbs image of the fast kernels
+                                * leaves the f64 range); NaN handling is POT's (revert to the last good iterate). */
 #define PILOT_OT_PREC_BF16X3 3 /* f32 values, products on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits
                                 * (six piece products per term, f32 accumulation): f32-level rounding, not bit-identical
                                 * to PREC_F32, ~2x its speed */
@@ -119,9 +123,9 @@ int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric
  * num_iter_max=1000, stop_thr=1e-9, tau=1e3, check_period=20.  In f32 the stop threshold is
  * floored at f32_floor_ulps * FLT_EPSILON * ||b||_2 (pass 0 for the default of 8).
  * cost_is_symmetric: 1 if M == M^T exactly (always true for pdist output), 0 otherwise.
- * Range: max(M)/reg <= 600 (PILOT_OT_ENOTSUP beyond: the kernels keep total scalings against the fixed exp(-M/reg) instead
- * of rebuilding POT's absorbed kernel, so the ratio must fit the f64 exponent range).  The device-resident form takes M
- * already divided by its max (Trajectory.py:101) and checks 1/reg.
+ * Range: K <= 128 and max(M)/reg <= 600 run on the MFMA kernels (they keep total scalings against the fixed exp(-M/reg), so
+ * the ratio must fit the f64 exponent range); larger K (<= 2048) or smaller reg run PILOT_OT_PREC_GENERIC, whatever precision
+ * was asked for.  The device-resident form takes M already divided by its max (Trajectory.py:101) and looks at 1/reg.
  * emd / iters / err / flags: n_rows x N; iters, err, flags may be NULL. */
 int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg,
                            int num_iter_max, double stop_thr, double tau, int check_period,

@@ -111,22 +111,25 @@ __device__ inline int wl_i32(int old, int value, int lane) { return (int)(thread
 // Nothing per wave is in LDS, so occupancy is bounded by registers only (the step loop is pure latency).
 constexpr int EMD_WAVES = 8;
 
-template <int NK>
+// MG: the cost matrix is read from global memory (L2) instead of LDS -- K > 128, where K*K doubles no longer fit LDS
+template <int NK, bool MG = false>
 __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    double *Msh = reinterpret_cast<double *>(smem_raw);   // K*K
-    double *rowmin = Msh + (size_t)K * K;                 // K: min_j M_ij (initial row potentials)
-    for (int t = threadIdx.x; t < K * K; t += blockDim.x) Msh[t] = p.M[t];
-    __syncthreads();
+    double *Msh = reinterpret_cast<double *>(smem_raw);   // K*K (not with MG)
+    double *rowmin = MG ? Msh : Msh + (size_t)K * K;      // K: min_j M_ij (initial row potentials)
+    if constexpr (!MG) {
+        for (int t = threadIdx.x; t < K * K; t += blockDim.x) Msh[t] = p.M[t];
+        __syncthreads();
+    }
+    const double *Mrd = MG ? p.M : Msh;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         double m = __builtin_inf();
-        for (int j = 0; j < K; ++j) { const double v = Msh[(size_t)i * K + j]; m = v < m ? v : m; }
+        for (int j = 0; j < K; ++j) { const double v = Mrd[(size_t)i * K + j]; m = v < m ? v : m; }
         rowmin[i] = m;
     }
     __syncthreads();
-    const double *Mrd = Msh;
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
     const double INF = __builtin_inf();
     const long total = (long)p.n_rows * N;

@@ -17,6 +17,7 @@
 #include "emd_kernels.hpp"
 #include "prepass_kernels.hpp"
 #include "cellw2_kernels.hpp"
+#include "generic_kernels.hpp"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -138,13 +139,16 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
     }
 }
 
-constexpr int MAX_K = 128;
+constexpr int MAX_K = 128;          // the MFMA pair-grid kernels (8 row-tiles of 16 cell types)
+constexpr int GENERIC_MAX_K = 2048;  // the reference-semantics fallback kernel (vectors in LDS)
+constexpr int EMD_MAX_K = 256;       // exact-OT kernel: 4 rows / columns per lane
 constexpr int CTRL_INTS = 12;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
 // exact-EMD kernel: workgroups of pilot::EMD_WAVES waves, M (+ row minima) in LDS; resident workgroups per CU
 static int emd_wgs_per_cu(int K) {
+    if (K > 128) return 1;                      // cost matrix in global memory, 3-4 rows per lane: one workgroup per CU
     const size_t lds = sizeof(double) * ((size_t)K * K + K);
     int by_lds = (int)(LDS_BYTES / lds);
     const int by_regs = K <= 64 ? 4 : 2;        // 58 / 88 VGPRs per lane: 8 / 5 waves per SIMD
@@ -170,6 +174,8 @@ struct pilot_ot_plan {
     size_t flags_ws_n;
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
     double *f_slab;    // exact-EMD flow values: one K*K block per resident wave
+    double *kws;       // generic Sinkhorn kernel: K' and its transpose per workgroup (allocated on first use)
+    int generic_wgs;
     int n_cu;
     // event ring for per-launch kernel timing (bench.py roofline)
     int timing;                       // 0 off
@@ -279,13 +285,13 @@ PILOT_API int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int c
 PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (!plan) return fail(PILOT_OT_EINVAL, "plan is NULL");
     if (N <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "N=%d K=%d must be positive", N, K);
-    if (K > MAX_K) return fail(PILOT_OT_ENOTSUP, "K=%d > %d cell types is not supported yet", K, MAX_K);
+    if (K > GENERIC_MAX_K) return fail(PILOT_OT_ENOTSUP, "K=%d > %d cell types", K, GENERIC_MAX_K);
     if ((long long)N * N > 0x7fffffffLL) return fail(PILOT_OT_ENOTSUP, "N=%d: N*N overflows the pair index", N);
     pilot_ot_plan *pl = new (std::nothrow) pilot_ot_plan();
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
-    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256;
+    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
@@ -297,7 +303,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
             pl->n_cu = n_cu;
     }
     const int kp = ((K + 31) / 32) * 32;
-    {
+    if (K <= MAX_K) {
         const int rt = (K + 15) / 16;
         size_t img_bytes = pilot::img_elems(pilot::CFG_F64, rt) * sizeof(double);
         const size_t b32 = pilot::img_elems(pilot::CFG_F32, rt) * sizeof(float), bs = pilot::img_elems(pilot::CFG_S32, rt) * sizeof(float);
@@ -311,7 +317,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
-    if (e == hipSuccess)
+    if (e == hipSuccess && K <= EMD_MAX_K)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
                       sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::EMD_WAVES);
     if (e != hipSuccess) {
@@ -333,6 +339,7 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->flags_ws) (void)hipFree(pl->flags_ws);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
     if (pl->f_slab) (void)hipFree(pl->f_slab);
+    if (pl->kws) (void)hipFree(pl->kws);
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) if (pl->ev[i][j]) (void)hipEventDestroy(pl->ev[i][j]);
     delete pl;
     return PILOT_OT_OK;
@@ -348,22 +355,54 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     if (check_period < 1) return fail(PILOT_OT_EINVAL, "check_period=%d must be >= 1", check_period);
     if (!(stop_thr >= 0.0) || !(stop_thr < 1.0)) return fail(PILOT_OT_EINVAL, "stop_thr=%g must be in [0, 1)", stop_thr);
     if (!(tau > 1.0)) return fail(PILOT_OT_EINVAL, "tau=%g must be > 1", tau);
-    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_AUTO_MIXED)
+    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_GENERIC)
         return fail(PILOT_OT_EINVAL, "unknown precision id %d", precision);
     if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
         return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
-    if (K > MAX_K) return fail(PILOT_OT_ENOTSUP, "K=%d > %d cell types is not supported yet", K, MAX_K);
+    if (K > GENERIC_MAX_K) return fail(PILOT_OT_ENOTSUP, "K=%d > %d cell types", K, GENERIC_MAX_K);
     return PILOT_OT_OK;
 }
 
-// The kernels iterate TOTAL scalings against the fixed Gibbs image exp(-M/reg) (POT's log-absorption is value-neutral and
-// only its bookkeeping is tracked), so max(M)/reg must stay inside the exponent range of the widest type: beyond ~600 an
-// f64 Gibbs entry underflows / a total scaling overflows where POT's absorbed kernel would not.  Refused, not emulated.
+// The MFMA kernels iterate TOTAL scalings against the fixed Gibbs image exp(-M/reg) (POT's log-absorption is value-neutral
+// and only its bookkeeping is tracked), so max(M)/reg must stay inside the exponent range of the widest type: beyond ~600
+// an f64 Gibbs entry underflows / a total scaling overflows where POT's absorbed kernel would not.  Such calls, and K > 128,
+// go to the reference-semantics kernel (generic_kernels.hpp), which rebuilds the absorbed kernel like POT.
 constexpr double MAX_COST_OVER_REG = 600.0;
-int check_reg_range(double max_cost_over_reg) {
-    if (max_cost_over_reg > MAX_COST_OVER_REG)
-        return fail(PILOT_OT_ENOTSUP, "max(M)/reg = %g > %g: exp(-M/reg) leaves the f64 range (use a larger reg or rescale M)",
-                    max_cost_over_reg, MAX_COST_OVER_REG);
+
+int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max, double stop_thr, double tau,
+                int check_period, int row_begin, int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags,
+                hipStream_t s) {
+    const int N = pl->N, K = pl->K;
+    const int n_pairs = n_rows * N;
+    if (n_pairs == 0) return PILOT_OT_OK;
+    const size_t lds = sizeof(double) * (8 * (size_t)K + 8) + 16;
+    if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the generic kernel's LDS vectors", K);
+    if (!pl->kws) {
+        // two workgroups per CU, fewer when K' and its transpose would take more than 8 GB in all
+        int wgs = 2 * pl->n_cu;
+        const size_t per = sizeof(double) * 2 * (size_t)K * K;
+        while (wgs > 1 && per * wgs > ((size_t)8 << 30)) wgs /= 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->kws), per * wgs));
+        pl->generic_wgs = wgs;
+    }
+    if (!d_flags) {
+        if ((size_t)n_pairs > pl->flags_ws_n) {
+            if (pl->flags_ws) HIP_TRY(hipFree(pl->flags_ws));
+            pl->flags_ws = nullptr; pl->flags_ws_n = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->flags_ws), sizeof(int) * (size_t)n_pairs));
+            pl->flags_ws_n = (size_t)n_pairs;
+        }
+        d_flags = pl->flags_ws;
+    }
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, sizeof(int), s));
+    pilot::GenericParams g;
+    g.P = d_P; g.M = d_M; g.N = N; g.K = K; g.n_pairs = n_pairs; g.row_begin = row_begin; g.row_step = row_step;
+    g.reg = reg; g.tau = tau; g.stop_thr = stop_thr; g.max_iter = num_iter_max; g.period = check_period;
+    g.emd = d_emd; g.iters = d_iters; g.err = d_err; g.flags = d_flags; g.kws = pl->kws; g.queue = pl->track_count;
+    int wgs = pl->generic_wgs < n_pairs ? pl->generic_wgs : n_pairs;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::sinkhorn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pilot::sinkhorn_generic_kernel, dim3(wgs), dim3(pilot::GENERIC_WG), lds, s, g);
+    HIP_TRY(hipGetLastError());
     return PILOT_OT_OK;
 }
 
@@ -570,8 +609,14 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     int rc = check_grid_args(pl->N, pl->K, reg, num_iter_max, stop_thr, tau, check_period, precision, row_begin,
                              row_end, row_step);
     if (rc != PILOT_OT_OK) return rc;
-    rc = check_reg_range(1.0 / reg);        // M is /max (Trajectory.py:101): device-resident callers keep that convention
-    if (rc != PILOT_OT_OK) return rc;
+    {
+        const int n_rows_g = (row_end - row_begin + row_step - 1) / row_step;
+        // K beyond the MFMA kernels, a reg beyond the f64 range of exp(-M/reg) (M is /max, Trajectory.py:101: device-resident
+        // callers keep that convention), or on request: POT's loop literally, absorbed kernel rebuilt per pair
+        if (precision == PILOT_OT_PREC_GENERIC || pl->K > MAX_K || 1.0 / reg > MAX_COST_OVER_REG)
+            return run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows_g, row_step, d_emd,
+                               d_iters, d_err, d_flags, static_cast<hipStream_t>(stream));
+    }
     bool mixed = false;
     if (precision == PILOT_OT_PREC_AUTO) {
         precision = pilot_ot_auto_precision_for(1.0 / reg, pl->K, cost_is_symmetric);  // M is /max (Trajectory.py:101)
@@ -706,8 +751,7 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     if (rc != PILOT_OT_OK) return rc;
     double mx = 0.0;
     for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
-    rc = check_reg_range(mx / reg);
-    if (rc != PILOT_OT_OK) return rc;
+    if (mx / reg > MAX_COST_OVER_REG) precision = PILOT_OT_PREC_GENERIC;     // exp(-M/reg) would leave the f64 range
     if (precision == PILOT_OT_PREC_AUTO) {
         precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
         if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
@@ -751,12 +795,17 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab;
     const long total = (long)n_rows * N;
     {
-        const size_t lds = sizeof(double) * ((size_t)K * K + K);
+        if (K > EMD_MAX_K || !pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: K=%d > %d cell types", K, EMD_MAX_K);
+        const size_t lds = K > 128 ? sizeof(double) * (size_t)K : sizeof(double) * ((size_t)K * K + K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
         long wgs = (total + pilot::EMD_WAVES - 1) / pilot::EMD_WAVES;
         const long cap = (long)pl->n_cu * emd_wgs_per_cu(K);
         if (wgs > cap) wgs = cap;
-        if (K <= 64) {
+        if (K > 192) {
+            hipLaunchKernelGGL((pilot::emd_grid_kernel<4, true>), dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+        } else if (K > 128) {
+            hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true>), dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+        } else if (K <= 64) {
             auto kern = pilot::emd_grid_kernel<1>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);

@@ -48,13 +48,14 @@ def test_argument_validation_needs_no_device():
     # NULL pointer
     rc = L.pilot_ot_sinkhorn_grid(None, 4, 3, dp(M), 0.1, 1000, 1e-9, 1e3, 20, 0, 0.0, 1, 0, 4, 1, dp(out), None, None, None)
     assert rc == _lib.EINVAL
-    # K beyond the kernels' range is ENOTSUP, not a silent fallback
-    rc = L.pilot_ot_sinkhorn_grid(dp(P), 4, 200, dp(M), 0.1, 1000, 1e-9, 1e3, 20, 0, 0.0, 1, 0, 4, 1, dp(out), None, None, None)
+    # K beyond every kernel's range is ENOTSUP, not a silent fallback (K <= 128: MFMA kernels, <= 2048: reference-semantics kernel)
+    rc = L.pilot_ot_sinkhorn_grid(dp(P), 4, 4000, dp(M), 0.1, 1000, 1e-9, 1e3, 20, 0, 0.0, 1, 0, 4, 1, dp(out), None, None, None)
     assert rc == _lib.ENOTSUP
-    # reg so small that exp(-M/reg) leaves the f64 range: refused, not silently wrong
+    # reg so small that exp(-M/reg) leaves the f64 range is a valid call (it runs the reference-semantics kernel):
+    # on this box it gets as far as needing a device
     M1 = np.ones((3, 3)) - np.eye(3)
     rc = L.pilot_ot_sinkhorn_grid(dp(P), 4, 3, dp(M1), 1e-3, 1000, 1e-9, 1e3, 20, 0, 0.0, 1, 0, 4, 1, dp(out), None, None, None)
-    assert rc == _lib.ENOTSUP and b"max(M)/reg" in L.pilot_ot_last_error()
+    assert rc in (_lib.OK, _lib.EHIP)
     rc = L.pilot_ot_cost_matrix(dp(P), 4, 3, 99, dp(out))
     assert rc in (_lib.EINVAL, _lib.EHIP)
     assert L.pilot_ot_auto_precision(10.0) == 3 and L.pilot_ot_auto_precision(100.0) == 2     # bf16x3 / f64

@@ -99,10 +99,37 @@ def test_every_tile_shape(K, prec, tol):
     assert np.abs(Eg - Eo).max() <= tol
 
 
-def test_k_above_128_is_rejected_not_emulated():
-    P, M = make_problem(5, 130, 4, seed=1, cells_per_patient=500)
-    with pytest.raises(NotImplementedError):
-        engine.sinkhorn_grid(P, M, 0.1)
+@pytest.mark.parametrize("K", [130, 200])
+def test_k_above_128_runs_the_reference_semantics_kernel(K):
+    """The reference has no limit on the number of cell types (Trajectory.py:479-523): beyond the MFMA kernels' 128 the
+    pair grid runs POT's loop literally in fp64 (generic_kernels.hpp) and must follow the oracle update for update."""
+    P, M = make_problem(9, K, 4, seed=K, cells_per_patient=2000)
+    Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+    assert np.abs(Eg - Eo).max() <= 1e-12
+    np.testing.assert_array_equal(ig["iters"], io["iters"])
+    assert np.all((ig["flags"] & _lib.FLAG_F64) > 0)
+    part = engine.sinkhorn_grid(P, M, 0.1, row_begin=2, row_end=7, row_step=3)
+    np.testing.assert_array_equal(part, Eg[2:7:3])
+    # exact mode up to 256 cell types (cost matrix read from L2 instead of LDS)
+    assert np.abs(engine.emd_grid(P, M) - O.emd_grid(P, M, n_threads=16)).max() <= 1e-12
+
+
+def test_generic_kernel_is_pot_literal_including_absorption_and_tiny_reg():
+    """precision='generic' forces the reference-semantics kernel on any shape: same update counts, absorption flags and
+    errors as the oracle at reg 0.01 (every pair absorbs, some on their last update); and a reg whose exp(-M/reg) leaves the
+    f64 range (max(M)/reg = 1000) is solved through the rebuilt absorbed kernel instead of returning NaN."""
+    P, M = make_problem(**CONFIGS["c1"])
+    for reg, kw in ((0.1, {}), (0.01, {}), (0.05, dict(tau=30.0)), (1e-3, {})):
+        Eo, io = O.sinkhorn_grid(P, M, reg, n_threads=16, return_info=True, **kw)
+        Eg, ig = engine.sinkhorn_grid(P, M, reg, precision="generic" if reg > 2e-3 else "auto", return_info=True, **kw)
+        assert np.isfinite(Eg).all()
+        np.testing.assert_array_equal(ig["iters"], io["iters"])
+        for bit in (1, 2, 4, 8):
+            np.testing.assert_array_equal(ig["flags"] & bit, io["flags"] & bit)
+        assert np.abs(Eg - Eo).max() <= 1e-10, (reg, np.abs(Eg - Eo).max())
+        np.testing.assert_allclose(ig["err"], io["err"], rtol=1e-6, atol=1e-13)
+    assert ((io["flags"] & 8) > 0).mean() > 0.9          # at reg 1e-3 nearly every pair absorbs
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("fp64", TOL64)])
