@@ -78,14 +78,14 @@ __device__ inline void swap32_f64(double x, double &a, double &b) {
     a = p.d; b = q.d;
 }
 __device__ inline double wave_min_f64(double x) {
-    double y;
-    y = dpp_f64<0xB1>(x); x = y < x ? y : x;     // quad_perm(1,0,3,2): lane ^ 1
-    y = dpp_f64<0x4E>(x); x = y < x ? y : x;     // quad_perm(2,3,0,1): lane ^ 2
-    y = dpp_f64<0x141>(x); x = y < x ? y : x;    // row_half_mirror: the other quad of the octet
-    y = dpp_f64<0x140>(x); x = y < x ? y : x;    // row_mirror: the other octet of the row
+    // (labels are never NaN, so v_min_f64 is the compare-and-select it replaces: 3 instead of 5 instructions per stage)
+    x = __builtin_fmin(x, dpp_f64<0xB1>(x));     // quad_perm(1,0,3,2): lane ^ 1
+    x = __builtin_fmin(x, dpp_f64<0x4E>(x));     // quad_perm(2,3,0,1): lane ^ 2
+    x = __builtin_fmin(x, dpp_f64<0x141>(x));    // row_half_mirror: the other quad of the octet
+    x = __builtin_fmin(x, dpp_f64<0x140>(x));    // row_mirror: the other octet of the row
     double a, b;
-    swap16_f64(x, a, b); x = a < b ? a : b;      // the neighbouring row
-    swap32_f64(x, a, b); x = a < b ? a : b;      // the other half of the wave
+    swap16_f64(x, a, b); x = __builtin_fmin(a, b);      // the neighbouring row
+    swap32_f64(x, a, b); x = __builtin_fmin(a, b);      // the other half of the wave
     return x;
 }
 __device__ inline double wave_sum_f64(double x) {

@@ -1,18 +1,37 @@
 #!/bin/bash
 # One GPU-box pass that produces everything the round commits under profiles/: usage tools/gpu_round_report.sh <tag>
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/report_$TAG
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
-python bench.py > $O/bench.json 2> $O/bench.err
-python tools/host_api_rate.py > $O/host_api_rate.txt 2>&1
+python bench.py > $O/bench_c3_reg0.1_n1.json 2> $O/bench.err
+python bench.py --mode emd > $O/bench_emd_c3.json 2>> $O/bench.err
+python bench.py --mode emd --config c4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_emd_c4.json 2>> $O/bench.err
+python bench.py --config c4 --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_c4_reg0.1_n1.json 2>> $O/bench.err
+python bench.py --config c2 --no-extras --no-cpu-baseline > $O/bench_c2_reg0.1_n1.json 2>> $O/bench.err
+python bench.py --precision fp32 --no-extras --no-cpu-baseline > $O/bench_c3_reg0.1_fp32_mfma.json 2>> $O/bench.err
+python bench.py --mode cellw2 > $O/bench_cellw2_c5.json 2>> $O/bench.err
+python bench.py --gpus 2 --logical-shards --no-cpu-baseline > $O/bench_two_logical_shards_one_process.json 2>> $O/bench.err
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29544 python bench.py --gpus 1 --force-comm --no-cpu-baseline > $O/bench_one_rank_rccl_comm.json 2>> $O/bench.err
+python tools/e2e_timing.py c3 > $O/e2e_tl_wasserstein_distance_c3.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_emd -- python3 $R/bench.py --mode emd --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_emd_c4 -- python3 $R/bench.py --mode emd --config c4 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cellw2 -- python3 $R/bench.py --mode cellw2 --cell-patients 48 > /dev/null 2>&1
 cd $R
-cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
-bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc > /dev/null 2>&1
-cat $O/pytest_gpu.txt $O/smoke.txt $O/host_api_rate.txt; cat $O/bench.json; head -8 $O/kernel_stats.csv; head -22 $O/pmc/summary.txt
+cp $O/stats/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_bench_c3.csv 2>/dev/null
+cp $O/stats_emd/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_emd_c3.csv 2>/dev/null
+cp $O/stats_emd_c4/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_emd_c4.csv 2>/dev/null
+cp $O/stats_cellw2/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_cellw2_48x5000.csv 2>/dev/null
+bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc --no-extras > /dev/null 2>&1
+cp $O/pmc/summary.txt $O/rocprofv3_pmc_summary_bench_c3.txt
+bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_emd --mode emd > /dev/null 2>&1
+cp $O/pmc_emd/summary.txt $O/rocprofv3_pmc_summary_emd_c3.txt
+python tools/make_traffic_json.py $O > $O/traffic.json
+rm -rf $O/stats $O/stats_emd $O/stats_emd_c4 $O/stats_cellw2 $O/pmc $O/pmc_emd
+cat $O/pytest_gpu.txt $O/smoke.txt; cut -c1-700 $O/bench_c3_reg0.1_n1.json; head -6 $O/rocprofv3_kernel_stats_bench_c3.csv; cat $O/traffic.json

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""traffic.json for bench.py's roofline.traffic: HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes
+(FETCH_SIZE and WRITE_SIZE in separate passes, KB; FETCH_SIZE doubled per MI355X_MICROARCH.md) and its average duration from
+the rocprofv3 --kernel-trace --stats run, keyed by workload and stamped with the git revision they were measured at."""
+import csv, json, os, re, subprocess, sys
+d = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+bench = json.load(open(os.path.join(d, "bench_under_rocprof.json")))
+prec = {"f64": "fp64"}.get(bench["dtype"], "bf16x3" if "bf16" in bench["dtype"] else "fp32")
+kern, fetch, write = None, None, None
+for line in open(os.path.join(d, "rocprofv3_pmc_summary_bench_c3.txt")):
+    m = re.match(r"== (sinkhorn_stream_kernel<[^>]*>)", line)
+    if m and kern is None:
+        kern = m.group(1)
+        cur = True
+    elif line.startswith("=="):
+        cur = False
+    elif kern and cur:
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+mean ([0-9.e+]+)", line)
+        if m and m.group(1) == "FETCH_SIZE" and fetch is None: fetch = float(m.group(2))
+        if m and m.group(1) == "WRITE_SIZE" and write is None: write = float(m.group(2))
+avg_ns = None
+for row in csv.DictReader(open(os.path.join(d, "rocprofv3_kernel_stats_bench_c3.csv"))):
+    if "sinkhorn_stream_kernel" in row["Name"] and (avg_ns is None or float(row["AverageNs"]) > avg_ns):
+        avg_ns = float(row["AverageNs"])
+sha = ""
+try:
+    sha = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except OSError:
+    pass
+if not sha:      # the GPU box gets a snapshot without .git: the revision travels in tools/.git_sha (written before the run)
+    try:
+        sha = open(os.path.join(root, "tools", ".git_sha")).read().strip()
+    except OSError:
+        sha = "unknown"
+N, K = bench["config"]["n_patients"], bench["config"]["n_cell_types"]
+s = 8 if prec == "fp64" else 4
+out = {
+    "_comment": "HBM traffic of the dominant kernel per launch from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE "
+                "passes, tools/profile_pmc.sh; counters in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is) and its "
+                "average duration from rocprofv3 --kernel-trace --stats (tools/gpu_round_report.sh), 1x MI355X.",
+    "c3|%g|%s" % (bench["config"]["reg"], prec): {
+        "kernel": kern, "fetch_size_kb": fetch, "write_size_kb": write,
+        "traffic_bytes": int(1024 * (2 * fetch + write)) if fetch is not None and write is not None else None,
+        "algorithmic_bytes": N * N * (2 * K * s + s),
+        "kernel_ms_rocprofv3": round(avg_ns / 1e6, 4) if avg_ns else None,
+        "git": sha,
+    },
+}
+print(json.dumps(out, indent=1))
