@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64", "bf16x3"])
     ap.add_argument("--mode", default="sinkhorn", choices=["sinkhorn", "emd", "cellw2"],
                     help="emd: time the exact-OT pair grid (the reference's default mode) instead; cellw2: the cell-level W2 "
-                         "extension at BASELINE config 5 (200 patients x 5000 cells x 30 dims; takes about half a minute)")
+                         "extension at BASELINE config 5 (200 patients x 5000 cells x 30 dims; takes about two minutes)")
     ap.add_argument("--cell-patients", type=int, default=200)
     ap.add_argument("--cell-cells", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,7 +135,8 @@ def main():
         comm = multi.Comm(rank, world) if (world > 1 or args.force_comm) else None
         if comm:
             d_stage, d_full = DevBuf(L, 8 * world * n_pad * N), DevBuf(L, 8 * N * N)
-            _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, np.zeros(n_pad * N).ctypes.data, 8 * n_pad * N))   # padding rows = 0
+            zeros = np.zeros(n_pad * N)                                  # (kept alive across the copy)
+            _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, zeros.ctypes.data, 8 * n_pad * N))   # padding rows = 0
 
         def step():
             plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=prec)
@@ -372,7 +373,8 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
     plan.enable_timing(True)
     if comm:
         d_stage, d_full = DevBuf(L, 8 * world * n_pad * N), DevBuf(L, 8 * N * N)
-        _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, np.zeros(n_pad * N).ctypes.data, 8 * n_pad * N))
+        zeros = np.zeros(n_pad * N)
+        _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, zeros.ctypes.data, 8 * n_pad * N))
 
     def step():
         plan.run(0.1, row_begin=rb, row_end=re_, row_step=rs, precision="auto")

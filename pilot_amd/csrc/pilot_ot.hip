@@ -410,7 +410,7 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
 int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split) {
     if (split) return RT <= 6 ? 2 : 1;
     const int na = RT * 4 * RT * w;
-    const bool greg = !split && sym && na <= 64;
+    const bool greg = !split && sym && na <= pilot::GREG_MAX;
     const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) + (split ? 3 * ((RT + 1) / 2) * 4 + 24 : 0) +
                      (greg ? na + 2 * tv * ((RT - 1) * 4 + 1) * w : 0);
     return regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));

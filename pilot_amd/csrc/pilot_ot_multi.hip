@@ -191,7 +191,7 @@ struct Shard {
     hipStream_t stream = nullptr;
     double *dP = nullptr, *dM = nullptr, *dLocal = nullptr, *dErr = nullptr, *dStage = nullptr, *dFull = nullptr;
     int *dIt = nullptr, *dFl = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_grid = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_grid = nullptr, ev_gather = nullptr, ev_end = nullptr;
     ncclComm_t comm = nullptr;
 };
 }  // namespace
@@ -214,7 +214,7 @@ void multi_free(pilot_ot_multi *m) {
         for (void *p : {(void *)s.dP, (void *)s.dM, (void *)s.dLocal, (void *)s.dErr, (void *)s.dStage, (void *)s.dFull,
                         (void *)s.dIt, (void *)s.dFl})
             if (p) (void)hipFree(p);
-        for (hipEvent_t e : {s.ev_begin, s.ev_grid, s.ev_end})
+        for (hipEvent_t e : {s.ev_begin, s.ev_grid, s.ev_gather, s.ev_end})
             if (e) (void)hipEventDestroy(e);
     }
     delete m;
@@ -261,6 +261,7 @@ PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shar
         }
         if (e == hipSuccess) e = hipEventCreate(&h.ev_begin);
         if (e == hipSuccess) e = hipEventCreate(&h.ev_grid);
+        if (e == hipSuccess) e = hipEventCreate(&h.ev_gather);
         if (e == hipSuccess) e = hipEventCreate(&h.ev_end);
         if (e != hipSuccess) { rc = fail(PILOT_OT_EHIP, "shard %d on device %d: %s", s, h.device, hipGetErrorString(e)); break; }
         rc = pilot_ot_plan_create(N, K, &h.plan);
@@ -310,6 +311,10 @@ int multi_gather(pilot_ot_multi *m, bool mirror) {
     if (m->gather == PILOT_OT_GATHER_RCCL) {
         RCCL_TRY(g_rccl.GroupStart());
         for (Shard &h : m->sh) {
+            HIP_TRY(hipSetDevice(h.device));
+            HIP_TRY(hipEventRecord(h.ev_gather, h.stream));
+        }
+        for (Shard &h : m->sh) {
             ncclResult_t r = g_rccl.AllGather(h.dLocal, h.dStage, n_loc, ncclDouble, h.comm, h.stream);
             if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(PILOT_OT_ERCCL, "ncclAllGather: %s", g_rccl.GetErrorString(r)); }
         }
@@ -325,9 +330,10 @@ int multi_gather(pilot_ot_multi *m, bool mirror) {
     }
     Shard &h0 = m->sh[0];
     HIP_TRY(hipSetDevice(h0.device));
+    for (int s = 1; s < m->G; ++s) HIP_TRY(hipStreamWaitEvent(h0.stream, m->sh[s].ev_grid, 0));
+    HIP_TRY(hipEventRecord(h0.ev_gather, h0.stream));      // every shard's rows are ready from here on
     for (int s = 0; s < m->G; ++s) {
         Shard &h = m->sh[s];
-        if (s > 0) HIP_TRY(hipStreamWaitEvent(h0.stream, h.ev_grid, 0));
         if (h.device == h0.device)
             HIP_TRY(hipMemcpyAsync(h0.dStage + s * n_loc, h.dLocal, sizeof(double) * n_loc, hipMemcpyDeviceToDevice, h0.stream));
         else
@@ -434,13 +440,18 @@ PILOT_API int pilot_ot_multi_times(pilot_ot_multi *m, float *grid_ms, float *gat
         HIP_TRY(hipSetDevice(m->sh[s].device));
         HIP_TRY(hipEventElapsedTime(&grid_ms[s], m->sh[s].ev_begin, m->sh[s].ev_grid));
     }
-    // the gather ends when shard 0's matrix is assembled; it can start only when the slowest shard is done
-    HIP_TRY(hipSetDevice(m->sh[0].device));
-    float total = 0.f;
-    HIP_TRY(hipEventElapsedTime(&total, m->sh[0].ev_begin, m->sh[0].ev_end));
-    float slowest = 0.f;
-    for (int s = 0; s < m->G; ++s) slowest = grid_ms[s] > slowest ? grid_ms[s] : slowest;
-    *gather_ms = total - slowest;
+    // gather = all-gather (or peer copies) + row interleave (+ mirror).  RCCL: a shard's collective also waits for its
+    // slower peers, so the collective's own cost is the SMALLEST per-shard (gather start -> matrix assembled) time; peer
+    // copies: shard 0's stream, measured from the point where every shard's rows are ready.
+    float best = -1.f;
+    const int n_meas = m->gather == PILOT_OT_GATHER_RCCL ? m->G : 1;
+    for (int s = 0; s < n_meas; ++s) {
+        HIP_TRY(hipSetDevice(m->sh[s].device));
+        float g = 0.f;
+        HIP_TRY(hipEventElapsedTime(&g, m->sh[s].ev_gather, m->sh[s].ev_end));
+        if (best < 0.f || g < best) best = g;
+    }
+    *gather_ms = best;
     return PILOT_OT_OK;
 }
 

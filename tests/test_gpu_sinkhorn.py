@@ -59,8 +59,8 @@ def test_small_reg_goes_through_absorption_tracking_f64():
     P, M = make_problem(**CONFIGS["c3"])
     rows = dict(row_begin=275, row_end=276, row_step=1)             # contains two known absorb-on-last pairs
     Eo, io = O.sinkhorn_grid(P, M, 0.01, n_threads=16, return_info=True, **rows)
-    Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="auto", return_info=True, **rows)
-    assert np.all((ig["flags"] & _lib.FLAG_F64) > 0)                 # auto -> f64 at max(M)/reg = 100
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="fp64", return_info=True, **rows)
+    assert np.all((ig["flags"] & _lib.FLAG_F64) > 0)
     assert np.abs(Eg - Eo).max() <= 1e-9
     np.testing.assert_array_equal(ig["iters"], io["iters"])
     hit_o = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0
