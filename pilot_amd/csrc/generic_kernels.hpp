@@ -23,6 +23,8 @@ struct GenericParams {
     double *emd; int *iters; double *err; int *flags;      // indexed by q = local_row * N + j (iters / err nullable)
     double *kws;               // per workgroup: K' (K x K, row-major) followed by its transpose
     int *queue;                // dynamic pair queue (zeroed by the host)
+    const int *list;           // nullable: explicit work-item list (pairs another kernel handed over), length *list_len
+    const int *list_len;
 };
 
 constexpr int GENERIC_WG = 256;
@@ -69,9 +71,10 @@ static __global__ void __launch_bounds__(GENERIC_WG) sinkhorn_generic_kernel(Gen
     for (;;) {
         if (threadIdx.x == 0) qs[0] = atomicAdd(p.queue, 1);
         __syncthreads();
-        const int q = qs[0];
+        const int item = qs[0];
         __syncthreads();
-        if (q >= p.n_pairs) break;
+        if (item >= (p.list_len ? *p.list_len : p.n_pairs)) break;
+        const int q = p.list ? p.list[item] : item;
         const int i_s = p.row_begin + (q / N) * p.row_step, j_s = q % N;
         for (int k = threadIdx.x; k < K; k += GENERIC_WG) {
             a[k] = p.P[(size_t)i_s * K + k]; b[k] = p.P[(size_t)j_s * K + k];

@@ -142,7 +142,7 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 constexpr int MAX_K = 128;          // the MFMA pair-grid kernels (8 row-tiles of 16 cell types)
 constexpr int GENERIC_MAX_K = 2048;  // the reference-semantics fallback kernel (vectors in LDS)
 constexpr int EMD_MAX_K = 256;       // exact-OT kernel: 4 rows / columns per lane
-constexpr int CTRL_INTS = 12;      // control block of a call: see pilot_ot_plan::track_count
+constexpr int CTRL_INTS = 16;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
@@ -166,7 +166,8 @@ struct pilot_ot_plan {
     int *track_count;  // [0] track-list length, [1] queue head of the fast launch, [2] queue head of the tracking launch,
                        // [3] queue head of the solo waves, [4..7] split of the ordered list: n_top, (unused copy), n_dup,
                        // n_dup = number of leading exact-duplicate pairs, [8] length of the f64 fallback list (mixed precision
-                       // at small reg), [9] its queue head
+                       // at small reg), [9] its queue head, [10] length of the NaN list (pairs re-solved by the POT-literal
+                       // kernel), [11] its queue head
     int *order_list;   // N x N: longest-first work order of the fast launch
     unsigned char *order_bucket;  // N x N
     int *order_hist;   // 2 * ORDER_NB: histogram + scatter cursors
@@ -176,6 +177,8 @@ struct pilot_ot_plan {
     double *f_slab;    // exact-EMD flow values: one K*K block per resident wave
     double *kws;       // generic Sinkhorn kernel: K' and its transpose per workgroup (allocated on first use)
     int generic_wgs;
+    int *nan_list;     // pairs that ended in NaN (grown on demand)
+    size_t nan_list_n;
     int n_cu;
     // event ring for per-launch kernel timing (bench.py roofline)
     int timing;                       // 0 off
@@ -291,7 +294,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
-    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0;
+    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
@@ -340,6 +343,7 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
     if (pl->f_slab) (void)hipFree(pl->f_slab);
     if (pl->kws) (void)hipFree(pl->kws);
+    if (pl->nan_list) (void)hipFree(pl->nan_list);
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) if (pl->ev[i][j]) (void)hipEventDestroy(pl->ev[i][j]);
     delete pl;
     return PILOT_OT_OK;
@@ -369,9 +373,10 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 // go to the reference-semantics kernel (generic_kernels.hpp), which rebuilds the absorbed kernel like POT.
 constexpr double MAX_COST_OVER_REG = 600.0;
 
+// list / list_len (device, nullable): only the listed pairs (NaN hand-over of the fast kernels); queue: zeroed counter
 int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max, double stop_thr, double tau,
                 int check_period, int row_begin, int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags,
-                hipStream_t s) {
+                hipStream_t s, const int *list = nullptr, const int *list_len = nullptr, int *queue = nullptr) {
     const int N = pl->N, K = pl->K;
     const int n_pairs = n_rows * N;
     if (n_pairs == 0) return PILOT_OT_OK;
@@ -394,12 +399,14 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
         }
         d_flags = pl->flags_ws;
     }
-    HIP_TRY(hipMemsetAsync(pl->track_count, 0, sizeof(int), s));
+    if (!queue) { queue = pl->track_count; HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), s)); }
     pilot::GenericParams g;
     g.P = d_P; g.M = d_M; g.N = N; g.K = K; g.n_pairs = n_pairs; g.row_begin = row_begin; g.row_step = row_step;
     g.reg = reg; g.tau = tau; g.stop_thr = stop_thr; g.max_iter = num_iter_max; g.period = check_period;
-    g.emd = d_emd; g.iters = d_iters; g.err = d_err; g.flags = d_flags; g.kws = pl->kws; g.queue = pl->track_count;
+    g.emd = d_emd; g.iters = d_iters; g.err = d_err; g.flags = d_flags; g.kws = pl->kws; g.queue = queue;
+    g.list = list; g.list_len = list_len;
     int wgs = pl->generic_wgs < n_pairs ? pl->generic_wgs : n_pairs;
+    if (list && wgs > 64) wgs = 64;          // a hand-over list is short (usually empty)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::sinkhorn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pilot::sinkhorn_generic_kernel, dim3(wgs), dim3(pilot::GENERIC_WG), lds, s, g);
     HIP_TRY(hipGetLastError());
@@ -511,6 +518,15 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
     p.ring = 0;
     p.fb_list = nullptr; p.fb_count = nullptr; p.bands = 1;
+    // pairs that end in NaN ("Numerical errors" in POT) are collected and re-solved by the POT-literal kernel, which
+    // returns the last good iterate like POT does
+    if ((size_t)n_pairs > pl->nan_list_n) {
+        if (pl->nan_list) HIP_TRY(hipFree(pl->nan_list));
+        pl->nan_list = nullptr; pl->nan_list_n = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->nan_list), sizeof(int) * (size_t)n_pairs));
+        pl->nan_list_n = (size_t)n_pairs;
+    }
+    p.nan_list = pl->nan_list; p.nan_count = pl->track_count + 10;
     p.debug = debug;
     const int tiles = (n_pairs + TILE - 1) / TILE;
     // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
@@ -587,6 +603,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         pilot::GridParams q = p;
         q.list = pl->track_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9;
         q.fb_list = nullptr; q.fb_count = nullptr; q.bands = 1;
+        q.nan_list = pl->nan_list; q.nan_count = pl->track_count + 10;
         const StreamLds L = stream_lds(fixed64, slot64, stream_min_waves(2, RT64, sym, true, 0, false));
         q.ring = L.ring;
         int wgs_t = pl->n_cu * L.wgs_per_cu;
@@ -595,6 +612,11 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         HIP_TRY(pilot::launch_stream_f64(RT64, sym, true, dim3(wgs_t), L.bytes, s, q));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
+    if (!(p.debug & 1024)) {
+        const int rc = run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows, row_step, d_emd, d_iters,
+                                   d_err, d_flags, s, pl->nan_list, pl->track_count + 10, pl->track_count + 11);
+        if (rc != PILOT_OT_OK) return rc;
+    }
     return PILOT_OT_OK;
 }
 

@@ -501,6 +501,8 @@ struct GridParams {
     int bands;            // bf16-split tracking kernel: 2 = the Gibbs kernel in two exponent bands (small reg), else 1
     int *fb_list;         // nullable (bf16-split configuration, small reg): pairs that went NaN / inf in f32 are appended here
     int *fb_count;        //   instead of being written out, and the f64 kernel solves them again (see ring_flush)
+    int *nan_list;        // nullable: pairs that end in NaN are appended here and re-solved by the POT-literal kernel, which
+    int *nan_count;       //   reverts to the last good iterate like POT does (generic_kernels.hpp)
     int debug;            // experiment switches (PILOT_OT_DEBUG): bit0 no priority, bit1 no longest-first order
 };
 
@@ -641,10 +643,14 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
                     val = wave_sum(live ? u * val : T(0));
                     if (lane == 0) {
                         if (val != val) flags |= FLAG_NAN;
-                        p.emd[q] = double(val);
-                        if (p.iters) p.iters[q] = ii;
-                        if (p.err) p.err[q] = double(errv);
-                        p.flags[q] = flags;
+                        if (p.nan_list && (flags & FLAG_NAN)) {
+                            p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
+                        } else {
+                            p.emd[q] = double(val);
+                            if (p.iters) p.iters[q] = ii;
+                            if (p.err) p.err[q] = double(errv);
+                            p.flags[q] = flags;
+                        }
                     }
                     break;
                 }
@@ -734,6 +740,8 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
         int fl = meta[1];
         if (redo || (p.fb_list && (fl & FLAG_NAN))) {
             p.fb_list[__hip_atomic_fetch_add(p.fb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
+        } else if (p.nan_list && (val != val || (fl & FLAG_NAN))) {
+            p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
         } else {
             if (val != val) fl |= FLAG_NAN;
             p.emd[qq] = double(val);

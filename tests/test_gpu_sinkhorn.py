@@ -132,6 +132,23 @@ def test_generic_kernel_is_pot_literal_including_absorption_and_tiny_reg():
     assert ((io["flags"] & 8) > 0).mean() > 0.9          # at reg 1e-3 nearly every pair absorbs
 
 
+def test_pairs_that_go_nan_are_resolved_like_pot():
+    """POT breaks out of a pair whose scalings become NaN and returns the cost of the last good iterate.  The
+    fast kernels hand such pairs to the POT-literal kernel instead of writing NaN: forcing the f32 kernel far outside its
+    range (max(M)/reg = 400: exp(-M/reg) underflows in f32) must leave no NaN behind, and every pair that was handed over
+    (flag F64) must carry the oracle's value, update count and flags."""
+    P, M = make_problem(**CONFIGS["c1"])
+    Eo, io = O.sinkhorn_grid(P, M, 0.0025, n_threads=16, return_info=True)
+    for prec in ("fp32", "bf16x3"):
+        Eg, ig = engine.sinkhorn_grid(P, M, 0.0025, precision=prec, return_info=True)
+        assert not np.isnan(Eg).any()
+        redone = (ig["flags"] & _lib.FLAG_F64) > 0
+        assert redone.any()
+        assert np.abs(Eg - Eo)[redone].max() <= 1e-10
+        np.testing.assert_array_equal(ig["iters"][redone], io["iters"][redone])
+        np.testing.assert_array_equal((ig["flags"] & 15)[redone], (io["flags"] & 15)[redone])
+
+
 @pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("fp64", TOL64)])
 def test_nonsymmetric_cost(prec, tol):
     rng = np.random.default_rng(4)
