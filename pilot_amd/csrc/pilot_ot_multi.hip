@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -44,7 +45,10 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+std::mutex g_rccl_mutex;
+
 int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);      // first use may come from several host threads at once
     if (g_rccl.h) return PILOT_OT_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
