@@ -77,16 +77,32 @@ __device__ inline void swap32_f64(double x, double &a, double &b) {
     p.u[0] = lo[0]; p.u[1] = hi[0]; q.u[0] = lo[1]; q.u[1] = hi[1];
     a = p.d; b = q.d;
 }
+template <int CTRL> __device__ inline unsigned int dpp_u32(unsigned int x) {
+    // (old = constant, bound_ctrl: every lane of these permutations is valid, and this form lets the compiler fold the move
+    // into the consumer: v_min_u32_dpp)
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+__device__ inline unsigned int wave_min_u32(unsigned int x) {
+    unsigned int y;
+    y = dpp_u32<0xB1>(x); x = y < x ? y : x;     // (mov_dpp + v_min_u32 fold into one v_min_u32_dpp)
+    y = dpp_u32<0x4E>(x); x = y < x ? y : x;
+    y = dpp_u32<0x141>(x); x = y < x ? y : x;
+    y = dpp_u32<0x140>(x); x = y < x ? y : x;
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    x = r[0] < r[1] ? r[0] : r[1];
+    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return r[0] < r[1] ? r[0] : r[1];
+}
+// Wave-wide minimum of NON-NEGATIVE doubles (Dijkstra labels, +inf included): their bit patterns order like unsigned
+// integers, so the minimum is the lexicographic minimum of (high word, low word) -- two 32-bit reductions with the DPP
+// modifier fused into v_min_u32 (~18 instructions) instead of six stages of 64-bit moves and v_min_f64 (~40).
 __device__ inline double wave_min_f64(double x) {
-    // (labels are never NaN, so v_min_f64 is the compare-and-select it replaces: 3 instead of 5 instructions per stage)
-    x = __builtin_fmin(x, dpp_f64<0xB1>(x));     // quad_perm(1,0,3,2): lane ^ 1
-    x = __builtin_fmin(x, dpp_f64<0x4E>(x));     // quad_perm(2,3,0,1): lane ^ 2
-    x = __builtin_fmin(x, dpp_f64<0x141>(x));    // row_half_mirror: the other quad of the octet
-    x = __builtin_fmin(x, dpp_f64<0x140>(x));    // row_mirror: the other octet of the row
-    double a, b;
-    swap16_f64(x, a, b); x = __builtin_fmin(a, b);      // the neighbouring row
-    swap32_f64(x, a, b); x = __builtin_fmin(a, b);      // the other half of the wave
-    return x;
+    union { double d; unsigned int u[2]; } v, o;
+    v.d = x;
+    const unsigned int mh = wave_min_u32(v.u[1]);
+    const unsigned int ml = wave_min_u32(v.u[1] == mh ? v.u[0] : 0xffffffffu);
+    o.u[0] = ml; o.u[1] = mh;
+    return o.d;
 }
 __device__ inline double wave_sum_f64(double x) {
     x += dpp_f64<0xB1>(x);
@@ -179,8 +195,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         int n_aug = 0;
-#ifdef EMD_COUNT_STEPS
-        int n_steps = 0;
+#ifdef EMD_STAT     // diagnostic builds: 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows in A rebuilds
+        int n_stat = 0;
 #endif
         const int aug_guard = 64 * K + 64;   // far above the O(K) augmentations SSP needs; bounds every loop
         bool tripped = false;
@@ -219,6 +235,9 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = srcmask[e];
                     while (m) {                                        // wave-uniform
+#if defined(EMD_STAT) && EMD_STAT == 4
+                        ++n_stat;
+#endif
                         const int l = __builtin_ctzll(m);
                         m &= m - 1ull;
                         const int in = l + 64 * e;
@@ -246,8 +265,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
             double dstar = 0.0;
             for (int step = 0;; ++step) {
                 if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: >= one node is scanned per step
-#ifdef EMD_COUNT_STEPS
-                ++n_steps;
+#if defined(EMD_STAT) && EMD_STAT == 1
+                ++n_stat;
 #endif
                 // smallest unscanned label; ALL nodes that carry it are final and are scanned in this one step (after the
                 // first augmentations most arcs around the sources are tight, so dozens of nodes tie at the same label)
@@ -296,6 +315,9 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = tieR[e];
                     while (m) {
+#if defined(EMD_STAT) && EMD_STAT == 2
+                        ++n_stat;
+#endif
                         const int l = __builtin_ctzll(m);
                         m &= m - 1ull;
                         const int in = l + 64 * e;
@@ -348,6 +370,9 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                         hb[e] = wl_i32(hb[e], jb, n_hops % 64);
                     }
                 ++n_hops;
+#if defined(EMD_STAT) && EMD_STAT == 3
+                ++n_stat;
+#endif
                 if (jb < 0) { src_row = i; break; }              // a source row
                 j = jb;
             }
@@ -428,8 +453,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
         cost = uni_f64(wave_sum_f64(cost));
         if (lane == 0) {
             p.emd[q] = tripped ? __builtin_nan("") : cost;
-#ifdef EMD_COUNT_STEPS
-            if (p.n_aug) p.n_aug[q] = n_steps;
+#ifdef EMD_STAT
+            if (p.n_aug) p.n_aug[q] = n_stat;
 #else
             if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;
 #endif
