@@ -752,9 +752,7 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
     __builtin_amdgcn_wave_barrier();
 }
 
-// (64 until round 2; with the cost flush as a call the RT = 4 f32 kernel no longer fits two waves per SIMD beside a
-// 64-register image)
-constexpr int GREG_MAX = 36;
+constexpr int GREG_MAX = 64;
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
 template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {

@@ -13,6 +13,7 @@ python bench.py --mode emd --config c4 --steps 2 --warmup 1 --no-cpu-baseline > 
 python bench.py --config c4 --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_c4_reg0.1_n1.json 2>> $O/bench.err
 python bench.py --config c2 --no-extras --no-cpu-baseline > $O/bench_c2_reg0.1_n1.json 2>> $O/bench.err
 python bench.py --precision fp32 --no-extras --no-cpu-baseline > $O/bench_c3_reg0.1_fp32_mfma.json 2>> $O/bench.err
+python bench.py --precision fp64 --no-extras --no-cpu-baseline > $O/bench_c3_reg0.1_fp64_mfma.json 2>> $O/bench.err
 python bench.py --mode cellw2 > $O/bench_cellw2_c5.json 2>> $O/bench.err
 python bench.py --gpus 2 --logical-shards --no-cpu-baseline > $O/bench_two_logical_shards_one_process.json 2>> $O/bench.err
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29544 python bench.py --gpus 1 --force-comm --no-cpu-baseline > $O/bench_one_rank_rccl_comm.json 2>> $O/bench.err
