@@ -200,7 +200,8 @@ int pilot_ot_multi_sync(pilot_ot_multi *m);
  * shard and interleaved on the host */
 int pilot_ot_multi_fetch(pilot_ot_multi *m, double *emd, int *iters, double *err, int *flags);
 int pilot_ot_multi_device_matrix(pilot_ot_multi *m, int shard, double **d_full);      /* the assembled matrix in HBM */
-/* HIP-event times of the last call: grid_ms[s] = shard s's kernels; gather_ms = end of the slowest shard -> matrix assembled */
+/* HIP-event times of the last call: grid_ms[s] = shard s's kernels; gather_ms = all-gather (or peer copies) + interleave: the
+ * smallest per-shard (gather start -> matrix assembled) time, since a shard's collective also waits for its slower peers */
 int pilot_ot_multi_times(pilot_ot_multi *m, float *grid_ms, float *gather_ms);
 /* host-buffer forms (context cached per calling thread, released by pilot_ot_shutdown) */
 int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const double *M, double reg, int num_iter_max,

@@ -236,7 +236,7 @@ __device__ inline void panel_product(const AOp &aop, const typename C::acc_t (&I
 // ceil(K/4) panel values it already holds (its lane group's share of the contraction index) with the matching
 // weights of TWO rows at once (f32: v_pk_fma_f32, ~8 pipe cycles; f64: two v_fma_f64), and the four lane-group partials of a column are
 // added with the permlane swaps.  13 pk-FMAs + one reduction replace 13 MFMAs at K = 50.  The element-wise loops skip
-// the three all-padding registers of that tile as well.  Every kernel variant (stream, tracking, cooperative) uses
+// the three all-padding registers of that tile as well.  Every kernel variant (stream, tracking) uses
 // this one function, so a pair's bits still do not depend on which kernel solves it.
 template <typename T> using pair_of = T __attribute__((ext_vector_type(2)));
 template <int RT> __host__ __device__ constexpr int tail_steps() { return (RT - 1) * 4 + 1; }   // k-steps when only register 0 of the last tile is live
@@ -1339,11 +1339,12 @@ __global__ void __launch_bounds__(256) sinkhorn_prep_kernel(const double *__rest
 // Every workgroup owns a contiguous chunk of items: LDS histogram of the chunk, ONE global atomic per
 // (workgroup, bucket) to reserve the range, then LDS cursors -- a handful of hot global addresses would
 // otherwise serialise all N^2 atomics.
-// `split` (3 ints, written by workgroup 0): [0] n_top = number of leading list items (the slowest pairs) that go to
-// the cooperative kernel, [1] initial head of the main kernel's queue (= n_top), [2] head of the cooperative queue (0).
+// `split` (4 ints, written by workgroup 0): [0], [1] = n_dup, the number of leading list items that the solo waves take (the
+// exact duplicates a == b: top bucket, first in the list) and the initial head of the tile queue; [2], [3] the same count for
+// the solo waves' own queue.  solo_mode bit 1: the launch carries solo waves.
 static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bucket, int n_items, const int *__restrict__ hist,
                                      int *__restrict__ cursor, int *__restrict__ list, int *__restrict__ split,
-                                     int *__restrict__ main_queue_head, int coop_enabled) {
+                                     int *__restrict__ main_queue_head, int solo_mode) {
     __shared__ int offs[ORDER_NB], lh[ORDER_NB], lbase[ORDER_NB], gh[ORDER_NB];
     if (threadIdx.x < ORDER_NB) { lh[threadIdx.x] = 0; gh[threadIdx.x] = hist[threadIdx.x]; }
     __syncthreads();
@@ -1353,20 +1354,9 @@ static __global__ void order_scatter_kernel(const unsigned char *__restrict__ bu
         offs[threadIdx.x] = run;
     }
     if (blockIdx.x == 0 && threadIdx.x == 64) {
-        // whole buckets from the top while they fit in 1/256 of the items; the top bucket (duplicates) always
-        int n_top = 0;
-        if (coop_enabled & 1) {
-            const int cap = n_items / 256 > gh[ORDER_NB - 1] ? n_items / 256 : gh[ORDER_NB - 1];
-            for (int b = ORDER_NB - 1; b >= 0; --b) {
-                if (n_top + gh[b] > cap) break;
-                n_top += gh[b];
-            }
-        }
-        // coop_enabled bit 1: the exact duplicates (top bucket, first in the list) go to solo_pairs, tiles start behind them
-        const int n_dup = (coop_enabled & 2) ? gh[ORDER_NB - 1] : 0;
-        if (n_top < n_dup) n_top = n_dup;      // no cooperative launch: the main queue starts behind the duplicates
-        split[0] = n_top; split[1] = n_top; split[2] = n_dup; split[3] = n_dup;
-        *main_queue_head = n_top;          // the main kernel's queue starts behind the cooperative head
+        const int n_dup = (solo_mode & 2) ? gh[ORDER_NB - 1] : 0;
+        split[0] = n_dup; split[1] = n_dup; split[2] = n_dup; split[3] = n_dup;
+        *main_queue_head = n_dup;          // the tile queue starts behind the duplicates
     }
     __syncthreads();
     const int chunk = (n_items + gridDim.x - 1) / gridDim.x;
