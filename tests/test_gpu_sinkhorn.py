@@ -132,6 +132,26 @@ def test_generic_kernel_is_pot_literal_including_absorption_and_tiny_reg():
     assert ((io["flags"] & 8) > 0).mean() > 0.9          # at reg 1e-3 nearly every pair absorbs
 
 
+@pytest.mark.parametrize("K,sym", [(40, False), (64, True), (21, True), (100, True)])
+def test_small_reg_two_exponent_bands_other_shapes(K, sym):
+    """precision='auto' beyond the f32 range (max(M)/reg = 90): f32 values with the Gibbs kernel in two exponent bands --
+    non-symmetric costs (both operand forms get a second band), K mod 16 in 1..4 (dead registers skipped), a K whose two
+    bands do not fit LDS (100: falls back to the f64 kernel).  Every pair within the f32 tolerance of the fp64 oracle."""
+    rng = np.random.default_rng(K)
+    P, M = make_problem(24, K, 8, seed=K, cells_per_patient=500)
+    if not sym:
+        M = rng.random((K, K)); M /= M.max()
+    reg = 1.0 / 90.0
+    Eo, io = O.sinkhorn_grid(P, M, reg, n_threads=16, return_info=True)
+    Eg, ig = engine.sinkhorn_grid(P, M, reg, precision="auto", return_info=True)
+    last = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+    assert np.isfinite(Eg).all()
+    assert np.abs(Eg - Eo)[~last].max() <= TOL32
+    assert np.all(ig["iters"] <= io["iters"])
+    f64 = (ig["flags"] & _lib.FLAG_F64) > 0
+    assert f64.all() if K == 100 else f64.mean() < 0.2
+
+
 def test_pairs_that_go_nan_are_resolved_like_pot():
     """POT breaks out of a pair whose scalings become NaN and returns the cost of the last good iterate.  The
     fast kernels hand such pairs to the POT-literal kernel instead of writing NaN: forcing the f32 kernel far outside its
