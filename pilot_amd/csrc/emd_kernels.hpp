@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
             for (int e = 0; e < NK; ++e) {
                 const bool src = ra[e] > tol && lane + 64 * e < K;
                 double rc = A[e] - pv[e];
-                rc = rc < 0.0 ? 0.0 : rc;
+                rc = __builtin_fmax(rc, 0.0);        // (one v_max_f64; rc is never NaN)
                 dR[e] = src ? 0.0 : INF; dC[e] = lane + 64 * e < K ? rc : INF; parR[e] = -1; parC[e] = Apar[e];
                 doneR[e] = src; doneC[e] = false;
             }
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                             const int idx = lane + 64 * e2;
                             if (idx < K && !doneC[e2]) {
                                 double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e2];
-                                rc = rc < 0.0 ? 0.0 : rc;
+                                rc = __builtin_fmax(rc, 0.0);        // (one v_max_f64; rc is never NaN)
                                 const double nd = bd + rc;
                                 if (nd < dC[e2]) { dC[e2] = nd; parC[e2] = in; }
                             }
