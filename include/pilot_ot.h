@@ -151,6 +151,11 @@ int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *plan, const double *d_P, const dou
  * first; *n_out = entries written. */
 int pilot_ot_plan_enable_timing(pilot_ot_plan *plan, int enable);
 int pilot_ot_plan_kernel_times(pilot_ot_plan *plan, int max_n, float *main_ms, float *track_ms, int *n_out);
+/* hipGraph replay for a caller that repeats one sinkhorn_grid_dev call (same buffers and arguments; the CONTENTS of
+ * P and M may change): the call's launch sequence (control-block memset, prep, order scatter, pair-grid kernel, tracking
+ * kernel, NaN hand-over) is captured on the second identical call and replayed as one graph launch from the third on.
+ * Any change of arguments falls back to ordinary launches and re-captures.  Off while kernel timing is enabled. */
+int pilot_ot_plan_enable_graph(pilot_ot_plan *plan, int enable);
 
 /* ---- exact OT pair grid: replaces the loop at Trajectory.py:507-511 (the reference default) ---- */
 /* Each pair returns the exact transportation-LP optimum, the value ot.emd2(a, b, M) returns

@@ -28,7 +28,7 @@ SYMBOLS = [
     "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
     "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
-    "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_shutdown",
+    "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_plan_enable_graph", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_centroid_medians", "pilot_ot_cell_w2_grid",
     "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
     "pilot_ot_mirror_upper_dev",
@@ -83,6 +83,7 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_auto_precision.argtypes = [c_dbl]
     L.pilot_ot_auto_precision_for.argtypes = [c_dbl, c_int, c_int]
     L.pilot_ot_plan_enable_timing.argtypes = [c_vp, c_int]
+    L.pilot_ot_plan_enable_graph.argtypes = [c_vp, c_int]
     L.pilot_ot_plan_kernel_times.argtypes = [c_vp, c_int, ctypes.POINTER(ctypes.c_float),
                                              ctypes.POINTER(ctypes.c_float), ip]
     L.pilot_ot_proportions.argtypes = [ip, ip, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int, c_dbl, c_int, dp]

@@ -184,6 +184,23 @@ struct pilot_ot_plan {
     int timing;                       // 0 off
     long n_timed;                     // calls recorded so far
     hipEvent_t ev[TIMING_RING][4];    // [slot]{main begin, main end, track begin, track end}
+    // hipGraph replay of a repeated Sinkhorn call (pilot_ot_plan_enable_graph): the launch sequence of one call captured
+    // on `gstream` and replayed on the caller's stream while the arguments stay the same
+    int graph_mode;                   // 0 off
+    int gkey_seen;                    // the key below was used by an ordinary (uncaptured) call: buffers are grown
+    struct GraphKey {
+        const void *P, *M, *emd, *iters, *err, *flags;
+        double reg, stop_thr, tau, floor_ulps;
+        int num_iter_max, check_period, cfg, mixed, sym, row_begin, n_rows, row_step, debug;
+        bool operator==(const GraphKey &o) const {
+            return P == o.P && M == o.M && emd == o.emd && iters == o.iters && err == o.err && flags == o.flags && reg == o.reg &&
+                   stop_thr == o.stop_thr && tau == o.tau && floor_ulps == o.floor_ulps && num_iter_max == o.num_iter_max &&
+                   check_period == o.check_period && cfg == o.cfg && mixed == o.mixed && sym == o.sym && row_begin == o.row_begin &&
+                   n_rows == o.n_rows && row_step == o.row_step && debug == o.debug;
+        }
+    } gkey;
+    hipStream_t gstream;
+    hipGraphExec_t gexec;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -298,6 +315,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
+    pl->graph_mode = 0; pl->gkey_seen = 0; pl->gstream = nullptr; pl->gexec = nullptr;
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) pl->ev[i][j] = nullptr;
     hipError_t e = hipGetDevice(&pl->device);
     if (e == hipSuccess) {
@@ -344,6 +362,8 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->f_slab) (void)hipFree(pl->f_slab);
     if (pl->kws) (void)hipFree(pl->kws);
     if (pl->nan_list) (void)hipFree(pl->nan_list);
+    if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
+    if (pl->gstream) (void)hipStreamDestroy(pl->gstream);
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) if (pl->ev[i][j]) (void)hipEventDestroy(pl->ev[i][j]);
     delete pl;
     return PILOT_OT_OK;
@@ -654,9 +674,48 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int cfg = mixed ? pilot::CFG_S32
                           : (precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : pilot::CFG_F64));
-    return run_grid(cfg, pl, d_P, d_M, reg, num_iter_max,
-                    stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0, row_begin, n_rows, row_step,
-                    d_emd, d_iters, d_err, d_flags, s, mixed);
+    auto run = [&](hipStream_t on) {
+        return run_grid(cfg, pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0,
+                        row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, on, mixed);
+    };
+    if (!pl->graph_mode || pl->timing || n_rows == 0) return run(s);
+    // graph replay: the first call with a new argument set runs as usual (and grows the work buffers), the second one is
+    // captured, later ones replay the instantiated graph
+    const char *dbg = getenv("PILOT_OT_DEBUG");
+    const pilot_ot_plan::GraphKey key = {d_P, d_M, d_emd, d_iters, d_err, d_flags, reg, stop_thr, tau, f32_floor_ulps, num_iter_max,
+                                         check_period, cfg, mixed ? 1 : 0, cost_is_symmetric != 0 ? 1 : 0, row_begin, n_rows, row_step,
+                                         dbg ? atoi(dbg) : 0};
+    if (pl->gexec && key == pl->gkey) {
+        HIP_TRY(hipGraphLaunch(pl->gexec, s));
+        return PILOT_OT_OK;
+    }
+    if (pl->gexec) { (void)hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; }
+    if (!(pl->gkey_seen && key == pl->gkey)) {
+        pl->gkey = key; pl->gkey_seen = 1;
+        return run(s);
+    }
+    if (!pl->gstream) HIP_TRY(hipStreamCreateWithFlags(&pl->gstream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(pl->gstream, hipStreamCaptureModeThreadLocal));
+    rc = run(pl->gstream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(pl->gstream, &graph);
+    if (rc != PILOT_OT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) { (void)hipGetLastError(); return fail(PILOT_OT_EHIP, "graph capture failed: %s", hipGetErrorString(ce)); }
+    const hipError_t ie = hipGraphInstantiate(&pl->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { (void)hipGetLastError(); pl->gexec = nullptr; return fail(PILOT_OT_EHIP, "graph instantiation failed: %s", hipGetErrorString(ie)); }
+    HIP_TRY(hipGraphLaunch(pl->gexec, s));
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_plan_enable_graph(pilot_ot_plan *pl, int enable) {
+    if (!pl) return fail(PILOT_OT_EINVAL, "plan is NULL");
+    pl->graph_mode = enable ? 1 : 0;
+    if (!enable) {
+        if (pl->gexec) { (void)hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; }
+        pl->gkey_seen = 0;
+    }
+    return PILOT_OT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -252,6 +252,10 @@ class DevicePlan:
     def enable_timing(self, enable=True):
         _lib.check(self.L.pilot_ot_plan_enable_timing(self.plan, int(enable)))
 
+    def enable_graph(self, enable=True):
+        """Replay repeated identical `run` calls as one hipGraph launch (pilot_ot_plan_enable_graph)."""
+        _lib.check(self.L.pilot_ot_plan_enable_graph(self.plan, int(enable)))
+
     def kernel_times_ms(self, max_n=64):
         """(main_ms, track_ms) float arrays of the most recent timed calls (sync the stream first)."""
         a = (ctypes.c_float * max_n)()

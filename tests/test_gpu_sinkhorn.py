@@ -241,6 +241,39 @@ def test_deterministic_across_runs():
     np.testing.assert_array_equal(a, b)
 
 
+def test_graph_replay_gives_the_same_bits_and_follows_argument_and_content_changes():
+    """pilot_ot_plan_enable_graph: the third identical call replays a captured hipGraph; results are bit-identical to
+    ordinary launches, a changed argument falls back (and re-captures), new CONTENTS of P are seen by the replay."""
+    P, M = make_problem(**CONFIGS["c2"])
+    N = P.shape[0]
+    plan = engine.DevicePlan(P, M)
+    ref = {}
+    for reg in (0.1, 0.02):
+        plan.run(reg)
+        ref[reg] = plan.fetch()
+    plan.enable_graph(True)
+    for reg in (0.1, 0.1, 0.1, 0.1, 0.02, 0.02, 0.02, 0.1, 0.1, 0.1):       # plain, capture, replay, replay, plain, capture, ...
+        plan.run(reg)
+        E, info = plan.fetch()
+        np.testing.assert_array_equal(E, ref[reg][0])
+        np.testing.assert_array_equal(info["iters"], ref[reg][1]["iters"])
+    part = np.array(ref[0.1][0][1::3])
+    for _ in range(4):
+        plan.run(0.1, row_begin=1, row_step=3)
+        np.testing.assert_array_equal(plan.fetch(n_rows=len(part))[0], part)
+    # same buffers, new contents: the replayed graph reads them
+    P2 = np.ascontiguousarray(P[::-1])
+    for _ in range(3):
+        plan.run(0.1)
+    _lib.check(plan.L.pilot_ot_memcpy_h2d(plan.dP, P2.ctypes.data, P2.nbytes))
+    plan.run(0.1)
+    np.testing.assert_array_equal(plan.fetch()[0], ref[0.1][0][::-1, ::-1])
+    plan.enable_graph(False)
+    plan.run(0.1)
+    np.testing.assert_array_equal(plan.fetch()[0], ref[0.1][0][::-1, ::-1])
+    plan.close()
+
+
 @pytest.mark.parametrize("reg,tau,lo,hi", [(0.1, 25.0, 0.1, 0.6), (0.05, 30.0, 0.8, 1.0)])
 def test_tau_tracking_path_mixes_with_the_fast_path(reg, tau, lo, hi):
     """A small tau makes a fraction of the pairs tau-absorb, so within one call some pairs finish in the

@@ -4,13 +4,22 @@ import sys, time, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pilot_amd import engine
 from pilot_amd.synthetic import make_problem, CONFIGS
-P, M = make_problem(**CONFIGS["c3"])
-pl = engine.DevicePlan(P, M); pl.enable_timing(True)
-for step in (1, 2, 4, 8):
-    for _ in range(3): pl.run(0.1, precision="fp32", row_begin=0, row_step=step)
+for cfg, reps in (("c3", 20), ("c4", 3)):
+    P, M = make_problem(**CONFIGS[cfg])
+    N = P.shape[0]
+    pl = engine.DevicePlan(P, M); pl.enable_timing(True)
+    for _ in range(150 if cfg == "c3" else 4): pl.run(0.1)          # clocks
     pl.sync()
-    t = time.perf_counter()
-    for _ in range(10): pl.run(0.1, precision="fp32", row_begin=0, row_step=step)
-    pl.sync(); dt = (time.perf_counter() - t) / 10
-    a, b = pl.kernel_times_ms(10)
-    print("PILOT_OT_DEBUG=%s rows 0::%d (%d pairs): main kernel %.3f ms, whole call %.3f ms" % (os.environ.get("PILOT_OT_DEBUG", "0"), step, 360000 // step, a.mean(), dt * 1e3))
+    _, info = pl.fetch()
+    it = info["iters"]
+    print("%s: updates per pair mean %.1f, p99 %d, p99.9 %d, max %d; max off-diagonal %d" % (
+        cfg, it.mean(), np.percentile(it, 99), np.percentile(it, 99.9), it.max(), (it - np.diag(np.diag(it))).max()))
+    for step in (1, 2, 4, 8):
+        for _ in range(3): pl.run(0.1, row_begin=0, row_step=step)
+        pl.sync()
+        t = time.perf_counter()
+        for _ in range(reps): pl.run(0.1, row_begin=0, row_step=step)
+        pl.sync(); dt = (time.perf_counter() - t) / reps
+        a, b = pl.kernel_times_ms(reps)
+        print("%s rows 0::%d (%d pairs): main kernel %.3f ms, track %.3f ms, whole call %.3f ms" % (cfg, step, N * N // step, a.mean(), b.mean(), dt * 1e3))
+    pl.close()
