@@ -93,14 +93,19 @@ __device__ inline unsigned int wave_min_u32(unsigned int x) {
     r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return r[0] < r[1] ? r[0] : r[1];
 }
-// Wave-wide minimum of NON-NEGATIVE doubles (Dijkstra labels, +inf included): their bit patterns order like unsigned
-// integers, so the minimum is the lexicographic minimum of (high word, low word) -- two 32-bit reductions with the DPP
-// modifier fused into v_min_u32 (~18 instructions) instead of six stages of 64-bit moves and v_min_f64 (~40).
+// Wave-wide minimum of doubles whose bit patterns order like unsigned integers (non-negative values, +inf included;
+// "done" entries are -1.0, whose pattern is above every non-negative one): the minimum is the lexicographic minimum of
+// (high word, low word).  The high words take one 32-bit reduction with the DPP modifier fused into v_min_u32; the low
+// word of the winner is then read straight from its lane when every lane that shares the minimal high word also shares
+// the low word (a unique minimum, or exact ties -- the usual cases: labels of a Dijkstra step either differ in their
+// leading 32 bits or are the same number); only otherwise a second reduction runs.
 __device__ inline double wave_min_f64(double x) {
     union { double d; unsigned int u[2]; } v, o;
     v.d = x;
     const unsigned int mh = wave_min_u32(v.u[1]);
-    const unsigned int ml = wave_min_u32(v.u[1] == mh ? v.u[0] : 0xffffffffu);
+    const unsigned long long top = __ballot(v.u[1] == mh);
+    unsigned int ml = (unsigned int)__builtin_amdgcn_readlane((int)v.u[0], __builtin_ctzll(top));
+    if (__ballot(v.u[1] == mh && v.u[0] != ml)) ml = wave_min_u32(v.u[1] == mh ? v.u[0] : 0xffffffffu);   // wave-uniform
     o.u[0] = ml; o.u[1] = mh;
     return o.d;
 }
@@ -115,8 +120,27 @@ __device__ inline double wave_sum_f64(double x) {
     return x;
 }
 
-// lane-indexed scalar helpers for the path registers
-__device__ inline int wl_i32(int old, int value, int lane) { return (int)(threadIdx.x % 64) == lane ? value : old; }
+// lane `lane` of `old` <- the wave-uniform `value` (v_writelane_b32: one instruction instead of compare + select; gfx950
+// reads at most one SGPR per VALU instruction, so the lane select travels in M0)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"       // M0 is reserved (never live across statements); the clobber is declared anyway
+__device__ inline int wl_i32(int old, int value, int lane) {
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(lane) : "m0");
+    return old;
+}
+#pragma clang diagnostic pop
+__device__ inline unsigned int hi_word(double x) {
+    union { double d; unsigned int u[2]; } v;
+    v.d = x;
+    return v.u[1];
+}
+// order of the bit patterns (see wave_min_f64)
+__device__ inline bool bits_less(double a, double b) {
+    union { double d; unsigned long long u; } x, y;
+    x.d = a; y.d = b;
+    return x.u < y.u;
+}
+
 
 // NK = rows/columns per lane (1: K <= 64, 2: K <= 128).
 //   * the cost matrix M and its row minima live in LDS (shared by the workgroup);
@@ -147,7 +171,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
     }
     __syncthreads();
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
-    const double INF = __builtin_inf();
+    const double INF = __builtin_inf(), NEG = -1.0;
     const long total = (long)p.n_rows * N;
 
     // pairs are dealt round-robin to the resident waves (wave-uniform loop bounds)
@@ -158,9 +182,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
         const int i_s = p.row_begin + r * p.row_step;
         if (p.upper_only && j_s < i_s) continue;   // wave-uniform
 
-        double pu[NK], pv[NK], ra[NK], rb[NK], dR[NK], dC[NK];
+        double pu[NK], pv[NK], ra[NK], rb[NK], dC[NK];
         int parR[NK], parC[NK];
-        bool doneR[NK], doneC[NK];
         unsigned long long ship[NK][NK];           // ship[e][w] bit b: row (lane + 64e) ships to column 64w + b
         // POT pre-step: b *= sum(a) / sum(b)   (ot/lp/__init__.py::emd2)
         double sa = 0.0, sb = 0.0;
@@ -253,13 +276,21 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                     }
                 }
             }
+            // Labels.  Columns: dC is the tentative distance while the column is open and NEG (-1) once it is scanned (or
+            // beyond K) -- as bit patterns NEG sorts above every distance and above +inf, so the arg-min, the tie test and
+            // the relaxation need no "scanned" flag; fC keeps the final distance (+inf: never scanned).  Rows are never
+            // pending: a row is reached only over a zero-reduced-cost backward arc from a column being scanned, takes that
+            // column's label and is scanned in the same step; fR is its final distance (0 for the sources, +inf: not reached).
+            double fR[NK], fC[NK];
+            unsigned long long demand[NK];
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
-                const bool src = ra[e] > tol && lane + 64 * e < K;
-                double rc = A[e] - pv[e];
-                rc = __builtin_fmax(rc, 0.0);        // (one v_max_f64; rc is never NaN)
-                dR[e] = src ? 0.0 : INF; dC[e] = lane + 64 * e < K ? rc : INF; parR[e] = -1; parC[e] = Apar[e];
-                doneR[e] = src; doneC[e] = false;
+                const bool valid = lane + 64 * e < K;
+                const bool src = ra[e] > tol && valid;
+                const double rc = __builtin_fmax(A[e] - pv[e], 0.0);        // (one v_max_f64; rc is never NaN)
+                dC[e] = valid ? rc + 0.0 : NEG; fC[e] = INF; parC[e] = Apar[e];   // (+ 0.0: never -0, whose pattern would sort last)
+                fR[e] = src ? 0.0 : INF; parR[e] = -1;
+                demand[e] = __ballot(rb[e] > 0.0);                          // (rb is 0 beyond K)
             }
             int target = -1;
             double dstar = 0.0;
@@ -268,49 +299,40 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
 #if defined(EMD_STAT) && EMD_STAT == 1
                 ++n_stat;
 #endif
-                // smallest unscanned label; ALL nodes that carry it are final and are scanned in this one step (after the
+                // smallest open label; ALL columns that carry it are final and are scanned in this one step (after the
                 // first augmentations most arcs around the sources are tight, so dozens of nodes tie at the same label)
-                double best = INF;
+                double best = dC[0];
 #pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    const int idx = lane + 64 * e;
-                    if (idx < K) {
-                        if (!doneC[e] && dC[e] < best) best = dC[e];
-                        if (!doneR[e] && dR[e] < best) best = dR[e];
-                    }
-                }
+                for (int e = 1; e < NK; ++e) best = bits_less(dC[e], best) ? dC[e] : best;
                 const double bd = uni_f64(wave_min_f64(best));
-                if (!(bd < INF)) break;                        // nothing reachable: only rounding dust left
+                if (hi_word(bd) >= 0x7ff00000u) break;         // +inf or NEG: nothing reachable, only rounding dust left
                 unsigned long long tieC[NK], tieR[NK];
                 bool found = false;
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
-                    const bool tc = lane + 64 * e < K && !doneC[e] && dC[e] == bd;
+                    const bool tc = dC[e] == bd;
                     tieC[e] = __ballot(tc);
-                    const unsigned long long dm = __ballot(tc && rb[e] > 0.0);    // a column with demand left: done
+                    const unsigned long long dm = tieC[e] & demand[e];           // a column with demand left: done
                     if (dm && !found) { target = __builtin_ctzll(dm) + 64 * e; dstar = bd; found = true; }
-                    if (tc) doneC[e] = true;
+                    if (tc) { fC[e] = bd; dC[e] = NEG; }
                 }
                 if (found) break;
                 // columns: backward arcs to the rows that ship to ANY of the tied columns (reduced cost 0): the ballot
                 // mask of the tied columns IS a column bit mask, so one AND with the row's support finds them
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
-                    if (!doneR[e] && bd < dR[e]) {
+                    unsigned long long hit = 0ull;
+                    int wsel = 0;
 #pragma unroll
-                        for (int w = 0; w < NK; ++w) {
-                            const unsigned long long hit = ship[e][w] & tieC[w];
-                            if (hit) { dR[e] = bd; parR[e] = __builtin_ctzll(hit) + 64 * w; }
-                        }
+                    for (int w = 0; w < NK; ++w) {
+                        const unsigned long long h = ship[e][w] & tieC[w];
+                        if (h) { hit = h; wsel = w; }
                     }
+                    const bool reach = hit != 0ull && fR[e] == INF;
+                    tieR[e] = __ballot(reach);
+                    if (reach) { parR[e] = __builtin_ctzll(hit) + 64 * wsel; fR[e] = bd; }
                 }
-                // rows (including the ones that just got this label): forward arcs to every column
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    const bool tr = lane + 64 * e < K && !doneR[e] && dR[e] == bd;
-                    tieR[e] = __ballot(tr);
-                    if (tr) doneR[e] = true;
-                }
+                // those rows: forward arcs to every open column
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = tieR[e];
@@ -325,11 +347,11 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
                             const int idx = lane + 64 * e2;
-                            if (idx < K && !doneC[e2]) {
+                            if (idx < K) {                                   // (guards the read of M only: dC is NEG beyond K)
                                 double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e2];
-                                rc = __builtin_fmax(rc, 0.0);        // (one v_max_f64; rc is never NaN)
+                                rc = __builtin_fmax(rc, 0.0);
                                 const double nd = bd + rc;
-                                if (nd < dC[e2]) { dC[e2] = nd; parC[e2] = in; }
+                                if (nd < dC[e2]) { dC[e2] = nd; parC[e2] = in; }     // never true for a scanned column (NEG)
                             }
                         }
                     }
@@ -344,11 +366,13 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
             // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the path
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
-                pu[e] -= dR[e] < dstar ? dR[e] : dstar;
-                pv[e] += dC[e] < dstar ? dC[e] : dstar;
+                pu[e] -= __builtin_fmin(fR[e], dstar);          // (not reached: +inf)
+                pv[e] += __builtin_fmin(fC[e], dstar);
             }
             // walk target <- ... <- source row once with wave-uniform indices; hop h is recorded in lane h (h % 64, slot
-            // h / 64): forward arc (hi -> hj) gains flow, backward arc (hi -> hb) loses it (hb < 0 at the source row)
+            // h / 64; v_writelane): forward arc (hi -> hj) gains flow, backward arc (hi -> hb) loses it (hb < 0 at the
+            // source row).  The forward arcs enter the support right here (the bottleneck is positive: support arcs carry
+            // flow > 0, the source has supply > tol, the target demand > 0).
             int hi[NK], hj[NK], hb[NK];
 #pragma unroll
             for (int e = 0; e < NK; ++e) { hi[e] = 0; hj[e] = 0; hb[e] = -1; }
@@ -369,6 +393,12 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                         hj[e] = wl_i32(hj[e], j, n_hops % 64);
                         hb[e] = wl_i32(hb[e], jb, n_hops % 64);
                     }
+#pragma unroll
+                for (int e = 0; e < NK; ++e)
+                    if (lane + 64 * e == i) {
+#pragma unroll
+                        for (int w = 0; w < NK; ++w) if (w == j / 64) ship[e][w] |= 1ull << (j % 64);
+                    }
                 ++n_hops;
 #if defined(EMD_STAT) && EMD_STAT == 3
                 ++n_stat;
@@ -377,15 +407,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 j = jb;
             }
             if (tripped) break;
-            // bottleneck: all backward-arc flows at once
-            double fb[NK], fmin = INF;
-#pragma unroll
-            for (int e = 0; e < NK; ++e) {
-                const bool act = lane + 64 * e < n_hops;
-                fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
-                fmin = fb[e] < fmin ? fb[e] : fmin;
-            }
-            double delta = wave_min_f64(fmin);
+            double delta;
             {
                 double rb_t = 0.0, ra_s = 0.0;
 #pragma unroll
@@ -393,41 +415,51 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                     if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
                     if (e == src_row / 64) ra_s = rl_f64(ra[e], src_row % 64);
                 }
-                delta = rb_t < delta ? rb_t : delta;
-                delta = uni_f64(ra_s < delta ? ra_s : delta);
+                delta = rb_t < ra_s ? rb_t : ra_s;
             }
-            // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
-            unsigned long long emptied[NK];
+            if (n_hops == 1) {          // (wave-uniform) the source ships straight to the target: no backward arc
+                if (lane == 0) F[(size_t)src_row * K + target] += delta;
+            } else {
+                // bottleneck: all backward-arc flows at once
+                double fb[NK], fmin = INF;
 #pragma unroll
-            for (int e = 0; e < NK; ++e) {
-                const bool act = lane + 64 * e < n_hops;
-                if (act) {
-                    F[(size_t)hi[e] * K + hj[e]] += delta;
-                    if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
+                for (int e = 0; e < NK; ++e) {
+                    const bool act = lane + 64 * e < n_hops;
+                    fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
+                    fmin = fb[e] < fmin ? fb[e] : fmin;
                 }
-                emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
+                const double fm = wave_min_f64(fmin);
+                delta = uni_f64(fm < delta ? fm : delta);
+                // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
+                unsigned long long emptied[NK];
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    const bool act = lane + 64 * e < n_hops;
+                    if (act) {
+                        F[(size_t)hi[e] * K + hj[e]] += delta;
+                        if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
+                    }
+                    emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
+                }
+                // backward arcs that ran empty leave the support
+#pragma unroll
+                for (int e = 0; e < NK; ++e) {
+                    unsigned long long m = emptied[e];
+                    while (m) {                                    // wave-uniform, usually no or one arc
+                        const int h = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const int i = rl_i32(hi[e], h), jb = rl_i32(hb[e], h);
+#pragma unroll
+                        for (int e2 = 0; e2 < NK; ++e2)
+                            if (lane + 64 * e2 == i) {
+#pragma unroll
+                                for (int w = 0; w < NK; ++w) if (w == jb / 64) ship[e2][w] &= ~(1ull << (jb % 64));
+                            }
+                    }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            // flow support: set the forward bits, clear the backward bits of the arcs that ran empty
-            for (int h = 0; h < n_hops; ++h) {
-                int i = 0, j = 0, jb = 0;
-#pragma unroll
-                for (int e = 0; e < NK; ++e)
-                    if (e == h / 64) { i = rl_i32(hi[e], h % 64); j = rl_i32(hj[e], h % 64); jb = rl_i32(hb[e], h % 64); }
-                bool gone = false;
-#pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == h / 64) gone = (emptied[e] >> (h % 64)) & 1ull;
-#pragma unroll
-                for (int e = 0; e < NK; ++e)
-                    if (lane + 64 * e == i) {
-#pragma unroll
-                        for (int w = 0; w < NK; ++w) {
-                            if (w == j / 64) ship[e][w] |= 1ull << (j % 64);
-                            if (gone && w == jb / 64) ship[e][w] &= ~(1ull << (jb % 64));
-                        }
-                    }
-            }
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
                 if (lane + 64 * e == src_row) ra[e] -= delta;
