@@ -217,8 +217,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        int n_aug = 0;
-#ifdef EMD_STAT     // diagnostic builds: 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows in A rebuilds
+        int n_aug = 0, n_search = 0;
+#ifdef EMD_STAT     // diagnostic builds: 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows in A rebuilds, 5 searches
         int n_stat = 0;
 #endif
         const int aug_guard = 64 * K + 64;   // far above the O(K) augmentations SSP needs; bounds every loop
@@ -227,9 +227,9 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
         const unsigned long long t_start = wall_clock64();
         const unsigned long long watchdog_ticks = 400000000ull;  // 4 s of the 100 MHz constant clock per pair
 
-        // One augmentation per round: shortest path from ANY row that still has supply to ANY column that still has
-        // demand (multi-source Dijkstra on the reduced costs).  All source rows are relaxed up front without an arg-min
-        // each, and every step scans ALL nodes tied at the smallest label.
+        // One search per round: shortest paths from ANY row that still has supply to the columns that still have demand
+        // (multi-source Dijkstra on the reduced costs), with as many augmentations as the tree survives.  All source rows
+        // are relaxed up front without an arg-min each, and every step scans ALL nodes tied at the smallest label.
         unsigned long long prev_src[NK];
         double A[NK];
         int Apar[NK];
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
             }
             if (!any_src) break;
             if (n_aug > aug_guard) { tripped = true; trip_code = 5; break; }
-            if ((n_aug & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
+            if ((n_search & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
             // initial column labels min over sources i of rc(i, j) = (A_j - pv_j)+ with A_j = min_i (M_ij - pu_i): a source's
             // potential never moves (its distance is 0), so A and its arg-min only change when a source runs dry
             bool src_changed = false;
@@ -292,8 +292,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 fR[e] = src ? 0.0 : INF; parR[e] = -1;
                 demand[e] = __ballot(rb[e] > 0.0);                          // (rb is 0 beyond K)
             }
-            int target = -1;
             double dstar = 0.0;
+            bool exhausted = false;
             for (int step = 0;; ++step) {
                 if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: >= one node is scanned per step
 #if defined(EMD_STAT) && EMD_STAT == 1
@@ -305,18 +305,133 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
 #pragma unroll
                 for (int e = 1; e < NK; ++e) best = bits_less(dC[e], best) ? dC[e] : best;
                 const double bd = uni_f64(wave_min_f64(best));
-                if (hi_word(bd) >= 0x7ff00000u) break;         // +inf or NEG: nothing reachable, only rounding dust left
+                if (hi_word(bd) >= 0x7ff00000u) { exhausted = true; break; }   // +inf or NEG: nothing reachable, only rounding dust left
                 unsigned long long tieC[NK], tieR[NK];
-                bool found = false;
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     const bool tc = dC[e] == bd;
                     tieC[e] = __ballot(tc);
-                    const unsigned long long dm = tieC[e] & demand[e];           // a column with demand left: done
-                    if (dm && !found) { target = __builtin_ctzll(dm) + 64 * e; dstar = bd; found = true; }
                     if (tc) { fC[e] = bd; dC[e] = NEG; }
                 }
-                if (found) break;
+                // Tied columns with demand left are targets: augment along the tree path right away, WITHOUT touching the
+                // potentials.  If that only saturated the target (the source keeps supply, no backward arc ran empty) the
+                // shortest-path tree is still valid -- the new support arcs join scanned nodes and are tight -- and the
+                // search simply goes on with the target as one more scanned column; otherwise the potentials are brought up
+                // to date with the labels (d* = this step's label) and a new search starts.
+                bool broke = false;
+#pragma unroll
+                for (int et = 0; et < NK; ++et) {
+                    unsigned long long dm = broke || tripped ? 0ull : (tieC[et] & demand[et]);
+                    while (dm) {                                   // wave-uniform
+                        const int target = __builtin_ctzll(dm) + 64 * et;
+                        dm &= dm - 1ull;
+                        // walk target <- ... <- source row once with wave-uniform indices; hop h is recorded in lane h (h % 64, slot
+                        // h / 64; v_writelane): forward arc (hi -> hj) gains flow, backward arc (hi -> hb) loses it (hb < 0 at the
+                        // source row).  The forward arcs enter the support right here (the bottleneck is positive: support arcs carry
+                        // flow > 0, the source has supply > tol, the target demand > 0).
+                        int hi[NK], hj[NK], hb[NK];
+#pragma unroll
+                        for (int e = 0; e < NK; ++e) { hi[e] = 0; hj[e] = 0; hb[e] = -1; }
+                        int n_hops = 0, src_row = -1;
+                        for (int j = target;;) {
+                            if (n_hops >= 64 * NK || j < 0) { tripped = true; trip_code = 2; break; }
+                            int i = 0;
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
+                            if (i < 0) { tripped = true; trip_code = 3; break; }
+                            int jb = 0;
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
+#pragma unroll
+                            for (int e = 0; e < NK; ++e)
+                                if (e == n_hops / 64) {
+                                    hi[e] = wl_i32(hi[e], i, n_hops % 64);
+                                    hj[e] = wl_i32(hj[e], j, n_hops % 64);
+                                    hb[e] = wl_i32(hb[e], jb, n_hops % 64);
+                                }
+#pragma unroll
+                            for (int e = 0; e < NK; ++e)
+                                if (lane + 64 * e == i) {
+#pragma unroll
+                                    for (int w = 0; w < NK; ++w) if (w == j / 64) ship[e][w] |= 1ull << (j % 64);
+                                }
+                            ++n_hops;
+#if defined(EMD_STAT) && EMD_STAT == 3
+                            ++n_stat;
+#endif
+                            if (jb < 0) { src_row = i; break; }              // a source row
+                            j = jb;
+                        }
+                        if (tripped) break;
+                        double delta;
+                        {
+                            double rb_t = 0.0, ra_s = 0.0;
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) {
+                                if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
+                                if (e == src_row / 64) ra_s = rl_f64(ra[e], src_row % 64);
+                            }
+                            delta = rb_t < ra_s ? rb_t : ra_s;
+                        }
+                        if (n_hops == 1) {          // (wave-uniform) the source ships straight to the target: no backward arc
+                            if (lane == 0) F[(size_t)src_row * K + target] += delta;
+                        } else {
+                            // bottleneck: all backward-arc flows at once
+                            double fb[NK], fmin = INF;
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) {
+                                const bool act = lane + 64 * e < n_hops;
+                                fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
+                                fmin = fb[e] < fmin ? fb[e] : fmin;
+                            }
+                            const double fm = wave_min_f64(fmin);
+                            delta = uni_f64(fm < delta ? fm : delta);
+                            // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
+                            unsigned long long emptied[NK];
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) {
+                                const bool act = lane + 64 * e < n_hops;
+                                if (act) {
+                                    F[(size_t)hi[e] * K + hj[e]] += delta;
+                                    if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
+                                }
+                                emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
+                                if (emptied[e]) broke = true;          // a tree arc is gone
+                            }
+                            // backward arcs that ran empty leave the support
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) {
+                                unsigned long long m = emptied[e];
+                                while (m) {                                    // wave-uniform, usually no or one arc
+                                    const int h = __builtin_ctzll(m);
+                                    m &= m - 1ull;
+                                    const int i = rl_i32(hi[e], h), jb = rl_i32(hb[e], h);
+#pragma unroll
+                                    for (int e2 = 0; e2 < NK; ++e2)
+                                        if (lane + 64 * e2 == i) {
+#pragma unroll
+                                            for (int w = 0; w < NK; ++w) if (w == jb / 64) ship[e2][w] &= ~(1ull << (jb % 64));
+                                        }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        bool dry = false;
+#pragma unroll
+                        for (int e = 0; e < NK; ++e) {
+                            if (lane + 64 * e == src_row) { ra[e] -= delta; dry = !(ra[e] > tol); }
+                            if (lane + 64 * e == target) rb[e] -= delta;
+                        }
+                        ++n_aug;
+                        if (__ballot(dry)) broke = true;
+                        if (et < NK) demand[et] = __ballot(rb[et] > 0.0);
+                        if ((demand[et] >> (target % 64)) & 1ull) broke = true;      // target not saturated: the tree changed
+                        if (broke) break;
+                    }
+                }
+                if (tripped) break;
+                if (broke) { dstar = bd; break; }
                 // columns: backward arcs to the rows that ship to ANY of the tied columns (reduced cost 0): the ballot
                 // mask of the tied columns IS a column bit mask, so one AND with the row's support finds them
 #pragma unroll
@@ -358,114 +473,21 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 }
             }
             if (tripped) break;
-            if (target < 0) {   // numerically exhausted: drop the dust (<= tol-scale mass) of every remaining source
+            if (exhausted) {    // numerically exhausted: drop the dust (<= tol-scale mass) of every remaining source
 #pragma unroll
                 for (int e = 0; e < NK; ++e) ra[e] = 0.0;
                 break;
             }
-            // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the path
+            // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the tree (so on every path used)
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
                 pu[e] -= __builtin_fmin(fR[e], dstar);          // (not reached: +inf)
                 pv[e] += __builtin_fmin(fC[e], dstar);
             }
-            // walk target <- ... <- source row once with wave-uniform indices; hop h is recorded in lane h (h % 64, slot
-            // h / 64; v_writelane): forward arc (hi -> hj) gains flow, backward arc (hi -> hb) loses it (hb < 0 at the
-            // source row).  The forward arcs enter the support right here (the bottleneck is positive: support arcs carry
-            // flow > 0, the source has supply > tol, the target demand > 0).
-            int hi[NK], hj[NK], hb[NK];
-#pragma unroll
-            for (int e = 0; e < NK; ++e) { hi[e] = 0; hj[e] = 0; hb[e] = -1; }
-            int n_hops = 0, src_row = -1;
-            for (int j = target;;) {
-                if (n_hops >= 64 * NK || j < 0) { tripped = true; trip_code = 2; break; }
-                int i = 0;
-#pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
-                if (i < 0) { tripped = true; trip_code = 3; break; }
-                int jb = 0;
-#pragma unroll
-                for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
-#pragma unroll
-                for (int e = 0; e < NK; ++e)
-                    if (e == n_hops / 64) {
-                        hi[e] = wl_i32(hi[e], i, n_hops % 64);
-                        hj[e] = wl_i32(hj[e], j, n_hops % 64);
-                        hb[e] = wl_i32(hb[e], jb, n_hops % 64);
-                    }
-#pragma unroll
-                for (int e = 0; e < NK; ++e)
-                    if (lane + 64 * e == i) {
-#pragma unroll
-                        for (int w = 0; w < NK; ++w) if (w == j / 64) ship[e][w] |= 1ull << (j % 64);
-                    }
-                ++n_hops;
-#if defined(EMD_STAT) && EMD_STAT == 3
-                ++n_stat;
+            ++n_search;
+#if defined(EMD_STAT) && EMD_STAT == 5
+            ++n_stat;
 #endif
-                if (jb < 0) { src_row = i; break; }              // a source row
-                j = jb;
-            }
-            if (tripped) break;
-            double delta;
-            {
-                double rb_t = 0.0, ra_s = 0.0;
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
-                    if (e == src_row / 64) ra_s = rl_f64(ra[e], src_row % 64);
-                }
-                delta = rb_t < ra_s ? rb_t : ra_s;
-            }
-            if (n_hops == 1) {          // (wave-uniform) the source ships straight to the target: no backward arc
-                if (lane == 0) F[(size_t)src_row * K + target] += delta;
-            } else {
-                // bottleneck: all backward-arc flows at once
-                double fb[NK], fmin = INF;
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    const bool act = lane + 64 * e < n_hops;
-                    fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
-                    fmin = fb[e] < fmin ? fb[e] : fmin;
-                }
-                const double fm = wave_min_f64(fmin);
-                delta = uni_f64(fm < delta ? fm : delta);
-                // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
-                unsigned long long emptied[NK];
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    const bool act = lane + 64 * e < n_hops;
-                    if (act) {
-                        F[(size_t)hi[e] * K + hj[e]] += delta;
-                        if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
-                    }
-                    emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
-                }
-                // backward arcs that ran empty leave the support
-#pragma unroll
-                for (int e = 0; e < NK; ++e) {
-                    unsigned long long m = emptied[e];
-                    while (m) {                                    // wave-uniform, usually no or one arc
-                        const int h = __builtin_ctzll(m);
-                        m &= m - 1ull;
-                        const int i = rl_i32(hi[e], h), jb = rl_i32(hb[e], h);
-#pragma unroll
-                        for (int e2 = 0; e2 < NK; ++e2)
-                            if (lane + 64 * e2 == i) {
-#pragma unroll
-                                for (int w = 0; w < NK; ++w) if (w == jb / 64) ship[e2][w] &= ~(1ull << (jb % 64));
-                            }
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < NK; ++e) {
-                if (lane + 64 * e == src_row) ra[e] -= delta;
-                if (lane + 64 * e == target) rb[e] -= delta;
-            }
-            ++n_aug;
         }
         // cost = sum over the support of F_ij * M_ij (lane i walks the bits of row i)
         double cost = 0.0;

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Diagnostic builds of the exact-OT kernel that report a per-pair event counter instead of the augmentation count
-# (EMD_STAT = 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows visited by A rebuilds).  GPU box.
+# (EMD_STAT = 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows visited by A rebuilds, 5 searches).  GPU box.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R/pilot_amd/csrc
 cp ../libpilot_ot.so /tmp/libpilot_ot.keep.so
 python3 $R/tools/emd_stats.py ${1:-c3} | sed 's/^/augmentations: /' | head -1
-for st in 1 2 3 4; do
+for st in 1 2 3 4 5; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -DEMD_STAT=$st -c -o /tmp/pilot_ot_stat.o pilot_ot.hip 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_stat.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_inst_*.o -ldl
   python3 $R/tools/emd_stats.py ${1:-c3} | sed "s/^/EMD_STAT=$st: /" | head -1
