@@ -150,10 +150,21 @@ __device__ inline bool bits_less(double a, double b) {
 //     rows ship to the columns being scanned" is one 64-bit AND against the ballot mask of those columns.
 // Nothing per wave is in LDS, so occupancy is bounded by registers only (the step loop is pure latency).
 constexpr int EMD_WAVES = 8;
+#ifndef EMD_LAZY
+#define EMD_LAZY 1
+#endif
+#ifndef EMD_WPE
+#define EMD_WPE 1
+#endif
+#if EMD_WPE
+#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK == 1 ? 8 : (NK == 2 ? 4 : 2), 8)))
+#else
+#define EMD_WPE_ATTR
+#endif
 
 // MG: the cost matrix is read from global memory (L2) instead of LDS -- K > 128, where K*K doubles no longer fit LDS
 template <int NK, bool MG = false>
-__global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
+__global__ void __launch_bounds__(64 * EMD_WAVES) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -172,6 +183,10 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
     __syncthreads();
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
     const double INF = __builtin_inf(), NEG = -1.0;
+    // LAZY: keep a search going after an augmentation dried its root / emptied an arc / left its target open, and restart
+    // only when a later path turns out to be unusable (pays from K > 64 on: c4 0.73 -> 0.66 s; at K = 50 the searches drop
+    // from 41 to 22 per pair but the steps do not, and the extra state costs registers: 10.5 -> 11.7 ms)
+    constexpr bool LAZY = NK >= 2 && EMD_LAZY;
     const long total = (long)p.n_rows * N;
 
     // pairs are dealt round-robin to the resident waves (wave-uniform loop bounds)
@@ -244,7 +259,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 any_src = any_src || srcmask[e] != 0ull;
             }
             if (!any_src) break;
-            if (n_aug > aug_guard) { tripped = true; trip_code = 5; break; }
+            if (n_aug > aug_guard || n_search > aug_guard) { tripped = true; trip_code = 5; break; }
             if ((n_search & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
             // initial column labels min over sources i of rc(i, j) = (A_j - pv_j)+ with A_j = min_i (M_ij - pu_i): a source's
             // potential never moves (its distance is 0), so A and its arg-min only change when a source runs dry
@@ -292,8 +307,8 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                 fR[e] = src ? 0.0 : INF; parR[e] = -1;
                 demand[e] = __ballot(rb[e] > 0.0);                          // (rb is 0 beyond K)
             }
-            double dstar = 0.0;
-            bool exhausted = false;
+            double dstar = 0.0, last_bd = 0.0;
+            bool exhausted = false, stale = false;
             for (int step = 0;; ++step) {
                 if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: >= one node is scanned per step
 #if defined(EMD_STAT) && EMD_STAT == 1
@@ -305,7 +320,12 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
 #pragma unroll
                 for (int e = 1; e < NK; ++e) best = bits_less(dC[e], best) ? dC[e] : best;
                 const double bd = uni_f64(wave_min_f64(best));
-                if (hi_word(bd) >= 0x7ff00000u) { exhausted = true; break; }   // +inf or NEG: nothing reachable, only rounding dust left
+                if (hi_word(bd) >= 0x7ff00000u) {   // +inf or NEG: nothing (more) reachable
+                    if (LAZY && stale) dstar = last_bd;     // ... from a tree that is out of date: search again
+                    else exhausted = true;                  // ... at all: only rounding dust is left
+                    break;
+                }
+                if constexpr (LAZY) last_bd = bd;
                 unsigned long long tieC[NK], tieR[NK];
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
@@ -314,10 +334,12 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                     if (tc) { fC[e] = bd; dC[e] = NEG; }
                 }
                 // Tied columns with demand left are targets: augment along the tree path right away, WITHOUT touching the
-                // potentials.  If that only saturated the target (the source keeps supply, no backward arc ran empty) the
-                // shortest-path tree is still valid -- the new support arcs join scanned nodes and are tight -- and the
-                // search simply goes on with the target as one more scanned column; otherwise the potentials are brought up
-                // to date with the labels (d* = this step's label) and a new search starts.
+                // potentials, and let the search go on with the target as one more scanned column.  The labels are exact
+                // distances from the sources the search started with, in a residual graph that only gains tight arcs
+                // between scanned nodes, so every tree path stays a shortest (tight) path as long as its root still has
+                // supply and its backward arcs still carry flow; a path that fails this test (a root that ran dry or an arc
+                // that ran empty in an earlier augmentation of this search) is not used: the potentials are brought up to
+                // date with the labels (d* = this step's label -- valid for ANY scanned set) and a new search starts.
                 bool broke = false;
 #pragma unroll
                 for (int et = 0; et < NK; ++et) {
@@ -363,9 +385,9 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                             j = jb;
                         }
                         if (tripped) break;
-                        double delta;
+                        double delta, ra_s = 0.0;
                         {
-                            double rb_t = 0.0, ra_s = 0.0;
+                            double rb_t = 0.0;
 #pragma unroll
                             for (int e = 0; e < NK; ++e) {
                                 if (e == target / 64) rb_t = rl_f64(rb[e], target % 64);
@@ -373,11 +395,10 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                             }
                             delta = rb_t < ra_s ? rb_t : ra_s;
                         }
-                        if (n_hops == 1) {          // (wave-uniform) the source ships straight to the target: no backward arc
-                            if (lane == 0) F[(size_t)src_row * K + target] += delta;
-                        } else {
-                            // bottleneck: all backward-arc flows at once
-                            double fb[NK], fmin = INF;
+                        // bottleneck: all backward-arc flows at once
+                        double fb[NK];
+                        auto bottleneck = [&]() {
+                            double fmin = INF;
 #pragma unroll
                             for (int e = 0; e < NK; ++e) {
                                 const bool act = lane + 64 * e < n_hops;
@@ -386,6 +407,37 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                             }
                             const double fm = wave_min_f64(fmin);
                             delta = uni_f64(fm < delta ? fm : delta);
+                        };
+                        if constexpr (LAZY) {
+                            if (n_hops > 1) bottleneck();   // (wave-uniform; one hop = the source ships straight to the target)
+                        }
+                        if (LAZY && (!(ra_s > tol) || !(delta > 0.0))) {
+                            // The tree is out of date here (its root ran dry, or a backward arc on the path ran empty, in an
+                            // earlier augmentation of this search): nothing moves; arcs the walk marked but that carry no
+                            // flow leave the support again, and a new search starts from up-to-date potentials.
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) {
+                                const bool act = lane + 64 * e < n_hops;
+                                unsigned long long z = __ballot(act && F[(size_t)hi[e] * K + hj[e]] == 0.0);
+                                while (z) {
+                                    const int h = __builtin_ctzll(z);
+                                    z &= z - 1ull;
+                                    const int i = rl_i32(hi[e], h), jf = rl_i32(hj[e], h);
+#pragma unroll
+                                    for (int e2 = 0; e2 < NK; ++e2)
+                                        if (lane + 64 * e2 == i) {
+#pragma unroll
+                                            for (int w = 0; w < NK; ++w) if (w == jf / 64) ship[e2][w] &= ~(1ull << (jf % 64));
+                                        }
+                                }
+                            }
+                            broke = true;
+                            break;
+                        }
+                        if (n_hops == 1) {
+                            if (lane == 0) F[(size_t)src_row * K + target] += delta;
+                        } else {
+                            if constexpr (!LAZY) bottleneck();
                             // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
                             unsigned long long emptied[NK];
 #pragma unroll
@@ -396,7 +448,7 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                                     if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
                                 }
                                 emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
-                                if (emptied[e]) broke = true;          // a tree arc is gone
+                                if (emptied[e]) stale = true;          // a tree arc is gone
                             }
                             // backward arcs that ran empty leave the support
 #pragma unroll
@@ -424,10 +476,10 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) emd_grid_kernel(EmdParams p) {
                             if (lane + 64 * e == target) rb[e] -= delta;
                         }
                         ++n_aug;
-                        if (__ballot(dry)) broke = true;
-                        if (et < NK) demand[et] = __ballot(rb[et] > 0.0);
-                        if ((demand[et] >> (target % 64)) & 1ull) broke = true;      // target not saturated: the tree changed
-                        if (broke) break;
+                        demand[et] = __ballot(rb[et] > 0.0);
+                        // a dry root, or a target that keeps demand (its path gave out first): the tree is out of date below them
+                        if (__ballot(dry) || ((demand[et] >> (target % 64)) & 1ull)) stale = true;
+                        if (!LAZY && stale) { broke = true; break; }        // restart at once: every path found is usable
                     }
                 }
                 if (tripped) break;
