@@ -77,21 +77,22 @@ __device__ inline void swap32_f64(double x, double &a, double &b) {
     p.u[0] = lo[0]; p.u[1] = hi[0]; q.u[0] = lo[1]; q.u[1] = hi[1];
     a = p.d; b = q.d;
 }
-template <int CTRL> __device__ inline unsigned int dpp_u32(unsigned int x) {
-    // (old = constant, bound_ctrl: every lane of these permutations is valid, and this form lets the compiler fold the move
-    // into the consumer: v_min_u32_dpp)
-    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+// x of the lane the DPP control selects, ~0u (the identity of an unsigned minimum) where it selects none: in this form the
+// compiler folds the move into the consumer (one v_min_u32_dpp per stage)
+template <int CTRL, int ROW_MASK = 0xf> __device__ inline unsigned int dpp_u32(unsigned int x) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, ROW_MASK, 0xf, false);
 }
+// wave-wide unsigned minimum (wave-uniform result): row_shr 1 / 2 / 4 / 8 scan inside each 16-lane row, row_bcast:15 and
+// row_bcast:31 across the rows -- six v_min_u32_dpp; lane 63 ends up with the minimum of all 64
 __device__ inline unsigned int wave_min_u32(unsigned int x) {
     unsigned int y;
-    y = dpp_u32<0xB1>(x); x = y < x ? y : x;     // (mov_dpp + v_min_u32 fold into one v_min_u32_dpp)
-    y = dpp_u32<0x4E>(x); x = y < x ? y : x;
-    y = dpp_u32<0x141>(x); x = y < x ? y : x;
-    y = dpp_u32<0x140>(x); x = y < x ? y : x;
-    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-    x = r[0] < r[1] ? r[0] : r[1];
-    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return r[0] < r[1] ? r[0] : r[1];
+    y = dpp_u32<0x111>(x); x = y < x ? y : x;
+    y = dpp_u32<0x112>(x); x = y < x ? y : x;
+    y = dpp_u32<0x114>(x); x = y < x ? y : x;
+    y = dpp_u32<0x118>(x); x = y < x ? y : x;
+    y = dpp_u32<0x142, 0xa>(x); x = y < x ? y : x;
+    y = dpp_u32<0x143, 0xc>(x); x = y < x ? y : x;
+    return (unsigned int)__builtin_amdgcn_readlane((int)x, 63);
 }
 // Wave-wide minimum of doubles whose bit patterns order like unsigned integers (non-negative values, +inf included;
 // "done" entries are -1.0, whose pattern is above every non-negative one): the minimum is the lexicographic minimum of
