@@ -624,12 +624,17 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         q.list = pl->track_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9;
         q.fb_list = nullptr; q.fb_count = nullptr; q.bands = 1;
         q.nan_list = pl->nan_list; q.nan_count = pl->track_count + 10;
-        const StreamLds L = stream_lds(fixed64, slot64, stream_min_waves(2, RT64, sym, true, 0, false));
-        q.ring = L.ring;
-        int wgs_t = pl->n_cu * L.wgs_per_cu;
-        const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
-        if (wgs_t > need) wgs_t = need;
-        HIP_TRY(pilot::launch_stream_f64(RT64, sym, true, dim3(wgs_t), L.bytes, s, q));
+        if (sym && K <= 64 && !(p.debug & 2048)) {
+            // the list is short (tens of pairs) and every pair on it runs long: one wave per pair, not 16-pair MFMA tiles
+            HIP_TRY(pilot::launch_solo_track_f64(dim3(64), s, q));
+        } else {
+            const StreamLds L = stream_lds(fixed64, slot64, stream_min_waves(2, RT64, sym, true, 0, false));
+            q.ring = L.ring;
+            int wgs_t = pl->n_cu * L.wgs_per_cu;
+            const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+            if (wgs_t > need) wgs_t = need;
+            HIP_TRY(pilot::launch_stream_f64(RT64, sym, true, dim3(wgs_t), L.bytes, s, q));
+        }
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
     if (!(p.debug & 1024)) {

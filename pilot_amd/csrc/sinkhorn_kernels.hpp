@@ -552,8 +552,11 @@ template <typename T> __device__ inline T wave_sum(T x) {
     return sum_xor32(sum_xor16(x));
 }
 
-template <class C, bool SYM>
-__device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned char *solo_smem) {
+// TRACK: POT's tau-absorptions are kept books of exactly as in the tracking stream kernel (reference scalings ru, rv per
+// element, the 1/K resets folded into the error test and the final cost) instead of handing the pair over; used for the
+// short f64 hand-over list of the small-reg path, where a 16-pair f64 MFMA tile would run 1000 updates nearly empty.
+template <class C, bool SYM, bool TRACK = false>
+__device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned char *solo_smem, const int *n_items_ptr, int *head_ptr) {
     using T = typename C::T;
     const int lane = threadIdx.x % WAVE;
     const int K = p.K, N = p.N;
@@ -591,10 +594,11 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
     const bool inrec = lane < KP;
     const T acc0 = inrec ? img[acc0_offset<C>(RT) + pos] : T(1);
     const T tau = T(p.tau);
-    const int n_items = *p.solo_len;
+    const int n_items = *n_items_ptr;
+    const T kk = T(K) * T(K);
     for (;;) {
         int item = 0;
-        if (lane == 0) item = __hip_atomic_fetch_add(p.solo_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) item = __hip_atomic_fetch_add(head_ptr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
         const int q = p.list[item];
@@ -602,15 +606,25 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
         const T a = inrec ? Pt[(size_t)i * KP + pos] : T(0), b = inrec ? Pt[(size_t)j * KP + pos] : T(0);
         const T thr = Pt[(size_t)N * KP + j];
         T u = live ? T(1) / T(K) : T(0), v = u, ACC = acc0, errv = T(1);
-        int ii = 0, chk = 1, flags = sizeof(T) == 8 ? FLAG_F64 : 0;
+        T ru = live ? T(1) : T(0), rv = ru;                      // TRACK: u * ru, v * rv are POT's residual scalings
+        int ii = 0, chk = 1, flags = sizeof(T) == 8 ? FLAG_F64 : 0, abs_at = -1;
         for (;;) {
             v = b * C::rcp(ACC);
             T r1 = SYM ? matvec(g1, v) : matvec(g1, v);
             r1 = live ? r1 : T(1);
             u = a * C::rcp(r1);
-            if (__ballot(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
-                if (lane == 0) p.track_list[__hip_atomic_fetch_add(p.track_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
-                break;
+            if constexpr (TRACK) {
+                if (__ballot(live && (u * ru > tau || v * rv > tau))) {     // POT: absorb, u = v = 1/K (see the stream kernel)
+                    ru = live ? C::rcp(u * T(K)) : T(0);
+                    rv = live ? T(K) * C::rcp(v) : T(0);
+                    abs_at = ii;
+                    flags |= FLAG_ABSORBED;
+                }
+            } else {
+                if (__ballot(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
+                    if (lane == 0) p.track_list[__hip_atomic_fetch_add(p.track_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
+                    break;
+                }
             }
             ++ii;
             if constexpr (SYM) ACC = matvec(g1, u); else ACC = matvec(g2, u);
@@ -618,7 +632,8 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
             const bool pending = ii == chk, capped = ii >= p.max_iter;
             if (pending) chk += p.period;
             if (pending || capped) {                              // wave-uniform
-                const T d = v * ACC - b;
+                const T sc = (TRACK && abs_at == ii - 1) ? T(1) / kk : T(1);      // u, v were just reset to 1/K each
+                const T d = v * ACC * sc - b;
                 const T e = sqrt(wave_sum(d * d));
                 bool fin = capped;
                 if (pending) {
@@ -641,6 +656,7 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
                         }
                     }
                     val = wave_sum(live ? u * val : T(0));
+                    if (TRACK && abs_at >= 0 && abs_at == ii - 1) { val *= T(1) / kk; flags |= FLAG_ABSORB_LAST; }
                     if (lane == 0) {
                         if (val != val) flags |= FLAG_NAN;
                         if (p.nan_list && (flags & FLAG_NAN)) {
@@ -657,6 +673,15 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
             }
         }
     }
+}
+
+// A (short) list of pairs, one wavefront per pair with POT's absorptions tracked: the f64 hand-over list of the small-reg
+// path (symmetric cost, K <= 64).  p.list / p.list_len / p.queue_head name the list.
+template <class C>
+__global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_solo_track_kernel(GridParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char solo_track_smem[];
+    const int RT = (p.K + C::TILE - 1) / C::TILE;
+    solo_pairs<C, true, true>(p, RT * C::TILE, RT, solo_track_smem, p.list_len, p.queue_head);
 }
 
 // Finished pairs in a wave's ring -> costs <Gamma, M> = u^T (G o M) v: ONE panel product for up to TILE pairs, one output
@@ -797,7 +822,7 @@ sinkhorn_stream_kernel(GridParams p) {
     int block = blockIdx.x;
     if constexpr (solo_in_stream<C, RT, SYM, TRACK, TV>()) {
         // the leading workgroups of the fast launch run the exact-duplicate pairs, one per wave (they start first)
-        if (block < p.solo_blocks) { solo_pairs<C, SYM>(p, KP, RT, smem_raw); return; }
+        if (block < p.solo_blocks) { solo_pairs<C, SYM>(p, KP, RT, smem_raw, p.solo_len, p.solo_head); return; }
         block -= p.solo_blocks;
     }
     const int n_items = p.list_len ? *p.list_len : p.n_pairs;

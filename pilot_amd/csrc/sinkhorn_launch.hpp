@@ -12,6 +12,8 @@ enum { CFG_F32 = 0, CFG_F64 = 1, CFG_S32 = 2 };   // CfgF32x16, CfgF64x16, CfgS3
 // persistent stream kernel (one tile per wave); track: tau-tracking variant
 hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+// a short list of pairs (p.list / p.list_len / p.queue_head), one wave per pair, absorptions tracked; symmetric cost, K <= 64
+hipError_t launch_solo_track_f64(dim3 grid, hipStream_t s, const GridParams &p);
 // live1: K mod 16 in 1..4, the dead registers of the last row-tile are skipped (RT >= 2)
 hipError_t launch_stream_s32(int RT, bool sym, bool track, int live1, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 // variants with the last row-tile on the VALU (tv = 1: <= 2 live rows, 2: <= 4; see tail_rows); RT >= 2

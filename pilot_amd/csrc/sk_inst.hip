@@ -102,6 +102,10 @@ hipError_t launch_stream_tv(int cfg, int tv, int RT, bool sym, bool track, dim3 
 hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<CfgF64x16>(RT, sym, track, grid, lds, s, p);
 }
+hipError_t launch_solo_track_f64(dim3 grid, hipStream_t s, const GridParams &p) {
+    hipLaunchKernelGGL(sinkhorn_solo_track_kernel<CfgF64x16>, grid, dim3(WAVE * WAVES_PER_WG), sizeof(double) * WAVE * WAVES_PER_WG, s, p);
+    return hipGetLastError();
+}
 hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
                            double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
