@@ -78,6 +78,7 @@ template <int KB> __device__ inline void cell_load(const uint4 *__restrict__ Xb,
 // 16 x 16 tile of <A_row, B_col>: six bf16 MFMAs per k-block, smallest terms first
 template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB> &a, const CellOperand<KB> &b) {
     cell_f4 acc = {0.f, 0.f, 0.f, 0.f};
+
     auto mm = [](const uint4 &x, const uint4 &y, cell_f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cell_bf16x8, x), __builtin_bit_cast(cell_bf16x8, y), c, 0, 0, 0);
     };
@@ -118,52 +119,119 @@ __device__ inline float row16_sum(float x) {
 
 // out2[r] = log2 sum_c 2^( two_alpha2 * <A_r, B_c> + h2[c] )  for every row r of the A side  (base-2 LSE)
 // FN(row, lse2) is called by one lane per row with the result.
+//
+// The exponent shift of a row is the value this same LSE had one update ago (ref_r = logw2 - hprev[r]: the potential the
+// previous update wrote IS log w - LSE): between two Sinkhorn updates it moves by a fraction of a unit, so the sum of
+// 2^(t - ref_r) is of order one and neither a running maximum nor its rescaling exponentials are needed -- per element
+// fma, sub, v_exp, add instead of fma, max, sub, v_exp, add plus one v_exp per row and step (the pass is bound by the
+// vector unit, not by the six MFMAs per tile).  use_ref = false (first update of a pair: no previous value), or a block
+// whose shifted sums leave [2^-64, 2^64] for any row (never seen in practice), takes the online-maximum form.
 template <int KB, class FN>
 __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, long b0, int nb,
-                                const float *h2 /* LDS, nb */, float two_alpha2, int wave, int n_waves, int lane, FN &&fn) {
+                                const float *h2 /* LDS, nb */, float two_alpha2, const float *hprev /* LDS, na */, float logw2,
+                                bool use_ref, int wave, int n_waves, int lane, FN &&fn) {
     using f4 = cell_f4;
     const int col = lane & 15, g = lane >> 4;
-    constexpr int TB = KB >= 2 ? 2 : 4;
-    for (int blk = wave; blk * 16 < na; blk += n_waves) {
-        int arow = blk * 16 + col;                        // A operand: lane holds row (lane & 15), k-slots of group g
-        if (arow >= na) arow = na - 1;
-        CellOperand<KB> a;
-        cell_load<KB>(Xb, a0 + arow, g, a);
-        float m[4], l[4];
+    // a wave keeps the A operands of RB row blocks in registers and sweeps the B side once for all of them: every B tile
+    // it loads (3 x 1 KB per k-block, from L1/L2) feeds RB output tiles -- the sweep is bound by the vector-memory path,
+    // not by the MFMAs
+#ifndef CELL_RB
+#define CELL_RB 4
+#endif
+    constexpr int RB = KB >= 2 ? 2 : CELL_RB, TB = KB >= 2 ? 1 : (CELL_RB >= 4 ? 1 : 2);
+    constexpr int TBS = KB >= 2 ? 2 : 4;                  // column tiles per step of the online-maximum form
+    for (int unit = wave; unit * 16 * RB < na; unit += n_waves) {
+        CellOperand<KB> a[RB];
+        float m[RB][4], l[RB][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { m[r] = CELL_NEG_BIG; l[r] = 0.f; }
-        // TB column tiles per step: one running-max rescale per row and step instead of one per element
-        for (int tb = 0; tb * 16 < nb; tb += TB) {
-            f4 acc[TB];
-            float h[TB];
+        for (int rb = 0; rb < RB; ++rb) {
+            int arow = (unit * RB + rb) * 16 + col;       // A operand: lane holds row (lane & 15), k-slots of group g
+            if (arow >= na) arow = na - 1;
+            cell_load<KB>(Xb, a0 + arow, g, a[rb]);
+        }
+        bool done = false;
+        if (use_ref) {                                    // (wave-uniform)
 #pragma unroll
-            for (int u = 0; u < TB; ++u) {
-                int bcol = (tb + u) * 16 + col;
-                const bool okc = bcol < nb;
-                if (!okc) bcol = nb - 1;
-                CellOperand<KB> b;
-                cell_load<KB>(Xb, b0 + bcol, g, b);
-                h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
-                acc[u] = cell_dot_tile<KB>(a, b);
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (unit * RB + rb) * 16 + 4 * g + r;
+                    m[rb][r] = logw2 - hprev[row < na ? row : na - 1];
+                    l[rb][r] = 0.f;
+                }
+            for (int tb = 0; tb * 16 < nb; tb += TB) {
+                CellOperand<KB> b[TB];
+                float h[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    int bcol = (tb + u) * 16 + col;
+                    const bool okc = bcol < nb;
+                    if (!okc) bcol = nb - 1;
+                    cell_load<KB>(Xb, b0 + bcol, g, b[u]);
+                    h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int u = 0; u < TB; ++u) {
+                        const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = <A_{4g+r}, B_col(u)>
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(fmaf(acc[r], two_alpha2, h[u]) - m[rb][r]);
+                    }
             }
+            bool bad = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                 // acc[u][r] = <A_{4g+r}, B_col(u)>
-                float t[TB], mn = m[r];
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int u = 0; u < TB; ++u) { t[u] = fmaf(acc[u][r], two_alpha2, h[u]); mn = fmaxf(mn, t[u]); }
-                float add = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    l[rb][r] = row16_sum(l[rb][r]);
+                    bad = bad || !(l[rb][r] > 5.4e-20f && l[rb][r] < 1.8e19f);
+                }
+            done = __ballot(bad) == 0ull;
+        }
+        if (!done) {
 #pragma unroll
-                for (int u = 0; u < TB; ++u) add += __builtin_amdgcn_exp2f(t[u] - mn);
-                l[r] = fmaf(l[r], __builtin_amdgcn_exp2f(m[r] - mn), add);
-                m[r] = mn;
+            for (int rb = 0; rb < RB; ++rb) {
+                if ((unit * RB + rb) * 16 >= na) continue;            // (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { m[rb][r] = CELL_NEG_BIG; l[rb][r] = 0.f; }
+                // TBS column tiles per step: one running-max rescale per row and step instead of one per element
+                for (int tb = 0; tb * 16 < nb; tb += TBS) {
+                    f4 acc[TBS];
+                    float h[TBS];
+#pragma unroll
+                    for (int u = 0; u < TBS; ++u) {
+                        int bcol = (tb + u) * 16 + col;
+                        const bool okc = bcol < nb;
+                        if (!okc) bcol = nb - 1;
+                        CellOperand<KB> b;
+                        cell_load<KB>(Xb, b0 + bcol, g, b);
+                        h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
+                        acc[u] = cell_dot_tile<KB>(a[rb], b);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t[TBS], mn = m[rb][r];
+#pragma unroll
+                        for (int u = 0; u < TBS; ++u) { t[u] = fmaf(acc[u][r], two_alpha2, h[u]); mn = fmaxf(mn, t[u]); }
+                        float add = 0.f;
+#pragma unroll
+                        for (int u = 0; u < TBS; ++u) add += __builtin_amdgcn_exp2f(t[u] - mn);
+                        l[rb][r] = fmaf(l[rb][r], __builtin_amdgcn_exp2f(m[rb][r] - mn), add);
+                        m[rb][r] = mn;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) row16_lse_combine(m[rb][r], l[rb][r]);
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            row16_lse_combine(m[r], l[r]);
-            const int row = blk * 16 + 4 * g + r;
-            if (col == 0 && row < na) fn(row, m[r] + __builtin_amdgcn_logf(l[r]));   // v_log_f32 is log2
-        }
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (unit * RB + rb) * 16 + 4 * g + r;
+                if (col == 0 && row < na) fn(row, m[rb][r] + __builtin_amdgcn_logf(l[rb][r]));   // v_log_f32 is log2
+            }
     }
 }
 
@@ -262,7 +330,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             //      after update ii-1 comes for free; if it stops the pair, (hu, hv_old) is exactly the plan POT returns.
             const bool check = ii > 0 && ((ii - 1) % p.period == 0);
             float e2 = 0.f;
-            lse_pass<KB>(p.Xb, o_q, nq, o_p, np, hu, p.two_alpha2, wave, n_waves, lane, [&](int row, float lse2) {
+            lse_pass<KB>(p.Xb, o_q, nq, o_p, np, hu, p.two_alpha2, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
                 if (check) {
                     const float d = __builtin_amdgcn_exp2f(hv_cur[row] + lse2) - bval;
                     e2 = fmaf(d, d, e2);
@@ -285,7 +353,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             }
             { float *t = hv_cur; hv_cur = hv_new; hv_new = t; }
             // ---- u-update:  hu_i = log a - LSE_j(2 alpha <x_i, y_j> + hv_j) -------------------------------------------
-            lse_pass<KB>(p.Xb, o_p, np, o_q, nq, hv_cur, p.two_alpha2, wave, n_waves, lane,
+            lse_pass<KB>(p.Xb, o_p, np, o_q, nq, hv_cur, p.two_alpha2, hu, loga2, ii > 0, wave, n_waves, lane,
                          [&](int row, float lse2) { hu[row] = loga2 - lse2; });
             __syncthreads();
             iters = ii + 1;

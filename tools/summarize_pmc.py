@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             k = row.get("Kernel_Name", "?").split("(")[0].replace("void pilot::", "")
             dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 for k in sorted(acc, key=lambda k: -sum(dur.get(k, [0]))):
-    if not k.startswith("sinkhorn") and not k.startswith("emd"):
+    if not k.startswith("sinkhorn") and not k.startswith("emd") and not k.startswith("cell_w2"):
         continue
     print("== %s   dispatches=%d  mean duration (profiled) = %.1f us" % (k, len(dur.get(k, [])), sum(dur[k]) / max(1, len(dur[k]))))
     for c in sorted(acc[k]):
