@@ -482,7 +482,7 @@ def bench_cellw2(args, reg=0.1, D=30):
         "dtype": "f32 potentials; dot products as exact 3-way bf16 splits of the coordinates on the bf16 MFMA", "data": "synthetic",
         "config": {"workload": "c5: %d patients x %d cells x %d dims, entropic W2 reg=%g (POT sinkhorn_log control flow), all N^2 "
                                "ordered pairs" % (Np, nc, D, reg), "n_patients": Np, "cells_per_patient": nc, "n_dims": D, "reg": reg},
-        "roofline": {"bound": "mfma", "kernel": "pilot::cell_w2_kernel<1>", "achieved": round(flop * 6 * Dp / D / kern_s / 1e12, 1),
+        "roofline": {"bound": "mfma", "kernel": "pilot::cell_w2_kernel<1, true>", "achieved": round(flop * 6 * Dp / D / kern_s / 1e12, 1),
                      "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flop * 6 * Dp / D / kern_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                      "traffic": None, "kernel_ms": round(co.last_kernel_ms, 1),
                      "note": "achieved = bf16 MFMA flop executed: 6 piece products per term (exact 3-way splits of both operands), "

@@ -31,7 +31,9 @@ struct CellParams {
     const long long *offs;  // N + 1: first cell of every patient
     int N;
     int n_rows, row_begin, row_step;
-    float two_alpha2;       // 2 * alpha * log2(e)
+    float two_alpha2;       // 2 * alpha * log2(e): the operand pieces are scaled by its square root, so a dot product of
+                            // two operands IS the exponent term 2 alpha log2(e) <x, y>
+    float dot_unscale;      // 1 / two_alpha2: back to <x, y>
     float alpha;            // 1 / (scale * eps)
     float inv_scale;        // 1 / scale
     int max_iter, period;
@@ -43,14 +45,14 @@ struct CellParams {
     int *queue;             // dynamic pair queue
 };
 
-// one pre-pass over the cells: the three bf16 pieces of every coordinate in MFMA operand order + squared norms
-__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, unsigned short *__restrict__ Xb,
-                                  float *__restrict__ nrm) {
+// one pre-pass over the cells: the three bf16 pieces of every (scaled) coordinate in MFMA operand order + squared norms
+__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, float op_scale,
+                                  unsigned short *__restrict__ Xb, float *__restrict__ nrm) {
     const long per = (long)KB * 3 * 32;            // bf16 values per cell
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * KB * 32; idx += (long)gridDim.x * blockDim.x) {
         const long c = idx / (KB * 32);
         const int o = (int)(idx % (KB * 32)), kb = o / 32, d = o;      // coordinate d sits in k-block d / 32, slot d % 32
-        float x = d < D ? X[c * D + d] : 0.f;
+        float x = d < D ? X[c * D + d] * op_scale : 0.f;
 #pragma unroll
         for (int piece = 0; piece < 3; ++piece) {
             const unsigned short hb = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
@@ -74,6 +76,36 @@ template <int KB> __device__ inline void cell_load(const uint4 *__restrict__ Xb,
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int piece = 0; piece < 3; ++piece) o.p[kb][piece] = Xb[((point * KB + kb) * 3 + piece) * 4 + g];
+}
+// exact 3-way split of an f32 into bf16 pieces by truncation (8 + 8 + 8 mantissa bits): x = hi + mid + lo
+__device__ inline void cell_split3(float x, unsigned int &hi, unsigned int &mid, unsigned int &lo) {
+    const unsigned int xh = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(xh);
+    const unsigned int xm = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(xm);
+    hi = xh >> 16; mid = xm >> 16; lo = __float_as_uint(r2) >> 16;
+}
+// The two spare k-slots of the last k-block (D <= 32 KB - 2) carry the exponent's additive terms through the MFMA:
+// slot 32 KB - 2 holds (1 on the A side, h_col on the B side), slot 32 KB - 1 holds (-m_row, 1), each value as its three
+// bf16 pieces -- with the 1 only in the leading piece, the six piece products of cell_dot_tile add exactly h_col - m_row,
+// and the tile comes out of the matrix pipe as the finished exponent.  Both slots sit in the .w word of the g = 3 lanes.
+template <int KB> __device__ inline void cell_patch_a(CellOperand<KB> &a, int g, float minus_m) {
+    unsigned int h, m, l;
+    cell_split3(minus_m, h, m, l);
+    if (g == 3) {
+        a.p[KB - 1][0].w = 0x3f80u | (h << 16);
+        a.p[KB - 1][1].w = m << 16;
+        a.p[KB - 1][2].w = l << 16;
+    }
+}
+template <int KB> __device__ inline void cell_patch_b(CellOperand<KB> &b, int g, float hcol) {
+    unsigned int h, m, l;
+    cell_split3(hcol, h, m, l);
+    if (g == 3) {
+        b.p[KB - 1][0].w = h | (0x3f80u << 16);
+        b.p[KB - 1][1].w = m;
+        b.p[KB - 1][2].w = l;
+    }
 }
 // 16 x 16 tile of <A_row, B_col>: six bf16 MFMAs per k-block, smallest terms first
 template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB> &a, const CellOperand<KB> &b) {
@@ -126,9 +158,9 @@ __device__ inline float row16_sum(float x) {
 // fma, sub, v_exp, add instead of fma, max, sub, v_exp, add plus one v_exp per row and step (the pass is bound by the
 // vector unit, not by the six MFMAs per tile).  use_ref = false (first update of a pair: no previous value), or a block
 // whose shifted sums leave [2^-64, 2^64] for any row (never seen in practice), takes the online-maximum form.
-template <int KB, class FN>
+template <int KB, bool AUG, class FN>
 __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, long b0, int nb,
-                                const float *h2 /* LDS, nb */, float two_alpha2, const float *hprev /* LDS, na */, float logw2,
+                                const float *h2 /* LDS, nb */, const float *hprev /* LDS, na */, float logw2,
                                 bool use_ref, int wave, int n_waves, int lane, FN &&fn) {
     using f4 = cell_f4;
     const int col = lane & 15, g = lane >> 4;
@@ -159,6 +191,14 @@ __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, l
                     m[rb][r] = logw2 - hprev[row < na ? row : na - 1];
                     l[rb][r] = 0.f;
                 }
+            if constexpr (AUG) {                          // the row shift goes into the spare slot of the A operands
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    int arow = (unit * RB + rb) * 16 + col;
+                    if (arow >= na) arow = na - 1;
+                    cell_patch_a<KB>(a[rb], g, hprev[arow] - logw2);
+                }
+            }
             for (int tb = 0; tb * 16 < nb; tb += TB) {
                 CellOperand<KB> b[TB];
                 float h[TB];
@@ -169,14 +209,21 @@ __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, l
                     if (!okc) bcol = nb - 1;
                     cell_load<KB>(Xb, b0 + bcol, g, b[u]);
                     h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
+                    if constexpr (AUG) cell_patch_b<KB>(b[u], g, h[u]);
                 }
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int u = 0; u < TB; ++u) {
-                        const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = <A_{4g+r}, B_col(u)>
+                        if constexpr (AUG) {
+                            const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = the exponent of (row 4g+r, column u)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(fmaf(acc[r], two_alpha2, h[u]) - m[rb][r]);
+                            for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r]);
+                        } else {
+                            const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = 2 alpha log2e <A_{4g+r}, B_col(u)>
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r] + h[u] - m[rb][r]);
+                        }
                     }
             }
             bool bad = false;
@@ -193,6 +240,11 @@ __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, l
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 if ((unit * RB + rb) * 16 >= na) continue;            // (wave-uniform)
+                if (AUG && use_ref) {                                 // the plain operand again
+                    int arow = (unit * RB + rb) * 16 + col;
+                    if (arow >= na) arow = na - 1;
+                    cell_load<KB>(Xb, a0 + arow, g, a[rb]);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { m[rb][r] = CELL_NEG_BIG; l[rb][r] = 0.f; }
                 // TBS column tiles per step: one running-max rescale per row and step instead of one per element
@@ -213,7 +265,7 @@ __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, l
                     for (int r = 0; r < 4; ++r) {
                         float t[TBS], mn = m[rb][r];
 #pragma unroll
-                        for (int u = 0; u < TBS; ++u) { t[u] = fmaf(acc[u][r], two_alpha2, h[u]); mn = fmaxf(mn, t[u]); }
+                        for (int u = 0; u < TBS; ++u) { t[u] = acc[u][r] + h[u]; mn = fmaxf(mn, t[u]); }
                         float add = 0.f;
 #pragma unroll
                         for (int u = 0; u < TBS; ++u) add += __builtin_amdgcn_exp2f(t[u] - mn);
@@ -239,7 +291,7 @@ __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, l
 template <int KB>
 __device__ inline float value_pass(const uint4 *__restrict__ Xb, long a0, const float *__restrict__ na2, int na,
                                    long b0, const float *__restrict__ nb2, int nb,
-                                   const float *hA2, const float *hB2, float two_alpha2, float inv_scale, int wave,
+                                   const float *hA2, const float *hB2, float dot_unscale, float inv_scale, int wave,
                                    int n_waves, int lane) {
     using f4 = cell_f4;
     const int col = lane & 15, g = lane >> 4;
@@ -268,8 +320,8 @@ __device__ inline float value_pass(const uint4 *__restrict__ Xb, long a0, const 
             const f4 acc = cell_dot_tile<KB>(a, b);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float wgt = __builtin_amdgcn_exp2f(fmaf(acc[r], two_alpha2, h) + hr[r]);   // Gamma_ij
-                const float c = fmaxf(fmaf(-2.f, acc[r], nr[r] + nc), 0.f) * inv_scale;          // C_ij >= 0
+                const float wgt = __builtin_amdgcn_exp2f(acc[r] + h + hr[r]);                    // Gamma_ij
+                const float c = fmaxf(fmaf(-2.f * dot_unscale, acc[r], nr[r] + nc), 0.f) * inv_scale;   // C_ij >= 0
                 total = fmaf(wgt, c, total);
             }
         }
@@ -277,7 +329,8 @@ __device__ inline float value_pass(const uint4 *__restrict__ Xb, long a0, const 
     return total;
 }
 
-template <int KB>
+// AUG: the embedding leaves two spare k-slots (D <= 32 KB - 2), see cell_patch_a / cell_patch_b
+template <int KB, bool AUG>
 __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *hu = reinterpret_cast<float *>(smem_raw);        // [max_n] shifted potentials of the row patient (base 2)
@@ -330,7 +383,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             //      after update ii-1 comes for free; if it stops the pair, (hu, hv_old) is exactly the plan POT returns.
             const bool check = ii > 0 && ((ii - 1) % p.period == 0);
             float e2 = 0.f;
-            lse_pass<KB>(p.Xb, o_q, nq, o_p, np, hu, p.two_alpha2, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
+            lse_pass<KB, AUG>(p.Xb, o_q, nq, o_p, np, hu, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
                 if (check) {
                     const float d = __builtin_amdgcn_exp2f(hv_cur[row] + lse2) - bval;
                     e2 = fmaf(d, d, e2);
@@ -353,13 +406,13 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             }
             { float *t = hv_cur; hv_cur = hv_new; hv_new = t; }
             // ---- u-update:  hu_i = log a - LSE_j(2 alpha <x_i, y_j> + hv_j) -------------------------------------------
-            lse_pass<KB>(p.Xb, o_p, np, o_q, nq, hv_cur, p.two_alpha2, hu, loga2, ii > 0, wave, n_waves, lane,
+            lse_pass<KB, AUG>(p.Xb, o_p, np, o_q, nq, hv_cur, hu, loga2, ii > 0, wave, n_waves, lane,
                          [&](int row, float lse2) { hu[row] = loga2 - lse2; });
             __syncthreads();
             iters = ii + 1;
         }
         // ---- value <Gamma, C> ---------------------------------------------------------------------------------------
-        float part = value_pass<KB>(p.Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.two_alpha2, p.inv_scale, wave, n_waves, lane);
+        float part = value_pass<KB>(p.Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) red[16 + wave] = part;

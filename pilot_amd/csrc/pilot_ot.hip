@@ -1084,6 +1084,8 @@ PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_ce
 struct pilot_ot_cell_cohort {
     int N = 0, D = 0, KB = 1, device = 0, n_cu = 256;
     long long C = 0, max_n = 0;
+    float *dX = nullptr;           // the cells as given (resident: the operand pieces are rebuilt when scale * reg changes)
+    float xb_scale = 0.f;          // operand scale the pieces were built with (0: not built)
     uint4 *dXb = nullptr;          // bf16 operand pieces of every cell (resident)
     float *dnrm = nullptr;
     long long *doffs = nullptr;
@@ -1097,7 +1099,7 @@ struct pilot_ot_cell_cohort {
 
 PILOT_API int pilot_ot_cell_cohort_destroy(pilot_ot_cell_cohort *c) {
     if (!c) return PILOT_OT_OK;
-    for (void *p : {(void *)c->dXb, (void *)c->dnrm, (void *)c->doffs, (void *)c->dW, (void *)c->dErr, (void *)c->dIt, (void *)c->dQ})
+    for (void *p : {(void *)c->dX, (void *)c->dXb, (void *)c->dnrm, (void *)c->doffs, (void *)c->dW, (void *)c->dErr, (void *)c->dIt, (void *)c->dQ})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1122,9 +1124,8 @@ PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offse
     if (!c) return fail(PILOT_OT_EINVAL, "out of host memory");
     c->N = N; c->D = D; c->KB = D <= 32 ? 1 : 2; c->C = offsets[N]; c->max_n = max_n;
     c->n_cu = current_cu_count();
-    DevBuf dX;
     hipError_t e = hipGetDevice(&c->device);
-    if (e == hipSuccess) e = dX.alloc(sizeof(float) * (size_t)c->C * D);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dX), sizeof(float) * (size_t)c->C * D);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dXb), (size_t)c->C * c->KB * 3 * 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dnrm), sizeof(float) * (size_t)c->C);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->doffs), sizeof(long long) * (size_t)(N + 1));
@@ -1132,14 +1133,8 @@ PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offse
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMemcpy(dX.p, X, sizeof(float) * (size_t)c->C * D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->dX, X, sizeof(float) * (size_t)c->C * D, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->doffs, offsets, sizeof(long long) * (size_t)(N + 1), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, dX.as<float>(),
-                           (long)c->C, D, c->KB, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    }
     if (e != hipSuccess) { pilot_ot_cell_cohort_destroy(c); return fail(PILOT_OT_EHIP, "cell cohort setup failed: %s", hipGetErrorString(e)); }
     *cohort = c;
     return PILOT_OT_OK;
@@ -1175,6 +1170,18 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
     const double alpha = 1.0 / (scale * reg);
     p.alpha = (float)alpha;
     p.two_alpha2 = (float)(2.0 * alpha * 1.4426950408889634);
+    {
+        // operand pieces of sqrt(2 alpha log2 e) * x: a dot product of two operands is the exponent term itself
+        const float op_scale = sqrtf(p.two_alpha2);
+        p.two_alpha2 = op_scale * op_scale;
+        p.dot_unscale = 1.f / p.two_alpha2;
+        if (c->xb_scale != op_scale) {
+            hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, c->dX,
+                               (long)c->C, c->D, c->KB, op_scale, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
+            HIP_TRY(hipGetLastError());
+            c->xb_scale = op_scale;
+        }
+    }
     p.inv_scale = (float)(1.0 / scale);
     p.max_iter = num_iter_max; p.period = check_period;
     p.stop_thr = (float)stop_thr; p.floor_ulps = (float)f32_floor_ulps;
@@ -1187,13 +1194,13 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
     if (wgs > c->n_cu * per_cu) wgs = c->n_cu * per_cu;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     hipError_t le = hipSuccess;
-    if (c->KB == 1) {
-        le = hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::cell_w2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (le == hipSuccess) hipLaunchKernelGGL(pilot::cell_w2_kernel<1>, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);
-    } else {
-        le = hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::cell_w2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (le == hipSuccess) hipLaunchKernelGGL(pilot::cell_w2_kernel<2>, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);
-    }
+    const bool aug = c->D <= 32 * c->KB - 2 && !getenv("PILOT_OT_CELL_NO_AUG");      // two spare k-slots carry h_col - m_row
+    auto launch = [&](auto kern) {
+        le = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (le == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);
+    };
+    if (c->KB == 1) { if (aug) launch(pilot::cell_w2_kernel<1, true>); else launch(pilot::cell_w2_kernel<1, false>); }
+    else            { if (aug) launch(pilot::cell_w2_kernel<2, true>); else launch(pilot::cell_w2_kernel<2, false>); }
     HIP_TRY(le);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
