@@ -25,8 +25,20 @@ constexpr float CELL_NEG_BIG = -1.0e30f;
 constexpr int CELL_WG = 1024;   // 16 waves share one pair: the self-pairs converge slowly and set the critical path
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 
+// the operand pieces of the cohort (see CellParams::Xb)
+struct CellXb {
+    const uint4 *p;
+    long long C;
+    __device__ inline const uint4 &at(long point, int kb, int piece, int g) const {
+        return p[((((long)kb * 3 + piece) * 2 + (g >> 1)) * C + point) * 2 + (g & 1)];
+    }
+};
+
 struct CellParams {
-    const uint4 *Xb;        // C x KB x 3 x 4 pieces of 16 bytes: Xb[((c*KB + kb)*3 + piece)*4 + g] = bf16 piece of X[c][32 kb + 8 g .. + 7]
+    const uint4 *Xb;        // bf16 operand pieces, 16 bytes = the 8 k-slots 32 kb + 8 g .. + 7 of one cell and piece, laid out
+                            // [kb][piece][g >> 1][cell][g & 1] (CellXb::at): the lanes of one load instruction cover consecutive
+                            // cells and so consecutive, fully used cache lines
+    long long C;            // cells in the cohort
     const float *nrm;       // C: |x_c|^2
     const long long *offs;  // N + 1: first cell of every patient
     int N;
@@ -48,7 +60,6 @@ struct CellParams {
 // one pre-pass over the cells: the three bf16 pieces of every (scaled) coordinate in MFMA operand order + squared norms
 __global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, float op_scale,
                                   unsigned short *__restrict__ Xb, float *__restrict__ nrm) {
-    const long per = (long)KB * 3 * 32;            // bf16 values per cell
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * KB * 32; idx += (long)gridDim.x * blockDim.x) {
         const long c = idx / (KB * 32);
         const int o = (int)(idx % (KB * 32)), kb = o / 32, d = o;      // coordinate d sits in k-block d / 32, slot d % 32
@@ -56,7 +67,8 @@ __global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, in
 #pragma unroll
         for (int piece = 0; piece < 3; ++piece) {
             const unsigned short hb = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
-            Xb[c * per + ((long)kb * 3 + piece) * 32 + (o % 32)] = hb;
+            const int g = (o % 32) / 8;
+            Xb[((((long)kb * 3 + piece) * 2 + (g >> 1)) * C + c) * 16 + (g & 1) * 8 + (o % 8)] = hb;
             x -= __uint_as_float((unsigned int)hb << 16);
         }
     }
@@ -71,11 +83,11 @@ using cell_bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
 using cell_f4 = float __attribute__((ext_vector_type(4)));
 // the lane's operand pieces of one point: p[kb][piece] = 8 bf16 (k-slots 8 g .. 8 g + 7 of k-block kb)
 template <int KB> struct CellOperand { uint4 p[KB][3]; };
-template <int KB> __device__ inline void cell_load(const uint4 *__restrict__ Xb, long point, int g, CellOperand<KB> &o) {
+template <int KB> __device__ inline void cell_load(const CellXb &Xb, long point, int g, CellOperand<KB> &o) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int piece = 0; piece < 3; ++piece) o.p[kb][piece] = Xb[((point * KB + kb) * 3 + piece) * 4 + g];
+        for (int piece = 0; piece < 3; ++piece) o.p[kb][piece] = Xb.at(point, kb, piece, g);
 }
 // exact 3-way split of an f32 into bf16 pieces by truncation (8 + 8 + 8 mantissa bits): x = hi + mid + lo
 __device__ inline void cell_split3(float x, unsigned int &hi, unsigned int &mid, unsigned int &lo) {
@@ -159,7 +171,7 @@ __device__ inline float row16_sum(float x) {
 // vector unit, not by the six MFMAs per tile).  use_ref = false (first update of a pair: no previous value), or a block
 // whose shifted sums leave [2^-64, 2^64] for any row (never seen in practice), takes the online-maximum form.
 template <int KB, bool AUG, class FN>
-__device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, long b0, int nb,
+__device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int nb,
                                 const float *h2 /* LDS, nb */, const float *hprev /* LDS, na */, float logw2,
                                 bool use_ref, int wave, int n_waves, int lane, FN &&fn) {
     using f4 = cell_f4;
@@ -289,7 +301,7 @@ __device__ inline void lse_pass(const uint4 *__restrict__ Xb, long a0, int na, l
 
 // sum_ij 2^(two_alpha2 <x_i, y_j> + hu2_i + hv2_j) * C_ij  for the rows handled by this wave (lane-local partial)
 template <int KB>
-__device__ inline float value_pass(const uint4 *__restrict__ Xb, long a0, const float *__restrict__ na2, int na,
+__device__ inline float value_pass(const CellXb &Xb, long a0, const float *__restrict__ na2, int na,
                                    long b0, const float *__restrict__ nb2, int nb,
                                    const float *hA2, const float *hB2, float dot_unscale, float inv_scale, int wave,
                                    int n_waves, int lane) {
@@ -340,6 +352,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
     int *qslot = reinterpret_cast<int *>(red + 32);
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, n_waves = blockDim.x / 64;
     const long total = (long)p.n_rows * p.N;
+    const CellXb Xb = {p.Xb, p.C};
 
     for (;;) {
         if (threadIdx.x == 0) qslot[0] = atomicAdd(p.queue, 1);
@@ -383,7 +396,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             //      after update ii-1 comes for free; if it stops the pair, (hu, hv_old) is exactly the plan POT returns.
             const bool check = ii > 0 && ((ii - 1) % p.period == 0);
             float e2 = 0.f;
-            lse_pass<KB, AUG>(p.Xb, o_q, nq, o_p, np, hu, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
+            lse_pass<KB, AUG>(Xb, o_q, nq, o_p, np, hu, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
                 if (check) {
                     const float d = __builtin_amdgcn_exp2f(hv_cur[row] + lse2) - bval;
                     e2 = fmaf(d, d, e2);
@@ -406,13 +419,13 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             }
             { float *t = hv_cur; hv_cur = hv_new; hv_new = t; }
             // ---- u-update:  hu_i = log a - LSE_j(2 alpha <x_i, y_j> + hv_j) -------------------------------------------
-            lse_pass<KB, AUG>(p.Xb, o_p, np, o_q, nq, hv_cur, hu, loga2, ii > 0, wave, n_waves, lane,
+            lse_pass<KB, AUG>(Xb, o_p, np, o_q, nq, hv_cur, hu, loga2, ii > 0, wave, n_waves, lane,
                          [&](int row, float lse2) { hu[row] = loga2 - lse2; });
             __syncthreads();
             iters = ii + 1;
         }
         // ---- value <Gamma, C> ---------------------------------------------------------------------------------------
-        float part = value_pass<KB>(p.Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
+        float part = value_pass<KB>(Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) red[16 + wave] = part;

@@ -1165,7 +1165,7 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
     }
     HIP_TRY(hipMemsetAsync(c->dQ, 0, sizeof(int), c->stream));
     pilot::CellParams p;
-    p.Xb = c->dXb; p.nrm = c->dnrm; p.offs = c->doffs; p.N = c->N;
+    p.Xb = c->dXb; p.C = c->C; p.nrm = c->dnrm; p.offs = c->doffs; p.N = c->N;
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
     const double alpha = 1.0 / (scale * reg);
     p.alpha = (float)alpha;
