@@ -23,7 +23,9 @@ def cohort(n_patients, cells, D, seed):
     return X, offs, scale
 
 
-@pytest.mark.parametrize("n_patients,cells,D", [(4, 40, 5), (5, 150, 30), (3, 333, 17), (3, 97, 50)])
+# D = 32 and D = 64 leave no spare k-slots in the 32-wide operand blocks: the kernel variant that adds the potentials on the
+# vector unit instead of carrying them through the MFMA
+@pytest.mark.parametrize("n_patients,cells,D", [(4, 40, 5), (5, 150, 30), (3, 333, 17), (3, 97, 50), (3, 120, 32), (3, 90, 64)])
 @pytest.mark.parametrize("reg", [0.5, 0.1])
 def test_cell_w2_parity(n_patients, cells, D, reg):
     X, offs, scale = cohort(n_patients, cells, D, seed=cells + D)
