@@ -30,6 +30,7 @@ struct EmdParams {
     double *emd;        // n_rows x N
     int *n_aug;         // nullable: augmentations per pair (diagnostic; negative = guard tripped)
     double *f_slab;     // global flow slabs (one K*K block per resident wave) when !F_IN_LDS
+    int *queue;         // dynamic pair queue (zeroed before the launch)
 };
 
 __device__ inline double rl_f64(double x, int lane) {
@@ -190,13 +191,38 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) EMD_WPE_ATTR emd_grid_kernel(E
     constexpr bool LAZY = NK >= 2 && EMD_LAZY;
     const long total = (long)p.n_rows * N;
 
-    // pairs are dealt round-robin to the resident waves (wave-uniform loop bounds)
-    const long n_waves = (long)gridDim.x * EMD_WAVES;
-    const long first = uni_i32(blockIdx.x * EMD_WAVES + wave);
-    for (long q = first; q < total; q += n_waves) {
-        const int r = (int)(q / N), j_s = (int)(q % N);
+    // Waves draw pairs from one device-wide counter.  (A static deal leaves the waves with very different numbers of SOLVED
+    // pairs when only the upper triangle is solved -- about 22 +- 5 of a wave's 44 at c3 -- and the launch ends with its
+    // unluckiest wave.)  With upper_only the counter runs over the solved pairs alone: local row r = rows row_begin +
+    // r row_step holds the N - i_s pairs j >= i_s, so item t sits in the row with offset(r) <= t < offset(r + 1),
+    // offset(r) = r (N - row_begin) - row_step r (r - 1) / 2.  Rows are drawn in order: the long rows start first.
+    const long n_items = p.upper_only ? (long)p.n_rows * (N - p.row_begin) - (long)p.row_step * p.n_rows * (p.n_rows - 1) / 2 : total;
+    auto row_offset = [&](long r) { return r * (N - p.row_begin) - (long)p.row_step * r * (r - 1) / 2; };
+    // (a wave's first item is its own number -- no burst of atomics on one address at the start of a small grid --, the
+    // following ones come from the counter, which starts behind the resident waves)
+    const int n_waves = (int)gridDim.x * EMD_WAVES;
+    for (bool first_item = true;; first_item = false) {
+        int ti = (int)blockIdx.x * EMD_WAVES + wave;
+        if (!first_item) {
+            if (lane == 0) ti = n_waves + __hip_atomic_fetch_add(p.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const long t = uni_i32(ti);
+        if (t >= n_items) break;
+        int r, j_s;
+        if (p.upper_only) {
+            const double a = 0.5 * p.row_step, b = (double)(N - p.row_begin) + a;      // offset(r) = b r - a r^2
+            const double disc = b * b - 4.0 * a * (double)t;
+            long rr = (long)((b - __builtin_sqrt(disc > 0.0 ? disc : 0.0)) / (2.0 * a));
+            rr = rr < 0 ? 0 : (rr > p.n_rows - 1 ? p.n_rows - 1 : rr);
+            while (rr + 1 < p.n_rows && row_offset(rr + 1) <= t) ++rr;                 // (the float estimate is off by at most one)
+            while (rr > 0 && row_offset(rr) > t) --rr;
+            r = uni_i32((int)rr);
+            j_s = uni_i32(p.row_begin + r * p.row_step + (int)(t - row_offset(rr)));
+        } else {
+            r = (int)(t / N); j_s = (int)(t % N);
+        }
+        const long q = (long)r * N + j_s;
         const int i_s = p.row_begin + r * p.row_step;
-        if (p.upper_only && j_s < i_s) continue;   // wave-uniform
 
         double pu[NK], pv[NK], ra[NK], rb[NK], dC[NK];
         int parR[NK], parC[NK];

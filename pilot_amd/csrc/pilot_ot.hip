@@ -878,7 +878,8 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.P = d_P; p.M = d_M; p.N = N; p.K = K;
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
     p.upper_only = mode != PILOT_OT_EMD_ALL;
-    p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab;
+    p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab; p.queue = pl->emd_counter;
+    HIP_TRY(hipMemsetAsync(pl->emd_counter, 0, sizeof(int), s));
     const long total = (long)n_rows * N;
     {
         if (K > EMD_MAX_K || !pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: K=%d > %d cell types", K, EMD_MAX_K);
