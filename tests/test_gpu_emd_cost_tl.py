@@ -37,9 +37,10 @@ def test_emd_modes_and_symmetry():
         engine.emd_grid(P, M, row_begin=1, mode="mirror")
 
 
-@pytest.mark.parametrize("K", [1, 2, 17, 64, 65, 100, 128])
+@pytest.mark.parametrize("K", [1, 2, 17, 64, 65, 100, 128, 129, 192, 193, 256])
 def test_emd_every_k_regime(K):
-    """K <= 64: one row/column per lane; K > 64: two (flow support masks of 2 x 64 bits per row)."""
+    """K <= 64: one row/column per lane; K > 64: two (flow support masks of 2 x 64 bits per row, lazy restarts); K > 128:
+    three / four, cost matrix read from global memory."""
     P, M = make_problem(12, K, 6, seed=200 + K, cells_per_patient=500)
     if K == 1:
         M = np.zeros((1, 1))
@@ -83,6 +84,32 @@ def test_emd_randomized_stress(K, sparsity, nonzero_diag, seed):
     assert (info["n_aug"] >= 0).all()
     assert np.abs(Eg - Eo).max() <= 1e-12
     assert Eg.min() >= -1e-15 and Eg.max() <= M.max() * P.sum(1).max() + 1e-12
+
+
+@pytest.mark.parametrize("K,seed", [(40, 11), (64, 12), (90, 13), (150, 14)])
+def test_emd_lattice_masses_and_integer_costs_vs_linprog(K, seed):
+    """Everything ties: masses are multiples of 1/32 (many bins empty, sources run dry and arcs run empty together),
+    costs are small integers.  The LP optimum from scipy's HiGHS on sampled pairs, the oracle on all of them; every
+    code path of the search (several augmentations per search, lazy restarts for K > 64, single-hop paths) is hit."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(seed)
+    N = 40
+    P = rng.multinomial(32, rng.dirichlet(0.3 * np.ones(K), size=N)[0], size=N).astype(np.float64) / 32.0
+    P[5] = P[6]
+    line = np.abs(np.arange(K)[:, None] - np.arange(K)[None, :]).astype(np.float64)
+    M = np.minimum(line, 7.0)                                       # truncated line metric: integer, heavily tied
+    Eo = O.emd_grid(P, M, n_threads=16)
+    Eg, info = engine.emd_grid(P, M, return_info=True)
+    assert (info["n_aug"][np.triu_indices(N)] >= 0).all()
+    assert np.abs(Eg - Eo).max() <= 1e-12
+    assert np.abs(Eg - Eg.T).max() == 0.0 and np.abs(np.diag(Eg)).max() == 0.0
+    A_eq = np.zeros((2 * K, K * K))
+    for i in range(K):
+        A_eq[i, i * K:(i + 1) * K] = 1.0
+        A_eq[K + i, i::K] = 1.0
+    for (i, j) in [(0, 1), (2, 30), (5, 6), (17, 39)]:
+        res = linprog(M.ravel(), A_eq=A_eq, b_eq=np.concatenate([P[i], P[j]]), bounds=(0, None), method="highs")
+        assert res.status == 0 and abs(res.fun - Eg[i, j]) <= 1e-9
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
