@@ -72,6 +72,10 @@ def test_cell_w2_resident_cohort_shards_and_devices():
             np.testing.assert_array_equal(ig["iters"], iref["iters"])
         assert co.last_kernel_ms > 0
         np.testing.assert_array_equal(co.w2_grid(scale, 0.2, row_begin=1, row_step=3), ref[1::3])
+        # another reg rebuilds the (scaled) operand pieces on the device; going back gives the first bits again
+        other = co.w2_grid(scale, 0.5)
+        np.testing.assert_array_equal(other, engine.cell_w2_grid(X, offs, scale, 0.5))
+        np.testing.assert_array_equal(co.w2_grid(scale, 0.2), ref)
         co.close()
         multi, im = engine.cell_w2_grid(X, offs, scale, 0.2, devices=[0, 0, 0], return_info=True)
         np.testing.assert_array_equal(multi, ref)
