@@ -619,6 +619,7 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
                     rv = live ? T(K) * C::rcp(v) : T(0);
                     abs_at = ii;
                     flags |= FLAG_ABSORBED;
+                    if (__ballot(live && (u == T(0) || v == T(0)))) u = T(__builtin_nanf(""));   // empty bins: see the stream kernel
                 }
             } else {
                 if (__ballot(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
@@ -1016,6 +1017,21 @@ sinkhorn_stream_kernel(GridParams p) {
                     }
                 abs_at = ii;
                 flags |= FLAG_ABSORBED;
+            }
+            if (omask) {    // (wave-uniform, rare)
+                // An empty bin (a_k = 0 or b_k = 0, so u_k = 0 or v_k = 0 exactly) makes POT's absorption take log(0): the
+                // potential becomes -inf, the rebuilt kernel row 0 and the next update 0/0 -- "Numerical errors", POT
+                // returns the iterate before it.  The books kept here cannot express that; the pair is poisoned instead, ends
+                // as NaN at its next test and is solved again by the POT-literal kernel (nan_list), which walks exactly
+                // that path.  (The reference's proportions are strictly positive: Trajectory.py:405-430.)
+                bool z = false;
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r)
+                        z = z || (M::lidx(t, r, grp) < K && (U[t][r] == T(0) || V[t][r] == T(0)));
+                const unsigned long long zmask = column_any_mask<C>(over && z);
+                if ((zmask >> col) & 1ull) U[0][0] = __builtin_nanf("");
             }
         } else {
             // hand the pair to the tracking kernel (it restarts the pair from its first update)

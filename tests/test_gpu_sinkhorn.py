@@ -241,6 +241,34 @@ def test_deterministic_across_runs():
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("K", [12, 50])
+@pytest.mark.parametrize("reg", [1.0, 0.1, 0.02])
+def test_empty_bins_follow_pot_through_the_absorption(K, reg):
+    """Histograms with empty bins (not produced by the reference, whose prior keeps every proportion positive, but legal
+    for ot.sinkhorn2): without an absorption nothing special happens; WITH one POT takes log(0), rebuilds a kernel with
+    zero rows, hits 0/0 at the next update and returns the iterate before it ("Numerical errors").  The engine sends such
+    pairs to the POT-literal kernel: values, update counts and flags equal the oracle's."""
+    from scipy.spatial.distance import pdist, squareform
+    rng = np.random.default_rng(3 + K)
+    P = rng.dirichlet(0.3 * np.ones(K), size=24)
+    P[P < 2e-2] = 0.0
+    P[0] = 0.0; P[0, 3] = 1.0
+    P /= P.sum(1, keepdims=True)
+    M = squareform(pdist(rng.standard_normal((K, 8)), "cosine"))
+    M /= M.max()
+    Eo, io = O.sinkhorn_grid(P, M, reg, return_info=True, n_threads=8)
+    nan_revert = (io["flags"] & O.FLAG_NAN_REVERT) > 0
+    assert nan_revert.any() == (reg < 1.0)                    # the path is taken at the smaller regs
+    for prec, tol in (("auto", TOL32), ("fp32", TOL32), ("fp64", 1e-12)):
+        Eg, ig = engine.sinkhorn_grid(P, M, reg, precision=prec, return_info=True)
+        assert np.isfinite(Eg).all()
+        assert np.abs(Eg - Eo).max() <= tol
+        got = (ig["flags"] & _lib.FLAG_NAN) > 0
+        np.testing.assert_array_equal(got, nan_revert)
+        np.testing.assert_array_equal(ig["iters"][nan_revert], io["iters"][nan_revert])
+        assert np.abs(Eg - Eo)[nan_revert].max(initial=0.0) <= 1e-12      # those pairs are solved in fp64, POT's way
+
+
 def test_graph_replay_gives_the_same_bits_and_follows_argument_and_content_changes():
     """pilot_ot_plan_enable_graph: the third identical call replays a captured hipGraph; results are bit-identical to
     ordinary launches, a changed argument falls back (and re-captures), new CONTENTS of P are seen by the replay."""
