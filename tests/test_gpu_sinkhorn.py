@@ -269,6 +269,33 @@ def test_empty_bins_follow_pot_through_the_absorption(K, reg):
         assert np.abs(Eg - Eo)[nan_revert].max(initial=0.0) <= 1e-12      # those pairs are solved in fp64, POT's way
 
 
+@pytest.mark.parametrize("case", ["unequal_masses", "tiny_masses", "huge_reg", "constant_cost", "zero_cost", "one_patient",
+                                  "tau5", "cap3", "stop1e-3"])
+def test_edge_inputs_against_the_oracle(case):
+    """Inputs the reference never produces but ot.sinkhorn2 accepts.  Pairs whose absorption lands on the final update
+    (POT then returns the plan / K^2) in one precision but not in the other sit on a knife edge and are compared in f64 only."""
+    P, M = make_problem(16, 20, 6, seed=5, cells_per_patient=400)
+    reg, kw_o, kw_g = 0.1, {}, {}
+    if case == "unequal_masses": P = P * np.linspace(0.5, 2.0, 16)[:, None]       # no rescaling in sinkhorn2: never converges
+    if case == "tiny_masses": P = P * 1e-6
+    if case == "huge_reg": reg = 100.0
+    if case == "constant_cost": M = np.ones_like(M) - np.eye(20)
+    if case == "zero_cost": M = np.zeros_like(M)
+    if case == "one_patient": P = P[:1]
+    if case == "tau5": kw_o, kw_g = dict(tau=5.0), dict(tau=5.0)
+    if case == "cap3": kw_o, kw_g = dict(numItermax=3), dict(num_iter_max=3)
+    if case == "stop1e-3": kw_o, kw_g = dict(stopThr=1e-3), dict(stop_thr=1e-3)
+    Eo, io = O.sinkhorn_grid(P, M, reg, return_info=True, n_threads=8, **kw_o)
+    E64, i64 = engine.sinkhorn_grid(P, M, reg, precision="fp64", return_info=True, **kw_g)
+    assert np.abs(E64 - Eo).max() <= 1e-12 * max(1.0, np.abs(Eo).max())
+    np.testing.assert_array_equal(i64["iters"], io["iters"])
+    for prec in ("auto", "fp32"):
+        Eg, ig = engine.sinkhorn_grid(P, M, reg, precision=prec, return_info=True, **kw_g)
+        edge = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) != ((ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+        assert np.isfinite(Eg).all() and edge.mean() < 0.05
+        assert np.abs(Eg - Eo)[~edge].max() <= TOL32 * max(1.0, np.abs(Eo).max())
+
+
 def test_graph_replay_gives_the_same_bits_and_follows_argument_and_content_changes():
     """pilot_ot_plan_enable_graph: the third identical call replays a captured hipGraph; results are bit-identical to
     ordinary launches, a changed argument falls back (and re-captures), new CONTENTS of P are seen by the replay."""
