@@ -155,6 +155,14 @@ def wasserstein_d(Clu_rep, cost, regularized="unreg", reg=0.1, engine_options=No
     else:
         P = np.stack([np.asarray(Clu_rep[s], dtype=np.float64) for s in samples_id])
         cost = np.asarray(cost, dtype=np.float64)
+        if regularized == "unreg":
+            # ot.emd2 (POT 0.9: check_marginals=True) refuses histograms of different mass before it rescales them:
+            # np.testing.assert_almost_equal(a.sum(0), b.sum(0), decimal=6).  With normalization=False the reference's
+            # proportions are raw counts and this is what stops it (Trajectory.py:428-436, :511).
+            sums = P.sum(1)
+            if sums.size and float(sums.max() - sums.min()) >= 1.5e-6:
+                raise AssertionError("a and b vector must have the same sum (sample masses range from %g to %g)"
+                                     % (sums.min(), sums.max()))
         multi = {k: opts.pop(k) for k in ("devices", "n_devices", "gather") if k in opts}
         if multi.get("devices") is not None or (multi.get("n_devices") or 1) > 1:
             # the pair grid row-sharded over several GPUs of this node, one RCCL all-gather (pilot_amd.multi)

@@ -91,3 +91,12 @@ def test_return_sil_ari_is_rejected_loudly_before_any_device_work():
     ad, _ = golden_adata(g)
     with pytest.raises(KeyError):
         tl.wasserstein_distance(ad, emb_matrix="X_PCA")            # reference default key, absent here
+
+
+def test_unequal_masses_stop_the_exact_mode_like_pot():
+    """ot.emd2 asserts equal masses (check_marginals) before anything runs; the mirror raises the same way, without a GPU."""
+    from pilot_amd import tl
+    reps = {"s1": np.array([2.0, 1.0, 1.0]), "s2": np.array([1.0, 1.0, 1.0])}       # raw counts (normalization=False)
+    cost = 1.0 - np.eye(3)
+    with pytest.raises(AssertionError, match="same sum"):
+        tl.wasserstein_d(reps, cost, regularized="unreg")
