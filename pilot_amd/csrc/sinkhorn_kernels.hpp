@@ -924,7 +924,7 @@ sinkhorn_stream_kernel(GridParams p) {
 
     // work queue: waves draw batches of TILE items from one device-wide counter, so a wave that got
     // long-running pairs simply draws fewer batches
-    int res_next = 0, res_end = 0;
+    int res_next = 0, res_end = 0, res_base = 0, qbatch = 0;
     bool exhausted = false;
     bool want = true;  // column asks for a (new) pair
     for (;;) {
@@ -939,12 +939,18 @@ sinkhorn_stream_kernel(GridParams p) {
                 res_next = exhausted ? n_items : base;
                 res_end = (base + TILE < n_items) ? base + TILE : n_items;
                 if (exhausted) res_end = n_items;
+                // the work-item numbers of the whole batch, one per lane (lane % TILE): the refills that take items of this
+                // batch later read them from here instead of chaining a list load in front of their row loads
+                res_base = base;
+                const int bi = base + col;
+                qbatch = (p.list && bi < n_items) ? p.list[bi] : bi;
             }
             const int avail = res_end - res_next;
             const int n_want = (int)__popcll(wmask);
             const int rank = (int)__popcll(wmask & ((1ull << col) - 1ull));
             const int item = res_next + rank;
             const bool take = want && rank < avail;
+            const int qsel = __builtin_amdgcn_ds_bpermute(4 * ((item - res_base) & (TILE - 1)), qbatch);     // (every lane takes part)
             res_next = __builtin_amdgcn_readfirstlane(res_next + (n_want < avail ? n_want : avail));
             if (want && !take && exhausted) {   // no work left: the slot goes dark
                 want = false;
@@ -956,7 +962,7 @@ sinkhorn_stream_kernel(GridParams p) {
             if (take) {
                 want = false;
                 active = true;
-                q = p.list ? p.list[item] : item;
+                q = qsel;
                 const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
                 const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
 #pragma unroll
