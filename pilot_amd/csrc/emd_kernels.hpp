@@ -6,14 +6,18 @@
 // GPU the problem is solved by successive shortest augmenting paths (multi-source: from any row with supply left
 // to any column with demand left) with node potentials
 // (complementary slackness is kept after every augmentation, so the final flow is optimal):
-//   * lane l owns row l and column l (and l+64 when K > 64): supplies/demands, potentials, Dijkstra
-//     labels and predecessor links live in registers;
-//   * one Dijkstra step = wave-wide arg-min over the unscanned labels (xor-shuffle reduction) and ONE
-//     parallel relaxation: a scanned row relaxes all K columns at once (row of M from LDS, coalesced),
-//     a scanned column relaxes all rows that currently ship to it (column of the flow matrix);
+//   * lane l owns row l and column l (and l + 64, l + 128, l + 192 for K up to 256): supplies/demands, potentials,
+//     Dijkstra labels and predecessor links live in registers;
+//   * one Dijkstra step = wave-wide minimum over the open column labels (a six-stage v_min_u32_dpp scan) and ONE
+//     parallel relaxation per scanned row: it relaxes all K columns at once (row of M from LDS, coalesced); a scanned
+//     column reaches the rows that currently ship to it (one AND against the support masks), and they are scanned in the
+//     same step -- every node tied at the minimum is handled in that one step;
+//   * a target is augmented at once, without touching the potentials, and the search goes on while its tree is valid
+//     (several augmentations per search); the potentials are brought up to date when a new search starts;
 //   * flow values in an L2-resident global slab per wave, flow support as bit masks in registers (see below);
 //   * path tracing / bottleneck / flow update walk the predecessor links with wave-uniform indices
-//     (v_readlane), touching one flow entry per hop.
+//     (v_readlane / v_writelane), touching one flow entry per hop;
+//   * pairs are drawn from a device-wide counter over the SOLVED pairs (upper triangle only for a symmetric cost).
 // All arithmetic is fp64 like POT's.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -144,13 +148,14 @@ __device__ inline bool bits_less(double a, double b) {
 }
 
 
-// NK = rows/columns per lane (1: K <= 64, 2: K <= 128).
+// NK = rows/columns per lane (1: K <= 64, 2: K <= 128, 3 / 4: K <= 192 / 256 with MG).
 //   * the cost matrix M and its row minima live in LDS (shared by the workgroup);
 //   * the flow VALUES live in an L2-resident global slab of K*K doubles per resident wave (row-major, zeroed per pair) and
 //     are touched only along augmenting paths and for the final cost;
 //   * the flow SUPPORT lives in registers: lane i keeps a bit mask of the columns row i currently ships to, so "which
 //     rows ship to the columns being scanned" is one 64-bit AND against the ballot mask of those columns.
-// Nothing per wave is in LDS, so occupancy is bounded by registers only (the step loop is pure latency).
+// Nothing per wave is in LDS, so occupancy is bounded by registers (and, from K = 91 on, by the LDS copy of M).
+// EMD_LAZY / EMD_WPE: experiment switches (lazy restarts for NK >= 2; per-variant register caps), see ab_experiments.md.
 constexpr int EMD_WAVES = 8;
 #ifndef EMD_LAZY
 #define EMD_LAZY 1
