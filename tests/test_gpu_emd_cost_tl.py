@@ -86,6 +86,25 @@ def test_emd_randomized_stress(K, sparsity, nonzero_diag, seed):
     assert Eg.min() >= -1e-15 and Eg.max() <= M.max() * P.sum(1).max() + 1e-12
 
 
+def test_emd_upper_triangle_queue_over_row_subsets():
+    """mode "upper" draws its pairs from a counter that enumerates only column >= row, row by row (row offsets inverted
+    with a square root and fixed up): every row subset must give exactly the rows of the full matrix, nothing solved
+    twice, nothing left out (untouched entries stay 0)."""
+    rng = np.random.default_rng(77)
+    N, K = 157, 9
+    P = rng.dirichlet(np.ones(K), size=N)
+    M = rng.random((K, K)); M = M + M.T; np.fill_diagonal(M, 0.0)
+    full = engine.emd_grid(P, M, mode="all")
+    cases = [(0, N, 1), (0, N, 2), (1, N, 2), (5, 140, 7), (156, 157, 1), (0, 1, 1), (3, 150, 149), (10, 11, 5), (0, N, 156)]
+    cases += [(int(b), int(min(N, b + 1 + rng.integers(0, N - b))), int(s)) for b, s in zip(rng.integers(0, N, 12), rng.integers(1, 40, 12))]
+    for rb, re_, rs in cases:
+        rows = np.arange(rb, re_, rs)
+        U, info = engine.emd_grid(P, M, row_begin=rb, row_end=re_, row_step=rs, mode="upper", return_info=True)
+        want = np.where(np.arange(N)[None, :] >= rows[:, None], full[rows], 0.0)
+        np.testing.assert_array_equal(U, want)
+        assert ((info["n_aug"] > 0) <= (np.arange(N)[None, :] >= rows[:, None])).all()
+
+
 @pytest.mark.parametrize("K,seed", [(40, 11), (64, 12), (90, 13), (150, 14)])
 def test_emd_lattice_masses_and_integer_costs_vs_linprog(K, seed):
     """Everything ties: masses are multiples of 1/32 (many bins empty, sources run dry and arcs run empty together),
