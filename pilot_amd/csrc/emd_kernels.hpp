@@ -156,7 +156,10 @@ __device__ inline bool bits_less(double a, double b) {
 //     rows ship to the columns being scanned" is one 64-bit AND against the ballot mask of those columns.
 // Nothing per wave is in LDS, so occupancy is bounded by registers (and, from K = 91 on, by the LDS copy of M).
 // EMD_LAZY / EMD_WPE: experiment switches (lazy restarts for NK >= 2; per-variant register caps), see ab_experiments.md.
-constexpr int EMD_WAVES = 8;
+// waves per workgroup: 8 (two per SIMD) in general; 16 for 64 < K <= 128, where the LDS copy of M (up to 128 KB) allows
+// at most two workgroups per CU -- with 8 waves each that is 4 waves per SIMD, too few to hide the latencies of this
+// kernel; 2 x 16 waves of <= 64 registers run c4 in 0.47 s instead of 0.55 s (ab_experiments.md)
+__host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? 16 : 8; }
 #ifndef EMD_LAZY
 #define EMD_LAZY 1
 #endif
@@ -164,14 +167,15 @@ constexpr int EMD_WAVES = 8;
 #define EMD_WPE 1
 #endif
 #if EMD_WPE
-#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK == 1 ? 8 : (NK == 2 ? 4 : 2), 8)))
+#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK <= 2 ? 8 : 2, 8)))
 #else
 #define EMD_WPE_ATTR
 #endif
 
 // MG: the cost matrix is read from global memory (L2) instead of LDS -- K > 128, where K*K doubles no longer fit LDS
 template <int NK, bool MG = false>
-__global__ void __launch_bounds__(64 * EMD_WAVES) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
+__global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
+    constexpr int EMD_WAVES = emd_waves(NK);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -191,9 +195,10 @@ __global__ void __launch_bounds__(64 * EMD_WAVES) EMD_WPE_ATTR emd_grid_kernel(E
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
     const double INF = __builtin_inf(), NEG = -1.0;
     // LAZY: keep a search going after an augmentation dried its root / emptied an arc / left its target open, and restart
-    // only when a later path turns out to be unusable (pays from K > 64 on: c4 0.73 -> 0.66 s; at K = 50 the searches drop
-    // from 41 to 22 per pair but the steps do not, and the extra state costs registers: 10.5 -> 11.7 ms)
-    constexpr bool LAZY = NK >= 2 && EMD_LAZY;
+    // only when a later path turns out to be unusable.  At K = 50 the searches drop from 41 to 22 per pair but the steps do
+    // not, and the extra state costs registers (10.5 -> 11.7 ms); at K = 100 it paid at 4 waves per SIMD (0.73 -> 0.66 s) but
+    // the eager form at 8 waves per SIMD and <= 64 registers is faster still (0.47 s): kept for the K > 128 variants only
+    constexpr bool LAZY = NK >= 3 && EMD_LAZY;
     const long total = (long)p.n_rows * N;
 
     // Waves draw pairs from one device-wide counter.  (A static deal leaves the waves with very different numbers of SOLVED

@@ -146,12 +146,13 @@ constexpr int CTRL_INTS = 16;      // control block of a call: see pilot_ot_plan
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
-// exact-EMD kernel: workgroups of pilot::EMD_WAVES waves, M (+ row minima) in LDS; resident workgroups per CU
+// exact-EMD kernel: workgroups of pilot::emd_waves(NK) waves, M (+ row minima) in LDS; resident workgroups per CU
+static int emd_nk(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : (K <= 192 ? 3 : 4)); }
 static int emd_wgs_per_cu(int K) {
     if (K > 128) return 1;                      // cost matrix in global memory, 3-4 rows per lane: one workgroup per CU
     const size_t lds = sizeof(double) * ((size_t)K * K + K);
     int by_lds = (int)(LDS_BYTES / lds);
-    const int by_regs = K <= 64 ? 4 : 2;        // 58 / 88 VGPRs per lane: 8 / 5 waves per SIMD
+    const int by_regs = K <= 64 ? 4 : 2;        // <= 64 VGPRs per lane: 4 x 8 or 2 x 16 waves = 8 per SIMD
     if (by_lds > by_regs) by_lds = by_regs;
     return by_lds < 1 ? 1 : by_lds;
 }
@@ -340,7 +341,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
     if (e == hipSuccess && K <= EMD_MAX_K)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
-                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::EMD_WAVES);
+                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)));
     if (e != hipSuccess) {
         pilot_ot_plan_destroy(pl);
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
@@ -885,21 +886,22 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         if (K > EMD_MAX_K || !pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: K=%d > %d cell types", K, EMD_MAX_K);
         const size_t lds = K > 128 ? sizeof(double) * (size_t)K : sizeof(double) * ((size_t)K * K + K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
-        long wgs = (total + pilot::EMD_WAVES - 1) / pilot::EMD_WAVES;
+        const int waves = pilot::emd_waves(emd_nk(K));
+        long wgs = (total + waves - 1) / waves;
         const long cap = (long)pl->n_cu * emd_wgs_per_cu(K);
         if (wgs > cap) wgs = cap;
         if (K > 192) {
-            hipLaunchKernelGGL((pilot::emd_grid_kernel<4, true>), dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+            hipLaunchKernelGGL((pilot::emd_grid_kernel<4, true>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else if (K > 128) {
-            hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true>), dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+            hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else if (K <= 64) {
             auto kern = pilot::emd_grid_kernel<1>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else {
             auto kern = pilot::emd_grid_kernel<2>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * pilot::EMD_WAVES), lds, s, p);
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         }
     }
     HIP_TRY(hipGetLastError());
