@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R/pilot_amd/csrc
 cp ../libpilot_ot.so /tmp/libpilot_ot.keep.so
-run() { for cfg in c2 c3; do timeout 120 python3 $R/bench.py --config $cfg --no-extras --no-cpu-baseline | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$1] $cfg: %.4f ms  kernel %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"; done; }
+run() { for cfg in ${K2_CFGS:-c2 c3}; do timeout 120 python3 $R/bench.py --config $cfg --no-extras --no-cpu-baseline | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$1] $cfg: %.4f ms  kernel %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"; done; }
 run baseline
 for v in "$@"; do
   for part in 6 7; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function $v -DSK_PART=$part -c -o /tmp/sk_var_$part.o sk_inst.hip 2>/dev/null & done; wait
