@@ -1217,15 +1217,20 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
     }
     }
     // first product of every pair: (G^T u0)[j] = (1/K) * sum_k G[k][j], in accumulator-slot order
-    for (int idx = tid; idx < KP; idx += nthr) {
-        const int r = idx % M::NREG;                              // slot order [tile][group][reg]
-        const int g = (idx / M::NREG) % M::NGRP;
-        const int t = idx / (M::NGRP * M::NREG);
+    // (four adjacent lanes share a slot, each sums every fourth k: the K serial fp64 exponentials of a slot were the longest
+    // chain of the whole preparation)
+    for (int idx = tid; idx < 4 * KP; idx += nthr) {              // (4 KP and nthr are multiples of the wave size)
+        const int part = idx & 3, slot = idx >> 2;
+        const int r = slot % M::NREG;                             // slot order [tile][group][reg]
+        const int g = (slot / M::NREG) % M::NGRP;
+        const int t = slot / (M::NGRP * M::NREG);
         const int j = M::lidx(t, r, g);
         double s = 0.0;
         if (j < K)
-            for (int k = 0; k < K; ++k) s += exp(-Msrc[(size_t)k * K + j] / reg);
-        img[acc0_offset<C>(RT) + idx] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
+            for (int k = part; k < K; k += 4) s += exp(-Msrc[(size_t)k * K + j] / reg);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0) img[acc0_offset<C>(RT) + slot] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
     }
     // tail-row weights for the VALU variant (see tail_rows): [form][chain][k-step][lane] pairs behind the table
     if (write_tail & 2) {     // plain tables of solo_pairs: G[lane][k], G[k][lane], (G o M)[lane][k]
