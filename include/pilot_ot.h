@@ -64,7 +64,8 @@ extern "C" {
 #define PILOT_OT_FLAG_NAN 2            /* a scaling became NaN (POT: "Numerical errors"): the pair was re-solved by the
                                         * POT-literal kernel, emd = cost of the last good iterate like POT returns
                                         * (also: histograms with empty bins that reach a tau-absorption, where POT's
-                                        * log(0) leads to 0/0 one update later) */
+                                        * log(0) leads to 0/0 one update later; and pairs of unequal mass whose total
+                                        * scalings leave the exact range of the fast kernels) */
 #define PILOT_OT_FLAG_ABSORB_LAST 4    /* POT tau-absorption fell on the final update (plan /K^2)   */
 #define PILOT_OT_FLAG_ABSORBED 8       /* at least one POT tau-absorption happened                  */
 #define PILOT_OT_FLAG_F64 16           /* pair was solved by the f64 kernel                         */

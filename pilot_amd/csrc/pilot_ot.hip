@@ -681,8 +681,14 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     const int cfg = mixed ? pilot::CFG_S32
                           : (precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : pilot::CFG_F64));
     auto run = [&](hipStream_t on) {
-        return run_grid(cfg, pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0,
-                        row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, on, mixed);
+        int r = run_grid(cfg, pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0,
+                         row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, on, mixed);
+        // a shape whose operand images do not fit LDS in this precision (non-symmetric cost at large K): the POT-literal
+        // kernel takes the whole grid -- the reference has no such limit
+        if (r == PILOT_OT_ENOTSUP)
+            r = run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows, row_step, d_emd, d_iters, d_err,
+                            d_flags, on);
+        return r;
     };
     if (!pl->graph_mode || pl->timing || n_rows == 0) return run(s);
     // graph replay: the first call with a new argument set runs as usual (and grows the work buffers), the second one is

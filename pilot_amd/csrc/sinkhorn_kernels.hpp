@@ -619,7 +619,11 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
                     rv = live ? T(K) * C::rcp(v) : T(0);
                     abs_at = ii;
                     flags |= FLAG_ABSORBED;
-                    if (__ballot(live && (u == T(0) || v == T(0)))) u = T(__builtin_nanf(""));   // empty bins: see the stream kernel
+                    {   // empty bins / scalings out of the exact range: see the stream kernel
+                        constexpr T BIG = sizeof(T) == 4 ? T(1.2676506e30) : T(8.452712498170644e270);
+                        constexpr T SMALL = T(1) / BIG;
+                        if (__ballot(live && !(u >= SMALL && u < BIG && v >= SMALL && v < BIG))) u = T(__builtin_nanf(""));
+                    }
                 }
             } else {
                 if (__ballot(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
@@ -659,7 +663,7 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
                     val = wave_sum(live ? u * val : T(0));
                     if (TRACK && abs_at >= 0 && abs_at == ii - 1) { val *= T(1) / kk; flags |= FLAG_ABSORB_LAST; }
                     if (lane == 0) {
-                        if (val != val) flags |= FLAG_NAN;
+                        if (!(val - val == T(0))) flags |= FLAG_NAN;     // NaN or inf
                         if (p.nan_list && (flags & FLAG_NAN)) {
                             p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
                         } else {
@@ -766,7 +770,7 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
         int fl = meta[1];
         if (redo || (p.fb_list && (fl & FLAG_NAN))) {
             p.fb_list[__hip_atomic_fetch_add(p.fb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
-        } else if (p.nan_list && (val != val || (fl & FLAG_NAN))) {
+        } else if (p.nan_list && (!(val - val == T(0)) || (fl & FLAG_NAN))) {       // NaN or inf
             p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
         } else {
             if (val != val) fl |= FLAG_NAN;
@@ -1030,12 +1034,18 @@ sinkhorn_stream_kernel(GridParams p) {
                 // returns the iterate before it.  The books kept here cannot express that; the pair is poisoned instead, ends
                 // as NaN at its next test and is solved again by the POT-literal kernel (nan_list), which walks exactly
                 // that path.  (The reference's proportions are strictly positive: Trajectory.py:405-430.)
+                // The same exit for total scalings that leave the range in which these books are exact (2^+-100 in f32,
+                // 2^+-900 in f64): histograms of unequal mass never converge and their scalings grow by the mass ratio at
+                // every update -- POT carries that in its log-domain potentials, the fixed Gibbs image cannot.  Between two
+                // absorptions a scaling moves by at most tau times one update's growth, so testing here is early enough.
+                constexpr T BIG = sizeof(T) == 4 ? T(1.2676506e30) : T(8.452712498170644e270);     // 2^100, 2^900
+                constexpr T SMALL = T(1) / BIG;
                 bool z = false;
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int r = 0; r < NREG; ++r)
-                        z = z || (M::lidx(t, r, grp) < K && (U[t][r] == T(0) || V[t][r] == T(0)));
+                        z = z || (M::lidx(t, r, grp) < K && !(U[t][r] >= SMALL && U[t][r] < BIG && V[t][r] >= SMALL && V[t][r] < BIG));
                 const unsigned long long zmask = column_any_mask<C>(over && z);
                 if ((zmask >> col) & 1ull) U[0][0] = __builtin_nanf("");
             }

@@ -296,6 +296,43 @@ def test_edge_inputs_against_the_oracle(case):
         assert np.abs(Eg - Eo)[~edge].max() <= TOL32 * max(1.0, np.abs(Eo).max())
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_randomized_shapes_and_options_against_the_oracle(seed):
+    """tools/fuzz_sinkhorn.py in small: random N, K (across every tile count), reg, tau, iteration caps, empty bins, unequal
+    masses (scalings that leave the f32 / f64 range are handed to the POT-literal kernel), non-symmetric costs (at K = 128
+    the operand images of a non-symmetric cost do not fit LDS in f64: the POT-literal kernel takes the grid).  fp64 must
+    agree in value and update count, the f32 paths in value wherever the absorb-on-the-final-update flag agrees."""
+    from scipy.spatial.distance import pdist, squareform
+    rng = np.random.default_rng(seed)
+    for _ in range(14):
+        N = int(rng.integers(1, 50)); K = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 20, 31, 32, 33, 48, 50, 64, 65, 80, 100, 128]))
+        reg = float(rng.choice([1.0, 0.3, 0.1, 0.05, 0.02, 0.01]))
+        P = rng.dirichlet(float(rng.choice([0.2, 1.0, 5.0])) * np.ones(K), size=N)
+        if rng.random() < 0.3:
+            P[P < 0.02] = 0.0; P[P.sum(1) == 0, 0] = 1.0; P /= P.sum(1, keepdims=True)
+        if rng.random() < 0.25:
+            P *= rng.uniform(0.5, 2.0, size=(N, 1))
+        M = np.zeros((1, 1))
+        if K > 1:
+            M = squareform(pdist(rng.standard_normal((K, 6)), str(rng.choice(["cosine", "euclidean", "cityblock"])))); M /= M.max()
+            if rng.random() < 0.15:
+                M = M * rng.uniform(0.7, 1.0, size=M.shape); M /= M.max()
+        kw_o, kw_g = {}, {}
+        if rng.random() < 0.2: kw_o["tau"] = kw_g["tau"] = float(rng.choice([6.5, 50.0]))
+        if rng.random() < 0.2: kw_o["numItermax"] = kw_g["num_iter_max"] = int(rng.choice([1, 7, 40, 200]))
+        Eo, io = O.sinkhorn_grid(P, M, reg, return_info=True, n_threads=8, **kw_o)
+        assert np.isfinite(Eo).all()
+        tag = "N=%d K=%d reg=%g %s" % (N, K, reg, kw_g)
+        E64, i64 = engine.sinkhorn_grid(P, M, reg, precision="fp64", return_info=True, **kw_g)
+        assert np.abs(E64 - Eo).max() <= 1e-11 * max(1.0, np.abs(Eo).max()), tag
+        np.testing.assert_array_equal(i64["iters"], io["iters"], err_msg=tag)
+        for prec in (("auto", "fp32") if 1.0 / reg <= 60.0 else ("auto",)):
+            Eg, ig = engine.sinkhorn_grid(P, M, reg, precision=prec, return_info=True, **kw_g)
+            edge = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) != ((ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+            assert np.isfinite(Eg).all() and edge.mean() <= 0.1, tag
+            assert np.abs(Eg - Eo)[~edge].max(initial=0.0) <= TOL32 * max(1.0, np.abs(Eo).max()), tag + " " + prec
+
+
 def test_graph_replay_gives_the_same_bits_and_follows_argument_and_content_changes():
     """pilot_ot_plan_enable_graph: the third identical call replays a captured hipGraph; results are bit-identical to
     ordinary launches, a changed argument falls back (and re-captures), new CONTENTS of P are seen by the replay."""
