@@ -165,7 +165,8 @@ int pilot_ot_plan_enable_graph(pilot_ot_plan *plan, int enable);
  * (after POT's own pre-step b *= sum(a)/sum(b)).  fp64 throughout.
  * mode: PILOT_OT_EMD_ALL    every selected (row, column) pair is solved;
  *       PILOT_OT_EMD_UPPER  only pairs with column >= row are solved, the rest of emd is left
- *                           untouched (valid when M is symmetric: the caller mirrors);
+ *                           untouched (valid when M is symmetric AND all histograms carry the same mass -- emd2 rescales
+ *                           b to the mass of a, so the value scales with sum(a): the caller mirrors);
  *       PILOT_OT_EMD_MIRROR like UPPER, then the lower triangle is filled from the upper one on the
  *                           device (requires the full square grid: rows 0..N step 1).
  * n_aug (nullable): augmenting paths used per pair (negative: iteration guard tripped, emd = NaN). */
@@ -202,7 +203,7 @@ int pilot_ot_multi_destroy(pilot_ot_multi *m);
 int pilot_ot_multi_set_inputs(pilot_ot_multi *m, const double *P, const double *M);   /* host -> every device */
 int pilot_ot_multi_sinkhorn(pilot_ot_multi *m, double reg, int num_iter_max, double stop_thr, double tau,
                             int check_period, int precision, double f32_floor_ulps, int cost_is_symmetric);
-int pilot_ot_multi_emd(pilot_ot_multi *m, int cost_is_symmetric);  /* symmetric: columns >= row solved, mirrored after the gather */
+int pilot_ot_multi_emd(pilot_ot_multi *m, int cost_is_symmetric);  /* symmetric (and equal masses, see PILOT_OT_EMD_UPPER): columns >= row solved, mirrored after the gather */
 int pilot_ot_multi_sync(pilot_ot_multi *m);
 /* emd: N x N from the device of shard 0; iters / err / flags (nullable; exact mode: iters = n_aug) are fetched shard by
  * shard and interleaved on the host */

@@ -295,13 +295,21 @@ class DevicePlan:
             pass
 
 
+def equal_masses(P, rtol=1e-12):
+    """ot.emd2 rescales b to the mass of a, so emd2(a, b) = sum(a) * W(a / sum a, b / sum b): the matrix of a symmetric cost
+    is symmetric only when every histogram carries the same mass (to rounding)."""
+    s = np.asarray(P, dtype=np.float64).sum(1)
+    return s.size == 0 or float(s.max() - s.min()) <= rtol * max(float(np.abs(s).max()), 1e-300)
+
+
 def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, mode="auto", return_info=False):
     """Exact OT cost for ordered pairs (device replacement of the ``ot.emd2`` loop,
     pilotpy/tools/Trajectory.py:507-511).
 
     mode: "all" solves every (row, column) pair; "upper" only column >= row (rest left 0);
     "mirror" = upper + device-side mirroring (full square grid only); "auto" picks "mirror"
-    when M is exactly symmetric and the full grid is requested, else "all".
+    when M is exactly symmetric, all histograms carry the same mass (see equal_masses) and the full grid is requested,
+    else "all".
     """
     P = _as_f64(P, "P")
     M = _as_f64(M, "M")
@@ -311,7 +319,7 @@ def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, mode="auto", return_in
     row_end = N if row_end is None else int(row_end)
     full = (row_begin == 0 and row_end == N and row_step == 1)
     if mode == "auto":
-        mode = "mirror" if (full and np.array_equal(M, M.T)) else "all"
+        mode = "mirror" if (full and np.array_equal(M, M.T) and equal_masses(P)) else "all"
     modes = {"all": _lib.EMD_ALL, "upper": _lib.EMD_UPPER, "mirror": _lib.EMD_MIRROR}
     if mode not in modes:
         raise ValueError("mode must be one of %s" % sorted(modes))

@@ -21,6 +21,7 @@ import time
 import numpy as np
 
 from . import _lib
+from . import engine
 from .engine import CHECK_PERIOD, NUM_ITER_MAX, STOP_THR, TAU, _as_f64
 
 
@@ -45,6 +46,7 @@ class MultiPlan:
             raise ValueError("shape mismatch: P %s, M %s" % (P.shape, M.shape))
         self.N, self.K = P.shape
         self.sym = int(np.array_equal(M, M.T))
+        self.equal_masses = engine.equal_masses(P)          # exact mode: the upper triangle may only be mirrored then
         self.max_cost = float(M.max()) if M.size else 0.0
         self.devices = _devices(devices, n_devices)
         self.G = len(self.devices)
@@ -66,7 +68,7 @@ class MultiPlan:
                                                   int(check_period), prec, float(f32_floor_ulps), self.sym))
 
     def emd(self):
-        _lib.check(self.L.pilot_ot_multi_emd(self.h, self.sym))
+        _lib.check(self.L.pilot_ot_multi_emd(self.h, int(self.sym and self.equal_masses)))
 
     def sync(self):
         _lib.check(self.L.pilot_ot_multi_sync(self.h))
@@ -138,7 +140,7 @@ def emd_grid_multi(P, M, devices=None, n_devices=None, gather="auto", return_inf
     dev = _devices(devices, n_devices)
     E = np.empty((N, N), dtype=np.float64)
     n_aug = np.zeros((N, N), dtype=np.int32)
-    _lib.check(_lib.load().pilot_ot_emd_grid_multi(_lib.dptr(P), N, K, _lib.dptr(M), int(np.array_equal(M, M.T)),
+    _lib.check(_lib.load().pilot_ot_emd_grid_multi(_lib.dptr(P), N, K, _lib.dptr(M), int(np.array_equal(M, M.T) and engine.equal_masses(P)),
                                                    _lib.iptr(dev), len(dev), _lib.GATHER[gather], _lib.dptr(E),
                                                    _lib.iptr(n_aug)))
     if (n_aug < 0).any():

@@ -86,6 +86,22 @@ def test_emd_randomized_stress(K, sparsity, nonzero_diag, seed):
     assert Eg.min() >= -1e-15 and Eg.max() <= M.max() * P.sum(1).max() + 1e-12
 
 
+def test_emd_unequal_masses_are_not_mirrored():
+    """emd2 rescales b to the mass of a: with unequal masses the matrix of a symmetric cost is NOT symmetric, and the
+    automatic mode must solve every ordered pair (found by tools/fuzz_emd.py)."""
+    from pilot_amd import multi
+    rng = np.random.default_rng(5)
+    N, K = 21, 12
+    P = rng.dirichlet(np.ones(K), size=N) * rng.uniform(0.3, 3.0, size=(N, 1))
+    M = rng.random((K, K)); M = M + M.T; np.fill_diagonal(M, 0.0)
+    Eo = O.emd_grid(P, M, n_threads=8)
+    assert np.abs(Eo - Eo.T).max() > 1e-3
+    np.testing.assert_allclose(engine.emd_grid(P, M), Eo, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(multi.emd_grid_multi(P, M, devices=[0, 0]), Eo, rtol=0, atol=1e-11)
+    Pn = P / P.sum(1, keepdims=True)                                  # equal masses: the mirrored form is used and agrees
+    np.testing.assert_allclose(engine.emd_grid(Pn, M), O.emd_grid(Pn, M, n_threads=8), rtol=0, atol=1e-12)
+
+
 def test_emd_upper_triangle_queue_over_row_subsets():
     """mode "upper" draws its pairs from a counter that enumerates only column >= row, row by row (row offsets inverted
     with a square root and fixed up): every row subset must give exactly the rows of the full matrix, nothing solved
