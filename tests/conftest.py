@@ -11,6 +11,8 @@ os.environ.setdefault("PILOT_AMD_NO_RESULTS_DIR", "1")
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = ["c1_20x10x10", "c2s_100x30x30", "ragged_categorical_12x7x5", "pathomics_15x6x8"]
+# reference-executed with NON-default options (metric, regulizer, reg are stored in the fixture)
+GOLDEN_OPTION_CASES = ["opts_euclidean_18x10x6", "opts_cityblock_14x8x4"]
 
 
 def pytest_configure(config):

@@ -90,13 +90,14 @@ def import_reference():
     return T
 
 
-def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.1, clusters_col="cell_types"):
+def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.1, clusters_col="cell_types", metric="cosine",
+             regulizer=0.2):
     obs = adata.obs
     results = {}
     for mode in ("unreg", "reg"):
         adata.uns = {}
         T.wasserstein_distance(adata, emb_matrix=emb_key, clusters_col=clusters_col, sample_col="sampleID",
-                               status="status", regularized=mode, reg=reg, data_type=data_type)
+                               status="status", regularized=mode, reg=reg, data_type=data_type, metric=metric, regulizer=regulizer)
         results[mode] = dict(adata.uns)
     u = results["unreg"]
     samples = list(u["proportions"].keys())
@@ -113,7 +114,7 @@ def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.
         emd_unreg=u["EMD"], emd_unreg_df=u["EMD_df"].to_numpy(),
         emd_reg=results["reg"]["EMD"], emd_reg_df=results["reg"]["EMD_df"].to_numpy(),
         emd_df_index_name=np.asarray(str(u["EMD_df"].index.name)),
-        reg=np.asarray(reg), data_type=np.asarray(data_type),
+        reg=np.asarray(reg), data_type=np.asarray(data_type), metric=np.asarray(metric), regulizer=np.asarray(regulizer),
         uns_keys=np.asarray(sorted(u.keys()), dtype=str),
     )
     print(name, "N=%d K=%d C=%d" % (len(samples), len(cells), len(obs)), "EMD unreg max", u["EMD"].max(),
@@ -146,6 +147,26 @@ def main():
             ad.obsm["X_pca"] = ad.X
             ad.obs = ad.obs.rename(columns={"cell_types": "Cell_type"})
             run_case(T, "pathomics_15x6x8", ad, out_dir, data_type="Pathomics", clusters_col="Cell_type")
+            # non-default options: metric, regulizer, reg; very unbalanced patients (one has a single cell), a cell type seen
+            # in one patient only, numeric-looking labels whose first-appearance order is neither numeric nor lexicographic
+            ad = make_cells(18, 9, 6, seed=21, cells_per_patient=50)
+            rng = np.random.default_rng(21)
+            keep = np.ones(len(ad.obs), dtype=bool)
+            sid = ad.obs["sampleID"].to_numpy()
+            first = np.flatnonzero(sid == sid[0])
+            keep[first[1:]] = False                                        # patient 0: one cell
+            second = np.flatnonzero(sid == np.unique(sid)[3])
+            keep[second[5:]] = False                                       # another: five cells
+            ad.obs = ad.obs[keep].reset_index(drop=True)
+            ad.obsm["X_pca"] = ad.obsm["X_pca"][keep]
+            ad.X = ad.obsm["X_pca"]
+            relabel = {c: str(v) for c, v in zip(pd.unique(ad.obs["cell_types"]), [10, 3, 7, 21, 1, 100, 12, 5, 30])}
+            ad.obs["cell_types"] = ad.obs["cell_types"].map(relabel)
+            lone = ad.obs.index[ad.obs["sampleID"] == pd.unique(ad.obs["sampleID"])[7]][:3]
+            ad.obs.loc[lone, "cell_types"] = "999"                         # a type that only one patient has
+            run_case(T, "opts_euclidean_18x10x6", ad, out_dir, metric="euclidean", regulizer=0.5, reg=0.05)
+            ad2 = make_cells(14, 8, 4, seed=22, cells_per_patient=35)
+            run_case(T, "opts_cityblock_14x8x4", ad2, out_dir, metric="cityblock", regulizer=1.0, reg=0.3)
         finally:
             os.chdir(cwd)
 

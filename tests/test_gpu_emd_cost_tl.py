@@ -4,7 +4,7 @@ import pandas as pd
 import pytest
 import scipy.spatial.distance as ssd
 
-from conftest import GOLDEN_CASES, golden_adata, load_golden
+from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden
 from oracle import oracle as O
 from pilot_amd import _lib, engine, tl
 from pilot_amd.synthetic import CONFIGS, make_cells, make_problem
@@ -277,6 +277,32 @@ def test_wasserstein_distance_end_to_end_vs_reference_fixture(name, mode, tmp_pa
     assert [str(x) for x in u["real_labels"]] == list(g["real_labels"])
     assert isinstance(u["annot"], pd.DataFrame) and isinstance(u["data"], pd.DataFrame)
     assert (E + E).shape == E.shape and (E / E.max()).max() == 1.0                        # test_pilot.py:30, ploting.py:95
+
+
+@pytest.mark.parametrize("name", GOLDEN_OPTION_CASES)
+@pytest.mark.parametrize("mode", ["unreg", "reg"])
+def test_wasserstein_distance_with_other_options_vs_reference_fixture(name, mode, tmp_path, monkeypatch):
+    """The same call as the reference was run with (metric, regulizer, reg from the fixture): every output it left."""
+    monkeypatch.chdir(tmp_path)
+    g = load_golden(name)
+    ad, cell_col = golden_adata(g)
+    tl.wasserstein_distance(ad, emb_matrix="X_pca", clusters_col=cell_col, sample_col="sampleID", status="status",
+                            metric=str(g["metric"]), regulizer=float(g["regulizer"]), regularized=mode, reg=float(g["reg"]),
+                            engine_options={"precision": "fp64"})
+    u = ad.uns
+    assert sorted(u.keys()) == list(g["uns_keys"])
+    assert [str(k) for k in u["proportions"]] == list(g["samples"])
+    np.testing.assert_array_equal(np.stack(list(u["proportions"].values())), g["proportions"])
+    assert [str(c) for c in u["cost"].columns] == list(g["cells"]) == [str(c) for c in u["cost"].index]
+    np.testing.assert_allclose(u["cost"].to_numpy(), g["cost"], rtol=0, atol=1e-13 * max(1.0, g["cost"].max()))
+    want = g["emd_unreg"] if mode == "unreg" else g["emd_reg"]
+    assert np.abs(u["EMD"] - want).max() <= 1e-12
+    np.testing.assert_array_equal(u["EMD_df"].to_numpy(), u["EMD"].T)
+    assert [str(x) for x in u["real_labels"]] == list(g["real_labels"])
+    if mode == "reg":                                              # and the default (f32-valued) precision
+        tl.wasserstein_distance(ad, emb_matrix="X_pca", clusters_col=cell_col, sample_col="sampleID", status="status",
+                                metric=str(g["metric"]), regulizer=float(g["regulizer"]), regularized=mode, reg=float(g["reg"]))
+        assert np.abs(ad.uns["EMD"] - want).max() <= 1e-5
 
 
 def test_wasserstein_distance_default_precision_c2_shape(tmp_path, monkeypatch):

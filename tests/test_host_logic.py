@@ -4,7 +4,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import GOLDEN_CASES, golden_adata, load_golden
+from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden
 from oracle import oracle as O
 from pilot_amd import tl
 
@@ -100,3 +100,19 @@ def test_unequal_masses_stop_the_exact_mode_like_pot():
     cost = 1.0 - np.eye(3)
     with pytest.raises(AssertionError, match="same sum"):
         tl.wasserstein_d(reps, cost, regularized="unreg")
+
+
+@pytest.mark.parametrize("name", GOLDEN_OPTION_CASES)
+def test_oracle_restatements_match_the_reference_with_other_options(name):
+    """Fixtures produced by the reference's own code with a non-default metric / regulizer, a patient of ONE cell, a cell
+    type that a single patient has, and numeric-looking labels: first-appearance order, the C - 1 prior and the medians of
+    one- and two-cell groups."""
+    g = load_golden(name)
+    data, annot = _annot(g)
+    assert [str(c) for c in annot["cell_type"].unique()] == list(g["cells"])
+    ora, cells = O.cluster_representations(annot["cell_type"], annot["sampleID"], regulizer=float(g["regulizer"]))
+    assert [str(k) for k in ora.keys()] == list(g["samples"])
+    np.testing.assert_array_equal(np.stack(list(ora.values())), g["proportions"])
+    ora_dis, _, _ = O.cost_matrix(data, annot["cell_type"], metric=str(g["metric"]))
+    np.testing.assert_array_equal(ora_dis, g["cost"])
+    assert [str(x) for x in tl.return_real_labels(annot)] == list(g["real_labels"])
