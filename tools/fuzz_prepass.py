@@ -1,0 +1,58 @@
+"""Random inputs for the host pre-pass kernels (proportions, per-type medians, pdist) against pandas / scipy / the oracle.
+Usage: python tools/fuzz_prepass.py [n_cases] [seed]"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import pandas as pd
+from scipy.spatial.distance import pdist, squareform
+from oracle import oracle as O
+from pilot_amd import engine, _lib
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+METRICS = list(_lib.METRICS)
+for case in range(n_cases):
+    C = int(rng.choice([2, 3, 5, 63, 64, 65, 1000, 4096, 4097, 30000])); D = int(rng.choice([1, 2, 3, 30, 64, 65, 80, 150, 400])); K = int(rng.choice([1, 2, 3, 7, 50, 130]))
+    N = int(rng.integers(1, 40))
+    dtype = rng.choice([np.float32, np.float64])
+    X = (rng.standard_normal((C, D)) * rng.choice([1e-3, 1.0, 1e4])).astype(dtype)
+    if rng.random() < 0.3: X = np.round(X, 1)                      # many ties
+    if rng.random() < 0.2: X[rng.integers(0, C, max(1, C // 50)), rng.integers(0, D)] = -0.0
+    cc = rng.integers(0, K, C).astype(np.int32)
+    if rng.random() < 0.3 and K > 1: cc[cc == K - 1] = 0              # an empty type
+    sc = rng.integers(0, N, C).astype(np.int32)
+    msgs = []
+    # medians vs pandas (in the data's dtype, like the reference)
+    got = engine.centroid_medians(X, cc, K)
+    df = pd.DataFrame(X)
+    want = np.stack([df[cc == k].median(axis=0).to_numpy(dtype=np.float64) if (cc == k).any() else np.full(D, np.nan) for k in range(K)])
+    if not np.array_equal(got, want, equal_nan=True): msgs.append("medians differ: max|d| %.3e" % np.nanmax(np.abs(got - want)))
+    # proportions vs the formula of Trajectory.py:405-430
+    reg = float(rng.choice([0.0, 0.2, 1.0]))
+    for norm in (True, False):
+        P = engine.proportions(cc, sc, N, K, regulizer=reg, normalization=norm, n_total=C)
+        cnt = np.zeros((N, K)); np.add.at(cnt, (sc, cc), 1.0)
+        if norm:
+            if C > 1:
+                prior = np.array([reg * float((cc == k).sum()) / (C - 1) for k in range(K)])
+                ref = np.stack([np.array([(cnt[s, k] + prior[k]) for k in range(K)]) / (sum(cnt[s].tolist()) + sum(prior.tolist())) for s in range(N)]) if True else None
+                ok = np.allclose(P, ref, rtol=1e-15, atol=0) if np.isfinite(ref).all() else True
+                if not ok: msgs.append("proportions(norm) differ: %.3e" % np.abs(P - ref).max())
+        else:
+            if not np.array_equal(P, cnt): msgs.append("raw counts differ")
+    # pdist
+    cent = got[~np.isnan(got).any(1)]
+    if len(cent) >= 2:
+        metric = str(rng.choice(METRICS))
+        try:
+            want = squareform(pdist(cent, metric))
+            g = engine.pdist_square(cent, metric)
+            fin = np.isfinite(want)
+            if not (np.isfinite(g) == fin).all() or np.abs(g - want)[fin].max(initial=0) > 1e-11 * max(1.0, np.abs(want[fin]).max(initial=0)):
+                msgs.append("pdist %s differs: %.3e" % (metric, np.abs(g - want)[fin].max(initial=0)))
+        except Exception as e:
+            msgs.append("pdist %s: %s" % (metric, e))
+    tag = "C=%d D=%d K=%d N=%d %s reg=%g" % (C, D, K, N, np.dtype(dtype).name, reg)
+    if msgs: bad += 1; print("FAIL", tag, "|", "; ".join(msgs), flush=True)
+    else: print("ok  ", tag, flush=True)
+print("%d of %d cases failed" % (bad, n_cases))
