@@ -1142,7 +1142,18 @@ PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offse
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMemcpy(c->dX, X, sizeof(float) * (size_t)c->C * D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        // |x - y|^2 does not change when every cell is shifted by the same vector, but the f32 cancellation in
+        // |x|^2 + |y|^2 - 2 <x, y> does: the cohort is stored centred on its mean (computed in fp64)
+        std::vector<double> mean((size_t)D, 0.0);
+        for (long long i = 0; i < c->C; ++i)
+            for (int d = 0; d < D; ++d) mean[(size_t)d] += (double)X[(size_t)i * D + d];
+        for (int d = 0; d < D; ++d) mean[(size_t)d] /= (double)c->C;
+        std::vector<float> Xc((size_t)c->C * D);
+        for (long long i = 0; i < c->C; ++i)
+            for (int d = 0; d < D; ++d) Xc[(size_t)i * D + d] = (float)((double)X[(size_t)i * D + d] - mean[(size_t)d]);
+        e = hipMemcpy(c->dX, Xc.data(), sizeof(float) * (size_t)c->C * D, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(c->doffs, offsets, sizeof(long long) * (size_t)(N + 1), hipMemcpyHostToDevice);
     if (e != hipSuccess) { pilot_ot_cell_cohort_destroy(c); return fail(PILOT_OT_EHIP, "cell cohort setup failed: %s", hipGetErrorString(e)); }
     *cohort = c;
