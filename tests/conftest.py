@@ -44,3 +44,10 @@ def golden_adata(g, categorical=False):
             obs[c] = obs[c].astype("category")
     ad = Cohort(g["emb"], obs, emb_key="X_pca")
     return ad, cell_col
+
+
+def load_golden_pack(name="random_pack"):
+    """Fixtures packed into one file (tests/golden/gen_golden.py): a list of per-case dicts like load_golden's."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    n = int(z["n_cases"])
+    return [{k[len("c%d_" % i):]: z[k] for k in z.files if k.startswith("c%d_" % i)} for i in range(n)]

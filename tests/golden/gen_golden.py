@@ -167,6 +167,32 @@ def main():
             run_case(T, "opts_euclidean_18x10x6", ad, out_dir, metric="euclidean", regulizer=0.5, reg=0.05)
             ad2 = make_cells(14, 8, 4, seed=22, cells_per_patient=35)
             run_case(T, "opts_cityblock_14x8x4", ad2, out_dir, metric="cityblock", regulizer=1.0, reg=0.3)
+            # a pack of small random cohorts with random options (one file: tests/golden/random_pack.npz)
+            rng = np.random.default_rng(2026)
+            pack = {}
+            metrics = ["cosine", "euclidean", "sqeuclidean", "cityblock", "chebyshev", "correlation", "braycurtis", "canberra"]
+            n_pack = 12
+            for i in range(n_pack):
+                Np, K, D = int(rng.integers(3, 13)), int(rng.integers(2, 9)), int(rng.integers(2, 9))
+                ad = make_cells(Np, K, D, seed=100 + i, cells_per_patient=int(rng.integers(8, 40)))
+                if rng.random() < 0.5:                                     # shuffled cell order
+                    perm = rng.permutation(len(ad.obs))
+                    ad.obs = ad.obs.iloc[perm].reset_index(drop=True)
+                    ad.obsm["X_pca"] = ad.obsm["X_pca"][perm]
+                if rng.random() < 0.5:
+                    ad.obsm["X_pca"] = ad.obsm["X_pca"].astype(np.float64) * float(rng.choice([1.0, 7.5])) + float(rng.choice([0.0, 2.0]))
+                ad.X = ad.obsm["X_pca"]
+                if rng.random() < 0.4:
+                    for c in ("cell_types", "sampleID", "status"):
+                        ad.obs[c] = ad.obs[c].astype("category")
+                opts = dict(metric=str(rng.choice(metrics)), regulizer=float(rng.choice([0.05, 0.2, 1.0, 3.0])), reg=float(rng.choice([0.05, 0.1, 0.5, 1.0])))
+                with tempfile.TemporaryDirectory() as one:
+                    run_case(T, "case", ad, one, **opts)
+                    z = np.load(os.path.join(one, "case.npz"))
+                    for k in z.files:
+                        pack["c%d_%s" % (i, k)] = z[k]
+            pack["n_cases"] = np.asarray(n_pack)
+            np.savez_compressed(os.path.join(out_dir, "random_pack.npz"), **pack)
         finally:
             os.chdir(cwd)
 

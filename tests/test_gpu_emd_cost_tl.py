@@ -4,7 +4,7 @@ import pandas as pd
 import pytest
 import scipy.spatial.distance as ssd
 
-from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden
+from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden, load_golden_pack
 from oracle import oracle as O
 from pilot_amd import _lib, engine, tl
 from pilot_amd.synthetic import CONFIGS, make_cells, make_problem
@@ -303,6 +303,27 @@ def test_wasserstein_distance_with_other_options_vs_reference_fixture(name, mode
         tl.wasserstein_distance(ad, emb_matrix="X_pca", clusters_col=cell_col, sample_col="sampleID", status="status",
                                 metric=str(g["metric"]), regulizer=float(g["regulizer"]), regularized=mode, reg=float(g["reg"]))
         assert np.abs(ad.uns["EMD"] - want).max() <= 1e-5
+
+
+def test_wasserstein_distance_over_the_random_reference_pack(tmp_path, monkeypatch):
+    """Twelve random cohorts x random options, each produced by the reference's own code: the same call must leave the
+    same proportions (bit for bit), cost, matrices and labels, in both modes."""
+    monkeypatch.chdir(tmp_path)
+    for g in load_golden_pack():
+        for mode in ("unreg", "reg"):
+            ad, cell_col = golden_adata(g)
+            tl.wasserstein_distance(ad, emb_matrix="X_pca", clusters_col=cell_col, sample_col="sampleID", status="status",
+                                    metric=str(g["metric"]), regulizer=float(g["regulizer"]), regularized=mode, reg=float(g["reg"]),
+                                    engine_options={"precision": "fp64"})
+            u = ad.uns
+            tag = "%s %s reg=%g regulizer=%g" % (mode, g["metric"], float(g["reg"]), float(g["regulizer"]))
+            assert [str(k) for k in u["proportions"]] == list(g["samples"]), tag
+            np.testing.assert_array_equal(np.stack(list(u["proportions"].values())), g["proportions"], err_msg=tag)
+            assert [str(c) for c in u["cost"].columns] == list(g["cells"]), tag
+            np.testing.assert_allclose(u["cost"].to_numpy(), g["cost"], rtol=0, atol=1e-13 * max(1.0, g["cost"].max()), err_msg=tag)
+            want = g["emd_unreg"] if mode == "unreg" else g["emd_reg"]
+            assert np.abs(u["EMD"] - want).max() <= 1e-11, tag
+            assert [str(x) for x in u["real_labels"]] == list(g["real_labels"]), tag
 
 
 def test_wasserstein_distance_default_precision_c2_shape(tmp_path, monkeypatch):

@@ -4,7 +4,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden
+from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden, load_golden_pack
 from oracle import oracle as O
 from pilot_amd import tl
 
@@ -116,3 +116,18 @@ def test_oracle_restatements_match_the_reference_with_other_options(name):
     ora_dis, _, _ = O.cost_matrix(data, annot["cell_type"], metric=str(g["metric"]))
     np.testing.assert_array_equal(ora_dis, g["cost"])
     assert [str(x) for x in tl.return_real_labels(annot)] == list(g["real_labels"])
+
+
+def test_oracle_restatements_match_the_random_reference_pack():
+    """Twelve small random cohorts with random options (metric, regulizer, dtype, shuffling, categorical columns), each run
+    through the reference's own code: the oracle's host steps must reproduce every one of them bit for bit."""
+    for g in load_golden_pack():
+        data, annot = _annot(g)
+        ora, cells = O.cluster_representations(annot["cell_type"], annot["sampleID"], regulizer=float(g["regulizer"]))
+        assert [str(k) for k in ora.keys()] == list(g["samples"]) and [str(c) for c in cells] == list(g["cells"])
+        np.testing.assert_array_equal(np.stack(list(ora.values())), g["proportions"])
+        ora_dis, _, _ = O.cost_matrix(data, annot["cell_type"], metric=str(g["metric"]))
+        np.testing.assert_array_equal(ora_dis, g["cost"])
+        P, M = g["proportions"], g["cost"] / g["cost"].max()
+        assert np.abs(O.emd_grid(P, M) - g["emd_unreg"]).max() <= 1e-13
+        assert np.abs(O.sinkhorn_grid(P, M, float(g["reg"])) - g["emd_reg"]).max() <= 1e-13
