@@ -1282,7 +1282,7 @@ PILOT_API int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offse
     }
     for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
         (void)hipSetDevice(devices[s]);
-        rc = cell_w2_enqueue(co[s], scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, s, N, n_devices, &n_out[s]);
+        rc = cell_w2_enqueue(co[s], scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, s < N ? s : N, N, n_devices, &n_out[s]);
     }
     std::vector<double> tw, te;
     std::vector<int> ti;

@@ -360,7 +360,7 @@ PILOT_API int pilot_ot_multi_sinkhorn(pilot_ot_multi *m, double reg, int num_ite
         HIP_TRY(hipSetDevice(h.device));
         HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
         int rc = pilot_ot_sinkhorn_grid_dev(h.plan, h.dP, h.dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
-                                            f32_floor_ulps, cost_is_symmetric, s, m->N, m->G, h.dLocal, h.dIt, h.dErr,
+                                            f32_floor_ulps, cost_is_symmetric, s < m->N ? s : m->N /* more shards than rows: empty */, m->N, m->G, h.dLocal, h.dIt, h.dErr,
                                             h.dFl, h.stream);
         if (rc != PILOT_OT_OK) return rc;
         HIP_TRY(hipEventRecord(h.ev_grid, h.stream));
@@ -379,7 +379,7 @@ PILOT_API int pilot_ot_multi_emd(pilot_ot_multi *m, int cost_is_symmetric) {
         HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
         HIP_TRY(hipMemsetAsync(h.dLocal, 0, sizeof(double) * n_loc, h.stream));
         HIP_TRY(hipMemsetAsync(h.dIt, 0, sizeof(int) * n_loc, h.stream));
-        int rc = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, cost_is_symmetric ? PILOT_OT_EMD_UPPER : PILOT_OT_EMD_ALL, s, m->N,
+        int rc = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, cost_is_symmetric ? PILOT_OT_EMD_UPPER : PILOT_OT_EMD_ALL, s < m->N ? s : m->N, m->N,
                                        m->G, h.dLocal, h.dIt, h.stream);
         if (rc != PILOT_OT_OK) return rc;
         HIP_TRY(hipEventRecord(h.ev_grid, h.stream));

@@ -18,7 +18,7 @@ def shard_rows(N: int, rank: int, world: int):
     """(row_begin, row_end, row_step) of the rows owned by ``rank``: rank, rank+world, ... < N."""
     if not (0 <= rank < world):
         raise ValueError("rank %d outside world %d" % (rank, world))
-    return rank, N, world
+    return min(rank, N), N, world          # (more ranks than rows: the surplus ranks own the empty range [N, N))
 
 
 def n_local_rows(N: int, rank: int, world: int) -> int:

@@ -123,3 +123,13 @@ def test_bench_multi_paths_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e7 and "rank0_kernel_ms" in line["multi_gpu"]
+
+
+def test_more_shards_than_patients():
+    """An 8-GPU node and a cohort of 3 patients: the surplus shards own empty row ranges (found by tools/fuzz_multi.py)."""
+    from pilot_amd.synthetic import make_problem
+    P, M = make_problem(3, 6, 4, seed=9, cells_per_patient=50)
+    ref = engine.sinkhorn_grid(P, M, 0.1)
+    for G in (4, 8):
+        np.testing.assert_array_equal(multi.sinkhorn_grid_multi(P, M, 0.1, devices=[0] * G), ref)
+        np.testing.assert_array_equal(multi.emd_grid_multi(P, M, devices=[0] * G), engine.emd_grid(P, M))
