@@ -318,7 +318,7 @@ def test_randomized_shapes_and_options_against_the_oracle(seed):
             if rng.random() < 0.15:
                 M = M * rng.uniform(0.7, 1.0, size=M.shape); M /= M.max()
         kw_o, kw_g = {}, {}
-        if rng.random() < 0.2: kw_o["tau"] = kw_g["tau"] = float(rng.choice([6.5, 50.0]))
+        if rng.random() < 0.2: kw_o["tau"] = kw_g["tau"] = float(rng.choice([6.5, 47.3]))
         if rng.random() < 0.2: kw_o["numItermax"] = kw_g["num_iter_max"] = int(rng.choice([1, 7, 40, 200]))
         Eo, io = O.sinkhorn_grid(P, M, reg, return_info=True, n_threads=8, **kw_o)
         assert np.isfinite(Eo).all()

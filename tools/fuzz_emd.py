@@ -1,6 +1,7 @@
 """Random exact-OT grids against the oracle (and LP bounds): usage python tools/fuzz_emd.py [n_cases] [seed]"""
 import sys
 sys.path.insert(0, ".")
+import os
 import numpy as np
 from scipy.spatial.distance import pdist, squareform
 from oracle import oracle as O
@@ -9,7 +10,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
-    N = int(rng.integers(1, 60)); K = int(rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 50, 63, 64, 65, 90, 100, 128, 129, 160, 192, 193, 256]))
+    N = int(rng.integers(1, 300 if os.environ.get("FUZZ_BIG") else 60)); K = int(rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 50, 63, 64, 65, 90, 100, 128, 129, 160, 192, 193, 256]))
     if K > 128: N = min(N, 24)
     kind = rng.choice(["dirichlet", "lattice", "sparse"])
     if kind == "dirichlet": P = rng.dirichlet(float(rng.choice([0.1, 1.0, 10.0])) * np.ones(K), size=N)

@@ -2,6 +2,7 @@
 the ABSORB_LAST knife edge differs.  Usage: python tools/fuzz_sinkhorn.py [n_cases] [seed]"""
 import sys
 sys.path.insert(0, ".")
+import os
 import numpy as np
 from scipy.spatial.distance import pdist, squareform
 from oracle import oracle as O
@@ -10,7 +11,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
-    N = int(rng.integers(1, 70)); K = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 20, 31, 32, 33, 48, 50, 64, 65, 80, 100, 128]))
+    N = int(rng.integers(1, 400 if os.environ.get("FUZZ_BIG") else 70)); K = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 20, 31, 32, 33, 48, 50, 64, 65, 80, 100, 128]))
     reg = float(rng.choice([1.0, 0.3, 0.1, 0.05, 0.02, 0.01]))
     alpha = float(rng.choice([0.2, 1.0, 5.0]))
     P = rng.dirichlet(alpha * np.ones(K), size=N)
@@ -23,7 +24,7 @@ for case in range(n_cases):
     sym = rng.random() < 0.85
     if not sym and K > 1: M = M * rng.uniform(0.7, 1.0, size=M.shape); M /= M.max()
     kw_o, kw_g = {}, {}
-    if rng.random() < 0.2: kw_o["tau"] = kw_g["tau"] = float(rng.choice([6.5, 50.0]))     # (tau == K is a knife edge: the residual after a reset is K)
+    if rng.random() < 0.2: kw_o["tau"] = kw_g["tau"] = float(rng.choice([6.5, 47.3]))     # (tau == K is a knife edge: the residual after a reset is K)
     if rng.random() < 0.2: kw_o["numItermax"] = kw_g["num_iter_max"] = int(rng.choice([1, 7, 40, 200]))
     Eo, io = O.sinkhorn_grid(P, M, reg, return_info=True, n_threads=8, **kw_o)
     msgs = []
