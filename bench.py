@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", help="synthetic config (c2 | c3 | c4)")
     ap.add_argument("--reg", type=float, default=0.1)
-    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64", "bf16x3"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp64", "bf16x3", "f16x2"])
     ap.add_argument("--mode", default="sinkhorn", choices=["sinkhorn", "emd", "cellw2"],
                     help="emd: time the exact-OT pair grid (the reference's default mode) instead; cellw2: the cell-level W2 "
                          "extension at BASELINE config 5 (200 patients x 5000 cells x 30 dims; takes about two minutes)")
@@ -109,7 +109,7 @@ def main():
     N, K = P.shape
     prec = args.precision
     if prec == "auto":
-        prec = {1: "fp32", 2: "fp64", 3: "bf16x3"}[L.pilot_ot_auto_precision_for(float(M.max()) / args.reg, K, int(np.array_equal(M, M.T)))]
+        prec = {1: "fp32", 2: "fp64", 3: "bf16x3", 6: "f16x2"}[L.pilot_ot_auto_precision_for(float(M.max()) / args.reg, K, int(np.array_equal(M, M.T)))]
 
     if args.mode == "emd":
         out = bench_emd(args, L, P, M, cfg)

@@ -43,7 +43,8 @@ extern "C" {
 #define PILOT_OT_ERCCL (-4)   /* RCCL error / librccl missing (multi-GPU entry points only) */
 
 /* precision of the Sinkhorn pair-grid kernel */
-#define PILOT_OT_PREC_AUTO 0 /* BF16X3 (f32 values) when exp(-max(M)/reg) stays a normal f32 far from underflow, else f64 */
+#define PILOT_OT_PREC_AUTO 0 /* F16X2 while max(M)/reg <= 11.5, BF16X3 (both f32 values) while exp(-max(M)/reg) stays a normal f32
+                              * far from underflow (<= 60), else AUTO_MIXED / f64 */
 #define PILOT_OT_PREC_F32 1    /* f32 values, products on the f32-input MFMA (v_mfma_f32_16x16x4_f32): IEEE f32 FMA chains */
 #define PILOT_OT_PREC_F64 2
 #define PILOT_OT_PREC_AUTO_MIXED 4 /* what AUTO resolves to beyond the f32 range (60 < max(M)/reg <= 140): every pair is iterated in
@@ -58,6 +59,11 @@ extern "C" {
 #define PILOT_OT_PREC_BF16X3 3 /* f32 values, products on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits
                                 * (six piece products per term, f32 accumulation): f32-level rounding, not bit-identical
                                 * to PREC_F32, ~2x its speed */
+#define PILOT_OT_PREC_F16X2 6  /* f32 values, products on v_mfma_f32_16x16x32_f16 through 2-way fp16 operand splits (11 + 11
+                                * significant bits, three piece products per term) in a fixed scaled domain (2^15 G, 32 u, 32 v):
+                                * valid while max(M)/reg <= 11.5 and tau <= 2000 (PILOT's defaults: reg 0.1 on cost/max, tau 1e3);
+                                * outside that range the call runs BF16X3.  Pairs in which POT would tau-absorb are redone by
+                                * the BF16X3 tracking kernel.  Same stopping checks as BF16X3 on 99.9 % of the pairs. */
 
 /* per-pair flag bits (flags output) */
 #define PILOT_OT_FLAG_CONVERGED 1      /* stopped on err <= stop_thr                              */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpilot_ot.so")
 
 OK, EINVAL, EHIP, ENOTSUP, ERCCL = 0, -1, -2, -3, -4
-PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2, "bf16x3": 3, "generic": 5}
+PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2, "bf16x3": 3, "generic": 5, "f16x2": 6}
 METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5,
            "minkowski": 6, "seuclidean": 7, "braycurtis": 8, "canberra": 9, "hamming": 10}
 

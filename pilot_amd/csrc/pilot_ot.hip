@@ -293,13 +293,17 @@ PILOT_API int pilot_ot_auto_precision(double max_cost_over_reg) {
     // far-transport entries lose bits, so AUTO switches to the f64 kernel.
     // Inside that range the f32 values are iterated with bf16-split products (PILOT_OT_PREC_BF16X3: f32-level rounding on
     // the bf16 matrix pipe, measured 1.3x the f32-input MFMA path).
+    // While max(M)/reg <= 11.5 (PILOT's default reg = 0.1 on the max-normalised cost gives 10) every entry of 2^15 exp(-M/reg)
+    // is a well-scaled fp16 pair and the products run on 2-way fp16 splits (PILOT_OT_PREC_F16X2: half the MFMAs, a third of
+    // the split instructions of BF16X3; same stopping checks, same 1e-7 class distance to the fp64 oracle).
+    if (max_cost_over_reg <= pilot::H_MAX_COST_OVER_REG) return PILOT_OT_PREC_F16X2;
     return max_cost_over_reg <= 60.0 ? PILOT_OT_PREC_BF16X3 : PILOT_OT_PREC_F64;
 }
 
 namespace { bool split_fits_lds(int K, bool sym, int bands); }
 PILOT_API int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int cost_is_symmetric) {
     int prec = pilot_ot_auto_precision(max_cost_over_reg);
-    if (prec == PILOT_OT_PREC_BF16X3 && !split_fits_lds(K, cost_is_symmetric != 0, 1)) prec = PILOT_OT_PREC_F32;
+    if ((prec == PILOT_OT_PREC_BF16X3 || prec == PILOT_OT_PREC_F16X2) && !split_fits_lds(K, cost_is_symmetric != 0, 1)) prec = PILOT_OT_PREC_F32;
     return prec;
 }
 
@@ -329,8 +333,10 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
         const int rt = (K + 15) / 16;
         size_t img_bytes = pilot::img_elems(pilot::CFG_F64, rt) * sizeof(double);
         const size_t b32 = pilot::img_elems(pilot::CFG_F32, rt) * sizeof(float), bs = pilot::img_elems(pilot::CFG_S32, rt) * sizeof(float);
+        const size_t bh = pilot::img_elems(pilot::CFG_H32, rt) * sizeof(float);
         if (b32 > img_bytes) img_bytes = b32;
         if (bs > img_bytes) img_bytes = bs;
+        if (bh > img_bytes) img_bytes = bh;
         if (e == hipSuccess) e = hipMalloc(&pl->img, img_bytes);
     }
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * ((size_t)N * kp + N));   // + one stop threshold per patient
@@ -380,7 +386,7 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
     if (check_period < 1) return fail(PILOT_OT_EINVAL, "check_period=%d must be >= 1", check_period);
     if (!(stop_thr >= 0.0) || !(stop_thr < 1.0)) return fail(PILOT_OT_EINVAL, "stop_thr=%g must be in [0, 1)", stop_thr);
     if (!(tau > 1.0)) return fail(PILOT_OT_EINVAL, "tau=%g must be > 1", tau);
-    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_GENERIC)
+    if (precision < PILOT_OT_PREC_AUTO || precision > PILOT_OT_PREC_F16X2)
         return fail(PILOT_OT_EINVAL, "unknown precision id %d", precision);
     if (row_step < 1 || row_begin < 0 || row_end > N || row_begin > row_end)
         return fail(PILOT_OT_EINVAL, "bad row range [%d, %d) step %d for N=%d", row_begin, row_end, row_step, N);
@@ -470,13 +476,15 @@ StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want) {
 }
 
 // does the bf16-split configuration fit LDS at this K (operand image(s) + table + a minimal ring)?
+// (the fp16-split configuration needs less for its fast pass and the same for its tracking pass)
 bool split_fits_lds(int K, bool sym, int bands = 1) {
     const int RT = (K + 15) / 16, KP = RT * 16;
     const size_t fixed = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * 4 * bands + (size_t)KP * 4;
     return fixed + (size_t)4 * pilot::WAVES_PER_WG * (2 * KP + 4) * 4 <= LDS_BYTES;
 }
 
-// cfg: pilot::CFG_F32 / CFG_F64 / CFG_S32 (all 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
+// cfg: pilot::CFG_F32 / CFG_F64 / CFG_S32 / CFG_H32 (all 16-pair tiles: TILE = 16, 4 accumulator registers, 4 lane groups)
+// CFG_H32 (fp16-split): the fast pass only; its tracking pass is the bf16-split kernel on the second operand block.
 // mixed (cfg == CFG_S32 only): small reg under PILOT_OT_PREC_AUTO -- every pair is first iterated in f32 (bf16-split
 // products, tau-tracking kernel); pairs whose plan may touch Gibbs entries outside the f32-safe range, or that went NaN, are
 // collected (ring_flush) and solved again by the f64 tracking kernel.
@@ -484,7 +492,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
              double stop_thr, double tau, int check_period, double floor_ulps, bool sym, int row_begin,
              int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err, int *d_flags, hipStream_t s,
              bool mixed = false) {
-    const bool f64 = cfg == pilot::CFG_F64, split = cfg == pilot::CFG_S32;
+    const bool f64 = cfg == pilot::CFG_F64, half = cfg == pilot::CFG_H32, split = cfg == pilot::CFG_S32 || half;
     const size_t ts = f64 ? sizeof(double) : sizeof(float);
     const int w = (int)(ts / 4);
     constexpr int TILE = 16;
@@ -573,6 +581,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     auto launch = [&](int tvv, bool track, int wgs, const StreamLds &L) -> hipError_t {
         p.ring = L.ring;
         if (tvv) return pilot::launch_stream_tv(cfg, tvv, RT, sym, track, dim3(wgs), L.bytes, s, p);
+        if (half && !track) return pilot::launch_stream_h32(RT, sym, live1, dim3(wgs), L.bytes, s, p);
         if (split) return pilot::launch_stream_s32(RT, sym, track, live1, dim3(wgs), L.bytes, s, p);
         return f64 ? pilot::launch_stream_f64(RT, sym, track, dim3(wgs), L.bytes, s, p)
                    : pilot::launch_stream_f32(RT, sym, track, dim3(wgs), L.bytes, s, p);
@@ -593,6 +602,10 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
     p.solo_blocks = 0;
     size_t fixed_t = fixed;
+    if (half) {     // tracking pass of the fp16-split configuration: the bf16-split kernel on its own operand block
+        p.img = static_cast<float *>(img) + pilot::track_img_elems(cfg, RT);
+        fixed_t = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * ts + (size_t)KP * ts;
+    }
     if (mixed) {
         // small reg: EVERY pair goes through the tracking kernel (longest first), with the Gibbs kernel in two exponent
         // bands; pairs that still leave the f32 range are collected in track_list for the f64 pass
@@ -675,11 +688,16 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     }
     // beyond the f32 range AUTO still tries f32 first, pair by pair, where the split images fit and POT's defaults hold
     mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && 1.0 / reg <= 140.0 && !getenv("PILOT_OT_NO_MIXED");
+    // the fp16-split kernel works in a fixed scaled domain: outside it (cost range, hand-over threshold, LDS) the bf16 split takes over
+    if (precision == PILOT_OT_PREC_F16X2 &&
+        (1.0 / reg > pilot::H_MAX_COST_OVER_REG || tau > pilot::H_MAX_TAU || !split_fits_lds(pl->K, cost_is_symmetric != 0, 1)))
+        precision = PILOT_OT_PREC_BF16X3;
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int cfg = mixed ? pilot::CFG_S32
-                          : (precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32 : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : pilot::CFG_F64));
+                          : (precision == PILOT_OT_PREC_F32 ? pilot::CFG_F32
+                             : (precision == PILOT_OT_PREC_BF16X3 ? pilot::CFG_S32 : (precision == PILOT_OT_PREC_F16X2 ? pilot::CFG_H32 : pilot::CFG_F64)));
     auto run = [&](hipStream_t on) {
         int r = run_grid(cfg, pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, cost_is_symmetric != 0,
                          row_begin, n_rows, row_step, d_emd, d_iters, d_err, d_flags, on, mixed);

@@ -44,7 +44,8 @@ constexpr int FLAG_CONVERGED = 1, FLAG_NAN = 2, FLAG_ABSORB_LAST = 4, FLAG_ABSOR
 
 struct CfgF32x32 {   // v_mfma_f32_32x32x2_f32: hardware row of register r in group g = (r&3) + 8*(r>>2) + 4*g
     using T = float;
-    static constexpr bool SPLIT = false;
+    static constexpr bool SPLIT = false, HALF = false;
+    static constexpr int NP = 0;
     static constexpr int TILE = 32, NREG = 16, NGRP = 2, VEC = 4;
     using acc_t = float __attribute__((ext_vector_type(16)));
     using vec4_t = float __attribute__((ext_vector_type(4)));
@@ -61,7 +62,8 @@ struct CfgF32x32 {   // v_mfma_f32_32x32x2_f32: hardware row of register r in gr
 
 struct CfgF32x16 {   // v_mfma_f32_16x16x4_f32: hardware row of register r in group g = 4*g + r
     using T = float;
-    static constexpr bool SPLIT = false;
+    static constexpr bool SPLIT = false, HALF = false;
+    static constexpr int NP = 0;
     static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 4;
     using acc_t = float __attribute__((ext_vector_type(4)));
     using vec4_t = float __attribute__((ext_vector_type(4)));
@@ -78,7 +80,8 @@ struct CfgF32x16 {   // v_mfma_f32_16x16x4_f32: hardware row of register r in gr
 // panel_product_split): same accumulator layout and slot dealing as CfgF32x16, so all element-wise code is shared.
 struct CfgS32x16 {
     using T = float;
-    static constexpr bool SPLIT = true;
+    static constexpr bool SPLIT = true, HALF = false;
+    static constexpr int NP = 3;        // operand pieces
     static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 4;
     using acc_t = float __attribute__((ext_vector_type(4)));
     using vec4_t = float __attribute__((ext_vector_type(4)));
@@ -91,9 +94,35 @@ struct CfgS32x16 {
     __device__ static inline float eps() { return 1.1920929e-07f; }
 };
 
+// f32 values with every product on v_mfma_f32_16x16x32_f16 through 2-way fp16 operand splits (11 + 11 significant bits,
+// 3 piece products instead of 6, 2 instead of 5.5 vector instructions per panel element): the fast path while
+// max(M)/reg <= H_MAX_COST_OVER_REG.  fp16 has 5 exponent bits, so the kernel works in a SCALED domain chosen once: the
+// Gibbs images hold 2^15 G (entries in [2^-2, 2^15]: both pieces normal), the panels hold 32 u and 32 v (the fast kernel
+// hands a pair over at u, v > tau <= 2000, so 32 u < 65504), and a = 2^25 a, b = 2^25 b make the update  v~ = b~ / (G~^T u~)
+// come out in the same scaled domain with no extra instruction.  Same accumulator layout as the other 16x16 configurations.
+constexpr float H_PANEL_SCALE = 32.f, H_GIBBS_SCALE = 32768.f, H_IN_SCALE = 33554432.f;     // 2^5, 2^15, 2^25 = 2^15 * 2^5 * 2^5
+constexpr double H_MAX_COST_OVER_REG = 11.5;       // exp(-11.78) * 2^15 = 2^-2: below it the low piece of an entry loses bits
+constexpr double H_MAX_TAU = 2000.0;
+struct CfgH32x16 {
+    using T = float;
+    static constexpr bool SPLIT = true, HALF = true;
+    static constexpr int NP = 2;
+    static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 4;
+    using acc_t = float __attribute__((ext_vector_type(4)));
+    using vec4_t = float __attribute__((ext_vector_type(4)));
+    __host__ __device__ static constexpr int lidx(int t, int r, int g) { return 4 * (4 * t + r) + g; }
+    __host__ __device__ static constexpr int lidx_of_row(int t, int p) { return lidx(t, p & 3, p >> 2); }
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) {     // (unused: selector of tail_rows only)
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    __device__ static inline float eps() { return 1.1920929e-07f; }
+};
+
 struct CfgF64x16 {   // v_mfma_f64_16x16x4_f64 has its own C/D map: hardware row = (lane>>4) + 4*reg (k-step order)
     using T = double;
-    static constexpr bool SPLIT = false;
+    static constexpr bool SPLIT = false, HALF = false;
+    static constexpr int NP = 0;
     static constexpr int TILE = 16, NREG = 4, NGRP = 4, VEC = 2;
     using acc_t = double __attribute__((ext_vector_type(4)));
     using vec4_t = double __attribute__((ext_vector_type(2)));
@@ -359,6 +388,8 @@ constexpr float BAND1_DOWN = 2.93873588e-39f;          // 2^-128: scale of the s
 constexpr double BAND1_UP_LN = 88.722839111672999;     // 128 ln 2
 using bf16x8_t = __bf16 __attribute__((ext_vector_type(8)));
 using bf16x2_t = __bf16 __attribute__((ext_vector_type(2)));
+using f16x8_t = _Float16 __attribute__((ext_vector_type(8)));
+using f16x2_t = _Float16 __attribute__((ext_vector_type(2)));
 using u32x4_t = unsigned int __attribute__((ext_vector_type(4)));
 using f32x2_t = float __attribute__((ext_vector_type(2)));
 
@@ -366,76 +397,107 @@ __device__ inline unsigned int cvt_pk_bf16(float lo, float hi) {      // v_cvt_p
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
-// (x0, x1) -> three packed bf16 pairs with hi + mid + lo == x exactly (each residual is exactly representable)
-struct Split3 { unsigned int hi, mid, lo; };
-__device__ inline Split3 split3(float x0, float x1) {
-    Split3 o;
-    o.hi = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(o.hi << 16), r1 = x1 - __uint_as_float(o.hi & 0xffff0000u);
-    o.mid = cvt_pk_bf16(r0, r1);
-    r0 -= __uint_as_float(o.mid << 16);
-    r1 -= __uint_as_float(o.mid & 0xffff0000u);
-    o.lo = cvt_pk_bf16(r0, r1);
+__device__ inline unsigned int cvt_pk_f16(float lo, float hi) {       // v_cvt_pk_f16_f32, round to nearest even
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+}
+// x - (the low / high fp16 of the packed register h) in ONE instruction each: v_fma_mix_f32 reads an fp16 operand straight
+// out of a packed register (the compiler's own choice is two v_cvt_f32_f16 and a double-rate v_pk_add_f32)
+__device__ inline float resid_f16_lo(float x, unsigned int h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+__device__ inline float resid_f16_hi(float x, unsigned int h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+// (x0, x1) -> NP packed pairs of pieces, largest first.  bf16 (NP = 3): hi + mid + lo == x exactly (each residual is exactly
+// representable).  fp16 (NP = 2): hi + lo == x to 2^-22 |x| while the low piece is a normal number (scaled domain of CfgH32x16).
+template <int NP> struct Pieces { unsigned int p[NP]; };
+template <class C> __device__ inline Pieces<C::NP> split_pair(float x0, float x1) {
+    Pieces<C::NP> o;
+    if constexpr (C::HALF) {
+        o.p[0] = cvt_pk_f16(x0, x1);
+        o.p[1] = cvt_pk_f16(resid_f16_lo(x0, o.p[0]), resid_f16_hi(x1, o.p[0]));
+    } else {
+        o.p[0] = cvt_pk_bf16(x0, x1);
+        float r0 = x0 - __uint_as_float(o.p[0] << 16), r1 = x1 - __uint_as_float(o.p[0] & 0xffff0000u);
+        o.p[1] = cvt_pk_bf16(r0, r1);
+        r0 -= __uint_as_float(o.p[1] << 16);
+        r1 -= __uint_as_float(o.p[1] & 0xffff0000u);
+        o.p[2] = cvt_pk_bf16(r0, r1);
+    }
     return o;
 }
 __host__ __device__ constexpr int split_kblocks(int RT) { return (RT + 1) / 2; }
+// piece products of one term block, smallest first: (A piece, B piece).  3 pieces: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1;
+// 2 pieces: a2 b1, a1 b2, a1 b1
+template <int NP> __host__ __device__ constexpr int n_terms() { return NP == 3 ? 6 : 3; }
+template <int NP> __host__ __device__ constexpr int term_a(int i) {
+    if (NP == 3) return i == 0 ? 2 : (i == 2 || i == 3 ? 1 : 0);
+    return i == 0 ? 1 : 0;
+}
+template <int NP> __host__ __device__ constexpr int term_b(int i) {
+    if (NP == 3) return i == 1 ? 2 : (i == 2 || i == 4 ? 1 : 0);
+    return i == 1 ? 1 : 0;
+}
+template <class C> __device__ inline typename C::acc_t mfma_pieces(u32x4_t a, u32x4_t b, typename C::acc_t c) {
+    if constexpr (C::HALF) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
-// the scaling panel as bf16 B operands: p[part][k-block] = the lane's 8 k-slots (accumulator registers of row-tiles 2 kb, 2 kb + 1)
-template <int RT> struct SplitPanel { u32x4_t p[3][split_kblocks(RT)]; };
+// the scaling panel as packed B operands: p[part][k-block] = the lane's 8 k-slots (accumulator registers of row-tiles 2 kb, 2 kb + 1)
+template <int RT, int NP> struct SplitPanel { u32x4_t p[NP][split_kblocks(RT)]; };
 // LIVE1: only accumulator register 0 of the last row-tile holds cell types (K mod 16 in 1..4); the others are zero
 template <class C, int RT, bool LIVE1 = false>
-__device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel<RT> &B) {
+__device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel<RT, C::NP> &B) {
     constexpr int KB = split_kblocks(RT);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {       // element pairs (0,1), (2,3) of row-tile 2 kb, then of row-tile 2 kb + 1
             const int t = 2 * kb + h / 2;
-            Split3 sp = {0u, 0u, 0u};
+            Pieces<C::NP> sp;
+#pragma unroll
+            for (int part = 0; part < C::NP; ++part) sp.p[part] = 0u;
             if (t < RT && !(LIVE1 && t == RT - 1 && (h & 1)))
-                sp = split3(IN[t < RT ? t : 0][2 * (h & 1)], (LIVE1 && t == RT - 1) ? 0.f : IN[t < RT ? t : 0][2 * (h & 1) + 1]);
-            B.p[0][kb][h] = sp.hi; B.p[1][kb][h] = sp.mid; B.p[2][kb][h] = sp.lo;
+                sp = split_pair<C>(IN[t < RT ? t : 0][2 * (h & 1)], (LIVE1 && t == RT - 1) ? 0.f : IN[t < RT ? t : 0][2 * (h & 1) + 1]);
+#pragma unroll
+            for (int part = 0; part < C::NP; ++part) B.p[part][kb][h] = sp.p[part];
         }
 }
 // one 16-row output tile of X * panel; `form` = the [part][k-block][out tile][lane] x 16-byte image of X (LDS or global)
 template <class C, int RT>
-__device__ inline typename C::acc_t split_tile_product(const typename C::T *form, int lane, int t, const SplitPanel<RT> &B,
+__device__ inline typename C::acc_t split_tile_product(const typename C::T *form, int lane, int t, const SplitPanel<RT, C::NP> &B,
                                                        typename C::acc_t acc) {
-    constexpr int KB = split_kblocks(RT);
+    constexpr int KB = split_kblocks(RT), NP = C::NP;
     const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form);
-    auto mm = [](u32x4_t a, u32x4_t b, typename C::acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    };
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        const u32x4_t a1 = img[((0 * KB + kb) * RT + t) * WAVE + lane];
-        const u32x4_t a2 = img[((1 * KB + kb) * RT + t) * WAVE + lane];
-        const u32x4_t a3 = img[((2 * KB + kb) * RT + t) * WAVE + lane];
-        // smallest terms first
-        acc = mm(a3, B.p[0][kb], acc);
-        acc = mm(a1, B.p[2][kb], acc);
-        acc = mm(a2, B.p[1][kb], acc);
-        acc = mm(a2, B.p[0][kb], acc);
-        acc = mm(a1, B.p[1][kb], acc);
-        acc = mm(a1, B.p[0][kb], acc);
+        u32x4_t a[NP];
+#pragma unroll
+        for (int part = 0; part < NP; ++part) a[part] = img[((part * KB + kb) * RT + t) * WAVE + lane];
+#pragma unroll
+        for (int i = 0; i < n_terms<NP>(); ++i) acc = mfma_pieces<C>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], acc);
     }
     return acc;
 }
-// OUT = X_form * IN for the whole panel.  The three operand pieces of step (t, kb + 1) are requested from LDS before the six
+// OUT = X_form * IN for the whole panel.  The operand pieces of step (t, kb + 1) are requested from LDS before the
 // MFMAs of step (t, kb) are issued, so a wave never sits on an LDS round trip between MFMA groups.
 // form1 (nullable, wave-uniform): the band-1 image of the same operand; OUT = X0 * IN + 2^-128 (X1 * IN).
 template <class C, int RT, bool LIVE1 = false>
 __device__ inline void panel_product_split(const typename C::T *form, const typename C::T *form1, int lane,
                                            const typename C::acc_t (&IN)[RT], typename C::acc_t (&OUT)[RT],
                                            const typename C::acc_t &last_init) {
-    constexpr int KB = split_kblocks(RT);
-    SplitPanel<RT> B;
+    constexpr int KB = split_kblocks(RT), NP = C::NP;
+    SplitPanel<RT, NP> B;
     split_panel<C, RT, LIVE1>(IN, B);
     const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form) + lane;
-    auto mm = [](u32x4_t a, u32x4_t b, typename C::acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    };
-    u32x4_t a1 = img[((0 * KB + 0) * RT + 0) * WAVE], a2 = img[((1 * KB + 0) * RT + 0) * WAVE], a3 = img[((2 * KB + 0) * RT + 0) * WAVE];
+    u32x4_t a[NP];
+#pragma unroll
+    for (int part = 0; part < NP; ++part) a[part] = img[((part * KB + 0) * RT + 0) * WAVE];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         typename C::acc_t acc;
@@ -444,22 +506,19 @@ __device__ inline void panel_product_split(const typename C::T *form, const type
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int nt = kb + 1 < KB ? t : t + 1, nkb = kb + 1 < KB ? kb + 1 : 0;      // the step after this one
-            u32x4_t n1 = a1, n2 = a2, n3 = a3;
+            u32x4_t n[NP];
+#pragma unroll
+            for (int part = 0; part < NP; ++part) n[part] = a[part];
             if (nt < RT) {
-                n1 = img[((0 * KB + nkb) * RT + nt) * WAVE];
-                n2 = img[((1 * KB + nkb) * RT + nt) * WAVE];
-                n3 = img[((2 * KB + nkb) * RT + nt) * WAVE];
+#pragma unroll
+                for (int part = 0; part < NP; ++part) n[part] = img[((part * KB + nkb) * RT + nt) * WAVE];
             }
             __builtin_amdgcn_sched_barrier(0x6);        // (VALU / SALU may move across; the LDS reads stay ahead of the MFMAs)
-            // smallest terms first
-            acc = mm(a3, B.p[0][kb], acc);
-            acc = mm(a1, B.p[2][kb], acc);
-            acc = mm(a2, B.p[1][kb], acc);
-            acc = mm(a2, B.p[0][kb], acc);
-            acc = mm(a1, B.p[1][kb], acc);
-            acc = mm(a1, B.p[0][kb], acc);
+#pragma unroll
+            for (int i = 0; i < n_terms<NP>(); ++i) acc = mfma_pieces<C>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], acc);
             __builtin_amdgcn_sched_barrier(0x6);
-            a1 = n1; a2 = n2; a3 = n3;
+#pragma unroll
+            for (int part = 0; part < NP; ++part) a[part] = n[part];
         }
         OUT[t] = acc;
     }
@@ -512,7 +571,7 @@ struct GridParams {
 //   [tail-row weights]                         2 forms x 2 chains x tail_steps x WAVE pairs (VALU tail rows)
 //   [plain tables: 3 x 64 x WAVE]              G[lane][k], G[k][lane], (G o M)[lane][k] for solo_pairs
 template <class C> __host__ __device__ constexpr int form_elems(int RT) {
-    return C::SPLIT ? 3 * ((RT + 1) / 2) * RT * WAVE * 4 : RT * C::TILE * RT * C::TILE;
+    return C::SPLIT ? C::NP * ((RT + 1) / 2) * RT * WAVE * 4 : RT * C::TILE * RT * C::TILE;
 }
 template <class C> __host__ __device__ constexpr int acc0_offset(int RT) { return 3 * form_elems<C>(RT); }
 template <class C> __host__ __device__ constexpr int tail_offset(int RT) { return acc0_offset<C>(RT) + RT * C::TILE; }
@@ -524,7 +583,11 @@ template <class C> __host__ __device__ constexpr int plain_offset(int RT) { retu
 // X0 * in + 2^-128 (X1 * in): both partial products are f32-accurate, so entries down to 2^-238 = exp(-165) take part
 // with full precision -- the range POT's log-absorption covers, without a per-pair kernel matrix.
 template <class C> __host__ __device__ constexpr int band1_offset(int RT) { return plain_offset<C>(RT) + 3 * 64 * WAVE; }
-template <class C> __host__ __device__ constexpr int img_total(int RT) { return band1_offset<C>(RT) + (C::SPLIT ? 3 * form_elems<C>(RT) : 0); }
+template <class C> __host__ __device__ constexpr int img_total_plain(int RT) { return band1_offset<C>(RT) + ((C::SPLIT && !C::HALF) ? 3 * form_elems<C>(RT) : 0); }
+// [tracking block] (fp16-split configuration): a complete bf16-split operand block behind the fp16 one -- pairs in which POT
+// would tau-absorb leave the scaled fp16 domain and are redone by the bf16-split tracking kernel
+template <class C> __host__ __device__ constexpr int track_img_offset(int RT) { return C::HALF ? band1_offset<C>(RT) : 0; }
+template <class C> __host__ __device__ constexpr int img_total(int RT) { return img_total_plain<C>(RT) + (C::HALF ? img_total_plain<CfgS32x16>(RT) : 0); }
 
 
 // ---- one wave per pair: the exact duplicates ---------------------------------------------------------------------------
@@ -592,7 +655,8 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
     const bool live = lane < K;
     const int pos = ((lane / 16) * 4 + (lane % 4)) * 4 + (lane % 16) / 4;     // accumulator slot of cell type `lane`
     const bool inrec = lane < KP;
-    const T acc0 = inrec ? img[acc0_offset<C>(RT) + pos] : T(1);
+    // (fp16-split configuration: the first-product table is stored in the scaled domain of the tile kernel, 2^20 G^T u0)
+    const T acc0 = inrec ? img[acc0_offset<C>(RT) + pos] * (C::HALF ? T(1) / (T(H_GIBBS_SCALE) * T(H_PANEL_SCALE)) : T(1)) : T(1);
     const T tau = T(p.tau);
     const int n_items = *n_items_ptr;
     const T kk = T(K) * T(K);
@@ -716,7 +780,7 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
     // one output row-tile at a time: only the v panel (or its bf16 pieces) is live
     T val = T(0);
     if constexpr (C::SPLIT) {
-        SplitPanel<RT> Bv;
+        SplitPanel<RT, C::NP> Bv;
         {
             acc_t Vr[RT];
 #pragma unroll
@@ -763,6 +827,7 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
         }
     }
     val = group_sum<C>(val) * scale;
+    if constexpr (C::HALF) val *= T(1) / T(H_IN_SCALE);     // u~^T (2^15 G o M) v~ = 2^25 u^T (G o M) v
     const bool redo = p.fb_list && !(val - val == T(0));       // NaN or inf: out of the f32 range somewhere along the way
     if (grp == 0 && col < cnt) {
         const int *meta = reinterpret_cast<const int *>(rec + 2 * KP + 1);
@@ -817,10 +882,13 @@ sinkhorn_stream_kernel(GridParams p) {
     using M = C;
     using T = typename C::T;
     using acc_t = typename M::acc_t;
+    static_assert(!(C::HALF && TRACK), "the fp16-split configuration has no tracking variant (scalings beyond tau leave its scaled domain)");
     constexpr int TILE = M::TILE, NREG = M::NREG, NGRP = M::NGRP;
     constexpr int KP = RT * TILE;
     constexpr int FORM = form_elems<C>(RT);
     constexpr int RSTRIDE = ring_slot_stride<C>(RT);
+    // fp16-split configuration: panels are 32 u, 32 v; a, b, the threshold and the error carry 2^25 (see CfgH32x16)
+    constexpr T PANEL_SCALE = C::HALF ? T(H_PANEL_SCALE) : T(1), IN_SCALE = C::HALF ? T(H_IN_SCALE) : T(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *lds = reinterpret_cast<T *>(smem_raw);
 
@@ -898,8 +966,8 @@ sinkhorn_stream_kernel(GridParams p) {
 
     const int K = p.K, N = p.N;
     const T *Pt = static_cast<const T *>(p.P);
-    const T uinit = T(1) / T(K);
-    const T tau = T(p.tau);
+    const T uinit = PANEL_SCALE / T(K);
+    const T tau = T(p.tau) * PANEL_SCALE;
     const T kk = T(K) * T(K);
     const unsigned long long colmask = (1ull << TILE) - 1ull;  // lanes of group 0
 
@@ -976,11 +1044,12 @@ sinkhorn_stream_kernel(GridParams p) {
                     load_regs<C>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
+                        if constexpr (C::HALF) { A[t][r] *= IN_SCALE; B[t][r] *= IN_SCALE; }
                         U[t][r] = (t == RT - 1) ? uinit - uinit * PADC[r] : uinit;   // 0 in padded slots; v follows from ACC
                         if constexpr (TRACK) { RU[t][r] = T(1); RV[t][r] = T(1); }
                     }
                 }
-                thr = Pt[(size_t)N * KP + j];      // stop threshold of column patient j (prep: f32 floor folded in)
+                thr = Pt[(size_t)N * KP + j] * IN_SCALE;      // stop threshold of column patient j (prep: f32 floor folded in)
                 chk = 1;
                 ii = 0; flags = 0; abs_at = -1; errv = T(1);
             }
@@ -1107,7 +1176,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 if constexpr (sizeof(T) == 8) flags |= FLAG_F64;
                 if (fin && grp == 0) {
                     if (p.iters) p.iters[q] = ii;
-                    if (p.err) p.err[q] = double(errv);
+                    if (p.err) p.err[q] = double(errv) * double(T(1) / IN_SCALE);
                 }
                 while (fmask) {     // wave-uniform: usually one pass; a second one when the ring fills up in between
                     const int space = p.ring - ring_cnt;
@@ -1143,6 +1212,93 @@ sinkhorn_stream_kernel(GridParams p) {
 __device__ inline unsigned short bf16_bits(float x) {
     return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
 }
+__device__ inline unsigned short f16_bits(float x) {
+    return __builtin_bit_cast(unsigned short, static_cast<_Float16>(x));
+}
+// split operand forms of configuration C at `img`: [part][k-block][out tile][lane][8 x 16 bit] pieces of G^T, G, G o M
+// (bf16: exact 3-way split of the f32 value; fp16: 2 pieces of 2^15 times the value -- the rounding chains of split_pair)
+template <class C>
+__device__ inline void write_split_forms(const double *__restrict__ Msrc, int K, int RT, double reg, float *__restrict__ img,
+                                         bool two_bands, int tid, int nthr) {
+    using M = C;
+    const int nimg = form_elems<C>(RT);
+    const int KB = split_kblocks(RT);
+    unsigned short *im16 = reinterpret_cast<unsigned short *>(img);
+    for (int idx = tid; idx < KB * RT * WAVE * 8; idx += nthr) {
+        const int e = idx % 8;
+        int rest = idx / 8;
+        const int lane = rest % WAVE; rest /= WAVE;
+        const int t = rest % RT;
+        const int kb = rest / RT;
+        const int orow = M::lidx_of_row(t, lane % M::TILE);
+        const int kt = 2 * kb + e / 4;                            // row-tile whose accumulator register e % 4 is this k-slot
+        const int k = kt < RT ? M::lidx(kt, e % 4, lane / M::TILE) : K;
+        float f[3] = {0.f, 0.f, 0.f}, f1[3] = {0.f, 0.f, 0.f};
+        if (orow < K && k < K) {
+            const double m_ko = Msrc[(size_t)k * K + orow], m_ok = Msrc[(size_t)orow * K + k];
+            const double sc = C::HALF ? double(H_GIBBS_SCALE) : 1.0;
+            f[0] = float(exp(-m_ko / reg) * sc);
+            f[1] = float(exp(-m_ok / reg) * sc);
+            f[2] = float(exp(-m_ok / reg) * m_ok * sc);
+            if (two_bands) {       // two exponent bands: entries below the safe minimum move to band 1, times 2^128
+                if (f[0] < SPLIT_SAFE_MIN) { f1[0] = float(exp(-m_ko / reg + BAND1_UP_LN)); f[0] = 0.f; }
+                if (f[1] < SPLIT_SAFE_MIN) {
+                    f1[1] = float(exp(-m_ok / reg + BAND1_UP_LN));
+                    f1[2] = float(exp(-m_ok / reg + BAND1_UP_LN) * m_ok);
+                    f[1] = 0.f; f[2] = 0.f;
+                }
+            }
+        }
+        if (two_bands) {
+            unsigned short *im1 = reinterpret_cast<unsigned short *>(img + band1_offset<C>(RT));
+#pragma unroll
+            for (int form = 0; form < 3; ++form) {
+                float x = f1[form];
+#pragma unroll
+                for (int part = 0; part < C::NP; ++part) {
+                    const unsigned short hb = bf16_bits(x);
+                    im1[(size_t)form * nimg * 2 + ((((size_t)part * KB + kb) * RT + t) * WAVE + lane) * 8 + e] = hb;
+                    x -= __uint_as_float((unsigned int)hb << 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int form = 0; form < 3; ++form) {
+            float x = f[form];
+#pragma unroll
+            for (int part = 0; part < C::NP; ++part) {
+                unsigned short hb;
+                if constexpr (C::HALF) { hb = f16_bits(x); x -= float(__builtin_bit_cast(_Float16, hb)); }
+                else { hb = bf16_bits(x); x -= __uint_as_float((unsigned int)hb << 16); }
+                im16[(size_t)form * nimg * 2 + ((((size_t)part * KB + kb) * RT + t) * WAVE + lane) * 8 + e] = hb;
+            }
+        }
+    }
+}
+// first product of every pair: (G^T u0)[j] = (1/K) * sum_k G[k][j] (times `scale`), in accumulator-slot order
+// (four adjacent lanes share a slot, each sums every fourth k: the K serial fp64 exponentials of a slot were the longest
+// chain of the whole preparation)
+template <class C>
+__device__ inline void write_first_product(const double *__restrict__ Msrc, int K, int RT, double reg, typename C::T *__restrict__ tab,
+                                           double scale, int tid, int nthr) {
+    using M = C;
+    using T = typename C::T;
+    const int KP = RT * M::TILE;
+    for (int idx = tid; idx < 4 * KP; idx += nthr) {              // (4 KP and nthr are multiples of the wave size)
+        const int part = idx & 3, slot = idx >> 2;
+        const int r = slot % M::NREG;                             // slot order [tile][group][reg]
+        const int g = (slot / M::NREG) % M::NGRP;
+        const int t = slot / (M::NGRP * M::NREG);
+        const int j = M::lidx(t, r, g);
+        double s = 0.0;
+        if (j < K)
+            for (int k = part; k < K; k += 4) s += exp(-Msrc[(size_t)k * K + j] / reg);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0) tab[slot] = T(j < K ? s / K * scale : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
+    }
+}
+
 template <class C>
 __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT, double reg,
                                   typename C::T *__restrict__ img, const double *__restrict__ Psrc,
@@ -1153,57 +1309,10 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
     const int KP = RT * M::TILE;
     const int nimg = form_elems<C>(RT);
     if constexpr (C::SPLIT) {
-        // [part][k-block][out tile][lane][8 bf16]: hi / mid / lo pieces of the three operand forms (exact 3-way split of the
-        // f32 value, the same rounding chain as split3)
-        const int KB = split_kblocks(RT);
-        unsigned short *im16 = reinterpret_cast<unsigned short *>(img);
-        for (int idx = tid; idx < KB * RT * WAVE * 8; idx += nthr) {
-            const int e = idx % 8;
-            int rest = idx / 8;
-            const int lane = rest % WAVE; rest /= WAVE;
-            const int t = rest % RT;
-            const int kb = rest / RT;
-            const int orow = M::lidx_of_row(t, lane % M::TILE);
-            const int kt = 2 * kb + e / 4;                            // row-tile whose accumulator register e % 4 is this k-slot
-            const int k = kt < RT ? M::lidx(kt, e % 4, lane / M::TILE) : K;
-            float f[3] = {0.f, 0.f, 0.f}, f1[3] = {0.f, 0.f, 0.f};
-            if (orow < K && k < K) {
-                const double m_ko = Msrc[(size_t)k * K + orow], m_ok = Msrc[(size_t)orow * K + k];
-                f[0] = float(exp(-m_ko / reg));
-                f[1] = float(exp(-m_ok / reg));
-                f[2] = float(exp(-m_ok / reg) * m_ok);
-                if (write_tail & 4) {       // two exponent bands: entries below the safe minimum move to band 1, times 2^128
-                    if (f[0] < SPLIT_SAFE_MIN) { f1[0] = float(exp(-m_ko / reg + BAND1_UP_LN)); f[0] = 0.f; }
-                    if (f[1] < SPLIT_SAFE_MIN) {
-                        f1[1] = float(exp(-m_ok / reg + BAND1_UP_LN));
-                        f1[2] = float(exp(-m_ok / reg + BAND1_UP_LN) * m_ok);
-                        f[1] = 0.f; f[2] = 0.f;
-                    }
-                }
-            }
-            if (write_tail & 4) {
-                unsigned short *im1 = reinterpret_cast<unsigned short *>(img + band1_offset<C>(RT));
-#pragma unroll
-                for (int form = 0; form < 3; ++form) {
-                    float x = f1[form];
-#pragma unroll
-                    for (int part = 0; part < 3; ++part) {
-                        const unsigned short hb = bf16_bits(x);
-                        im1[(size_t)form * nimg * 2 + ((((size_t)part * KB + kb) * RT + t) * WAVE + lane) * 8 + e] = hb;
-                        x -= __uint_as_float((unsigned int)hb << 16);
-                    }
-                }
-            }
-#pragma unroll
-            for (int form = 0; form < 3; ++form) {
-                float x = f[form];
-#pragma unroll
-                for (int part = 0; part < 3; ++part) {
-                    const unsigned short hb = bf16_bits(x);
-                    im16[(size_t)form * nimg * 2 + ((((size_t)part * KB + kb) * RT + t) * WAVE + lane) * 8 + e] = hb;
-                    x -= __uint_as_float((unsigned int)hb << 16);
-                }
-            }
+        write_split_forms<C>(Msrc, K, RT, reg, img, (write_tail & 4) != 0, tid, nthr);
+        if constexpr (C::HALF) {     // the bf16-split block of the tracking kernel
+            write_split_forms<CfgS32x16>(Msrc, K, RT, reg, img + track_img_offset<C>(RT), false, tid, nthr);
+            write_first_product<CfgS32x16>(Msrc, K, RT, reg, img + track_img_offset<C>(RT) + acc0_offset<CfgS32x16>(RT), 1.0, tid, nthr);
         }
     } else {
     for (int idx = tid; idx < nimg; idx += nthr) {
@@ -1226,22 +1335,7 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
         img[2 * nimg + idx] = T(gm);
     }
     }
-    // first product of every pair: (G^T u0)[j] = (1/K) * sum_k G[k][j], in accumulator-slot order
-    // (four adjacent lanes share a slot, each sums every fourth k: the K serial fp64 exponentials of a slot were the longest
-    // chain of the whole preparation)
-    for (int idx = tid; idx < 4 * KP; idx += nthr) {              // (4 KP and nthr are multiples of the wave size)
-        const int part = idx & 3, slot = idx >> 2;
-        const int r = slot % M::NREG;                             // slot order [tile][group][reg]
-        const int g = (slot / M::NREG) % M::NGRP;
-        const int t = slot / (M::NGRP * M::NREG);
-        const int j = M::lidx(t, r, g);
-        double s = 0.0;
-        if (j < K)
-            for (int k = part; k < K; k += 4) s += exp(-Msrc[(size_t)k * K + j] / reg);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (part == 0) img[acc0_offset<C>(RT) + slot] = T(j < K ? s / K : 1.0);   // padded slots: 1 keeps b/acc = 0/1 finite
-    }
+    write_first_product<C>(Msrc, K, RT, reg, img + acc0_offset<C>(RT), C::HALF ? double(H_GIBBS_SCALE) * double(H_PANEL_SCALE) : 1.0, tid, nthr);
     // tail-row weights for the VALU variant (see tail_rows): [form][chain][k-step][lane] pairs behind the table
     if (write_tail & 2) {     // plain tables of solo_pairs: G[lane][k], G[k][lane], (G o M)[lane][k]
         T *plain = img + plain_offset<C>(RT);

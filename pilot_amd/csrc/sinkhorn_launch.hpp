@@ -7,7 +7,7 @@
 
 namespace pilot {
 
-enum { CFG_F32 = 0, CFG_F64 = 1, CFG_S32 = 2 };   // CfgF32x16, CfgF64x16, CfgS32x16 (bf16-split products, f32 values)
+enum { CFG_F32 = 0, CFG_F64 = 1, CFG_S32 = 2, CFG_H32 = 3 };   // CfgF32x16, CfgF64x16, CfgS32x16 (bf16-split products, f32 values), CfgH32x16 (fp16-split)
 
 // persistent stream kernel (one tile per wave); track: tau-tracking variant
 hipError_t launch_stream_f32(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
@@ -16,6 +16,8 @@ hipError_t launch_stream_f64(int RT, bool sym, bool track, dim3 grid, size_t lds
 hipError_t launch_solo_track_f64(dim3 grid, hipStream_t s, const GridParams &p);
 // live1: K mod 16 in 1..4, the dead registers of the last row-tile are skipped (RT >= 2)
 hipError_t launch_stream_s32(int RT, bool sym, bool track, int live1, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+// fp16-split configuration: fast pass only (its tracking pass is the bf16-split kernel on the block at track_img_elems)
+hipError_t launch_stream_h32(int RT, bool sym, int live1, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 // variants with the last row-tile on the VALU (tv = 1: <= 2 live rows, 2: <= 4; see tail_rows); RT >= 2
 hipError_t launch_stream_tv(int cfg, int tv, int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
 // one call's preparation: operand images + tables + slot-ordered proportions and the longest-first order keys in one
@@ -26,5 +28,7 @@ hipError_t launch_prep(int cfg, const double *M, int K, int RT, double reg, void
 // elements of T in the operand block of a call (see img_layout in sinkhorn_kernels.hpp)
 size_t img_elems(int cfg, int RT);
 size_t form_elems_rt(int cfg, int RT);
+// offset (in 4-byte elements) of the tracking kernel's operand block inside the call's block; 0: the block itself
+size_t track_img_elems(int cfg, int RT);
 
 }  // namespace pilot

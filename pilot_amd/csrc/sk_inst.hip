@@ -72,11 +72,17 @@ hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img
 hipError_t launch_prep_s32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
                            double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                            int *main_queue_head, int mode, int n_blocks, hipStream_t s);
+hipError_t launch_prep_h32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s);
 hipError_t launch_prep(int cfg, const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
                        double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                        int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
     if (cfg == CFG_F64)
         return launch_prep_f64(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
+    if (cfg == CFG_H32)
+        return launch_prep_h32(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
                                main_queue_head, mode, n_blocks, s);
     if (cfg == CFG_S32)
         return launch_prep_s32(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
@@ -85,9 +91,12 @@ hipError_t launch_prep(int cfg, const double *M, int K, int RT, double reg, void
                                main_queue_head, mode, n_blocks, s);
 }
 size_t form_elems_rt(int cfg, int RT) {
+    if (cfg == CFG_H32) return (size_t)form_elems<CfgH32x16>(RT);
     return cfg == CFG_S32 ? (size_t)form_elems<CfgS32x16>(RT) : (cfg == CFG_F64 ? (size_t)form_elems<CfgF64x16>(RT) : (size_t)form_elems<CfgF32x16>(RT));
 }
+size_t track_img_elems(int cfg, int RT) { return cfg == CFG_H32 ? (size_t)track_img_offset<CfgH32x16>(RT) : 0; }
 size_t img_elems(int cfg, int RT) {
+    if (cfg == CFG_H32) return (size_t)img_total<CfgH32x16>(RT);
     return cfg == CFG_S32 ? (size_t)img_total<CfgS32x16>(RT) : (cfg == CFG_F64 ? (size_t)img_total<CfgF64x16>(RT) : (size_t)img_total<CfgF32x16>(RT));
 }
 #define PILOT_TV_DECL(NAME) \
@@ -116,6 +125,42 @@ hipError_t launch_prep_f64(const double *M, int K, int RT, double reg, void *img
 // split configuration with only register 0 of the last row-tile live (K mod 16 in 1..4): TV = 1 skips the dead registers
 hipError_t launch_stream_s32_l1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
     return stream_any<CfgS32x16, 1>(RT, sym, track, grid, lds, s, p);
+}
+#elif SK_PART == 9
+// fp16-split configuration (fast pass only: no tracking variant), dead registers of the last row-tile skipped
+hipError_t launch_stream_h32_l1(int RT, bool sym, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    switch (RT) {
+    case 2: return sym ? stream_one<CfgH32x16, 2, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 2, false, false, 1>(grid, lds, s, p);
+    case 3: return sym ? stream_one<CfgH32x16, 3, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 3, false, false, 1>(grid, lds, s, p);
+    case 4: return sym ? stream_one<CfgH32x16, 4, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 4, false, false, 1>(grid, lds, s, p);
+    case 5: return sym ? stream_one<CfgH32x16, 5, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 5, false, false, 1>(grid, lds, s, p);
+    case 6: return sym ? stream_one<CfgH32x16, 6, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 6, false, false, 1>(grid, lds, s, p);
+    case 7: return sym ? stream_one<CfgH32x16, 7, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 7, false, false, 1>(grid, lds, s, p);
+    case 8: return sym ? stream_one<CfgH32x16, 8, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 8, false, false, 1>(grid, lds, s, p);
+    default: return hipErrorInvalidValue;
+    }
+}
+#elif SK_PART == 8
+hipError_t launch_stream_h32_l1(int RT, bool sym, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
+hipError_t launch_stream_h32(int RT, bool sym, int live1, dim3 grid, size_t lds, hipStream_t s, const GridParams &p) {
+    if (live1) return launch_stream_h32_l1(RT, sym, grid, lds, s, p);
+    switch (RT) {
+    case 1: return sym ? stream_one<CfgH32x16, 1, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 1, false, false>(grid, lds, s, p);
+    case 2: return sym ? stream_one<CfgH32x16, 2, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 2, false, false>(grid, lds, s, p);
+    case 3: return sym ? stream_one<CfgH32x16, 3, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 3, false, false>(grid, lds, s, p);
+    case 4: return sym ? stream_one<CfgH32x16, 4, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 4, false, false>(grid, lds, s, p);
+    case 5: return sym ? stream_one<CfgH32x16, 5, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 5, false, false>(grid, lds, s, p);
+    case 6: return sym ? stream_one<CfgH32x16, 6, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 6, false, false>(grid, lds, s, p);
+    case 7: return sym ? stream_one<CfgH32x16, 7, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 7, false, false>(grid, lds, s, p);
+    case 8: return sym ? stream_one<CfgH32x16, 8, true, false>(grid, lds, s, p) : stream_one<CfgH32x16, 8, false, false>(grid, lds, s, p);
+    default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_prep_h32(const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
+                           double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
+                           int *main_queue_head, int mode, int n_blocks, hipStream_t s) {
+    return prep_any<CfgH32x16>(M, K, RT, reg, img, P, Pslot, N, write_tail, stop_thr, floor_ulps, n_rows, row_begin, row_step, bucket, hist, list, split,
+                               main_queue_head, mode, n_blocks, s);
 }
 #elif SK_PART == 6
 hipError_t launch_stream_s32_l1(int RT, bool sym, bool track, dim3 grid, size_t lds, hipStream_t s, const GridParams &p);
