@@ -41,7 +41,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA == f3
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def algorithmic_flops(iters, K, period=20):
@@ -207,7 +207,7 @@ def main():
     pairs_launch = iters.size if not single_process_multi else iters.size // args.gpus
     bytes_launch = float(pairs_launch) * (2 * K * s_bytes + s_bytes)     # 2*K*s + s per pair
     roofline = {
-        "bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % {"fp32": "CfgF32x16", "fp64": "CfgF64x16", "bf16x3": "CfgS32x16"}[prec],
+        "bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % {"fp32": "CfgF32x16", "fp64": "CfgF64x16", "bf16x3": "CfgS32x16", "f16x2": "CfgH32x16"}[prec],
         "achieved": round(achieved_tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
         "traffic": None,
         "kernel_ms": round(kern_ms, 4), "kernel_ms_source": "HIP events on the launch stream, mean over the timed steps",
@@ -215,6 +215,19 @@ def main():
         "algorithmic_flop_per_launch": flops_launch, "pairs_per_launch": int(pairs_launch),
         "mean_updates_per_pair": round(float(iters.mean()), 2),
     }
+    if prec in ("bf16x3", "f16x2"):
+        # what the matrix pipe executes for those algorithmic flop: per 16-pair update 2 products x RT row-tiles x ceil(RT/2)
+        # k-blocks x (6 | 3) piece MFMAs of 16x16x32 (16 384 flop each), padding of K to 16 / 32 included
+        rt = (K + 15) // 16
+        terms = 6 if prec == "bf16x3" else 3
+        mfma_launch = float(iters.sum()) / 16.0 * 2 * rt * ((rt + 1) // 2) * terms * (1.0 if not single_process_multi else 1.0 / args.gpus)
+        ex_tf = mfma_launch * 16384.0 / (kern_ms * 1e-3) / 1e12
+        roofline["executed_on_matrix_pipe"] = {
+            "mfma_per_launch": mfma_launch, "tflops": round(ex_tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+            "frac": round(ex_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+            "note": "piece products actually issued (v_mfma_f32_16x16x32_%s) against the dense 16-bit MFMA peak; `frac` above prices "
+                    "the ALGORITHMIC f32 flop of SURVEY 8(d) against the f32-input MFMA peak, which this formulation can exceed"
+                    % ("bf16" if prec == "bf16x3" else "f16")}
     # offline rocprofv3 measurements of this exact workload (bench.py cannot profile itself): HBM traffic per launch from
     # the PMC passes and the kernel-trace average duration, both written by tools/profile_pmc.sh and keyed by workload
     try:
@@ -222,7 +235,7 @@ def main():
             tr = json.load(fh).get("%s|%g|%s" % (args.config, args.reg, prec))
         if tr and world == 1 and not single_process_multi:
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_source"] = ("profiles/r02/traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per launch, "
+            roofline["traffic_source"] = ("profiles/r03/traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per launch, "
                                           "measured at git %s)" % tr.get("git", "?"))
             if tr.get("kernel_ms_rocprofv3"):
                 roofline["kernel_ms_rocprofv3"] = tr["kernel_ms_rocprofv3"]
@@ -240,7 +253,8 @@ def main():
         "metric": "W2 patient-pairs/sec (full NxN EMD matrix)", "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "fp64": "f64", "bf16x3": "f32 (products as exact 3-way bf16 splits on the bf16 MFMA, f32 accumulate)"}[prec],
+        "dtype": {"fp32": "f32", "fp64": "f64", "bf16x3": "f32 (products as exact 3-way bf16 splits on the bf16 MFMA, f32 accumulate)",
+                  "f16x2": "f32 (products as 2-way fp16 splits, 22 significant bits, on the f16 MFMA, f32 accumulate)"}[prec],
         "data": "synthetic",
         "config": {"workload": "%s: %d patients x %d cell types x %d PCA dims, Sinkhorn reg=%g "
                                "(POT sinkhorn_stabilized semantics), all N^2 ordered pairs"

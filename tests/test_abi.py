@@ -58,7 +58,7 @@ def test_argument_validation_needs_no_device():
     assert rc in (_lib.OK, _lib.EHIP)
     rc = L.pilot_ot_cost_matrix(dp(P), 4, 3, 99, dp(out))
     assert rc in (_lib.EINVAL, _lib.EHIP)
-    assert L.pilot_ot_auto_precision(10.0) == 3 and L.pilot_ot_auto_precision(100.0) == 2     # bf16x3 / f64
+    assert L.pilot_ot_auto_precision(10.0) == 6 and L.pilot_ot_auto_precision(30.0) == 3 and L.pilot_ot_auto_precision(100.0) == 2     # f16x2 / bf16x3 / f64
 
 
 def test_python_wrappers_validate_shapes():

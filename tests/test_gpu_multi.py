@@ -63,7 +63,7 @@ def test_multi_plan_resident_and_timed():
     rng = np.random.default_rng(0)
     P, _ = make_problem(37, 20, 6, seed=3, cells_per_patient=300)
     M = rng.random((20, 20)); M /= M.max()
-    for prec in ("fp32", "bf16x3", "fp64"):
+    for prec in ("fp32", "bf16x3", "f16x2", "fp64"):
         np.testing.assert_array_equal(multi.sinkhorn_grid_multi(P, M, 0.2, devices=[0, 0, 0], precision=prec),
                                       engine.sinkhorn_grid(P, M, 0.2, precision=prec))
     np.testing.assert_array_equal(multi.emd_grid_multi(P, M, devices=[0, 0, 0]), engine.emd_grid(P, M))

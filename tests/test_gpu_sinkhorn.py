@@ -22,7 +22,7 @@ def test_pot_docstring_known_answers_through_the_c_abi():
     """ot.sinkhorn2([.5, .5], [.5, .5], [[0, 1], [1, 0]], 1) = 0.26894142 and ot.emd2(...) = 0.0 (POT docstrings)."""
     P = np.array([[0.5, 0.5], [0.5, 0.5], [1.0, 0.0], [0.0, 1.0]])
     M = np.array([[0.0, 1.0], [1.0, 0.0]])
-    for prec, tol in (("fp32", 1e-6), ("bf16x3", 1e-6), ("fp64", 5e-9)):
+    for prec, tol in (("fp32", 1e-6), ("bf16x3", 1e-6), ("f16x2", 1e-6), ("fp64", 5e-9)):
         E = engine.sinkhorn_grid(P, M, 1.0, precision=prec)
         assert abs(E[0, 1] - 0.26894142) < tol and abs(E[0, 0] - 0.26894142) < tol
     X = engine.emd_grid(P, M)
@@ -36,10 +36,13 @@ def test_parity_f32_and_f64(cfg, step, reg):
     Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=16, return_info=True)
     E32, i32 = engine.sinkhorn_grid(P, M, reg, precision="fp32", row_step=step, return_info=True)
     E64, i64 = engine.sinkhorn_grid(P, M, reg, precision="fp64", row_step=step, return_info=True)
-    # precision "auto" at these regs = f32 values iterated with bf16-split products (PILOT_OT_PREC_BF16X3)
+    # precision "auto" at these regs (max(M)/reg <= 11.5) = f32 values iterated with fp16-split products (PILOT_OT_PREC_F16X2)
     Es, isp = engine.sinkhorn_grid(P, M, reg, precision="auto", row_step=step, return_info=True)
-    np.testing.assert_array_equal(Es, engine.sinkhorn_grid(P, M, reg, precision="bf16x3", row_step=step))
+    np.testing.assert_array_equal(Es, engine.sinkhorn_grid(P, M, reg, precision="f16x2", row_step=step))
     assert np.abs(Es - Eo).max() <= TOL32
+    # the bf16-split configuration (AUTO for 11.5 < max(M)/reg <= 60) on the same problem
+    Eb, ib = engine.sinkhorn_grid(P, M, reg, precision="bf16x3", row_step=step, return_info=True)
+    assert np.abs(Eb - Eo).max() <= TOL32 and (ib["iters"] == i32["iters"]).mean() > 0.98
     assert np.all(isp["iters"] <= io["iters"]) and np.all(isp["iters"] % 20 == 1) and np.all((isp["flags"] & _lib.FLAG_F64) == 0)
     assert (isp["iters"] == i32["iters"]).mean() > 0.98          # same stopping decisions as the f32 MFMA path, up to rounding
     assert np.abs(E32 - Eo).max() <= TOL32
@@ -86,7 +89,7 @@ def test_small_reg_f32_stays_within_tolerance_on_this_distribution():
 
 
 @pytest.mark.parametrize("K", [1, 2, 7, 31, 32, 33, 48, 64, 65, 96, 100, 128])
-@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("fp64", TOL64)])
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("f16x2", TOL32), ("fp64", TOL64)])
 def test_every_tile_shape(K, prec, tol):
     """K sweeps the row-tile counts (f32: 32 rows per tile, f64: 16) incl. padding edges; N=37 is not a
     multiple of the 32 / 16 pairs a wave handles."""
@@ -159,7 +162,7 @@ def test_pairs_that_go_nan_are_resolved_like_pot():
     (flag F64) must carry the oracle's value, update count and flags."""
     P, M = make_problem(**CONFIGS["c1"])
     Eo, io = O.sinkhorn_grid(P, M, 0.0025, n_threads=16, return_info=True)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x3", "f16x2"):
         Eg, ig = engine.sinkhorn_grid(P, M, 0.0025, precision=prec, return_info=True)
         assert not np.isnan(Eg).any()
         redone = (ig["flags"] & _lib.FLAG_F64) > 0
@@ -169,7 +172,7 @@ def test_pairs_that_go_nan_are_resolved_like_pot():
         np.testing.assert_array_equal((ig["flags"] & 15)[redone], (io["flags"] & 15)[redone])
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("fp64", TOL64)])
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("f16x2", TOL32), ("fp64", TOL64)])
 def test_nonsymmetric_cost(prec, tol):
     rng = np.random.default_rng(4)
     P, _ = make_problem(20, 40, 6, seed=9, cells_per_patient=300)
@@ -182,7 +185,7 @@ def test_nonsymmetric_cost(prec, tol):
 
 
 @pytest.mark.parametrize("K", [34, 67])
-@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("fp64", TOL64)])
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("f16x2", TOL32), ("fp64", TOL64)])
 def test_nonsymmetric_cost_with_tail_rows(K, prec, tol):
     """K mod 16 <= 4 puts the last row-tile on the VALU (tail_rows); a non-symmetric cost uses the second weight form
     and (small grid, no solo waves) the cooperative kernel."""
@@ -195,7 +198,7 @@ def test_nonsymmetric_cost_with_tail_rows(K, prec, tol):
     assert np.abs(Eg - Eo).max() <= tol
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("fp64", TOL64)])
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("f16x2", TOL32), ("fp64", TOL64)])
 def test_duplicate_patients_take_the_solo_path(prec, tol, monkeypatch):
     """Pairs with a == b bit for bit (the diagonal AND duplicate patients) are solved one per wavefront; more duplicates
     than rows must queue up, row shards must reproduce the full matrix, and switching the path off must agree within
@@ -379,7 +382,7 @@ def test_tau_tracking_path_mixes_with_the_fast_path(reg, tau, lo, hi):
     np.testing.assert_array_equal((ig["flags"] & _lib.FLAG_ABSORBED) > 0, abs_o)
     np.testing.assert_array_equal(ig["iters"], io["iters"])
     assert np.abs(Eg - Eo).max() <= 1e-10
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x3", "f16x2"):
         Eg, ig = engine.sinkhorn_grid(P, M, reg, tau=tau, precision=prec, return_info=True)
         assert abs(((ig["flags"] & _lib.FLAG_ABSORBED) > 0).mean() - abs_o.mean()) < 0.05
         assert np.abs(Eg - Eo)[ok].max() <= TOL32
@@ -402,7 +405,7 @@ def test_golden_fixture_matrix(name):
     P, M = g["proportions"], g["cost"] / g["cost"].max()
     E = engine.sinkhorn_grid(P, M, float(g["reg"]), precision="fp64")
     assert np.abs(E - g["emd_reg"]).max() <= TOL64
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x3", "f16x2"):
         E = engine.sinkhorn_grid(P, M, float(g["reg"]), precision=prec)
         assert np.abs(E - g["emd_reg"]).max() <= TOL32
 
@@ -432,7 +435,7 @@ def test_c4_shape_sampled_rows():
     P, M = make_problem(**CONFIGS["c4"])
     rows = dict(row_begin=11, row_end=2000, row_step=997)
     Eo = O.sinkhorn_grid(P, M, 0.1, n_threads=16, **rows)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x3", "f16x2"):
         Eg = engine.sinkhorn_grid(P, M, 0.1, precision=prec, **rows)
         assert np.abs(Eg - Eo).max() <= TOL32
     Eg = engine.sinkhorn_grid(P, M, 0.1, precision="fp64", **rows)
@@ -443,7 +446,7 @@ def test_results_do_not_depend_on_work_order_or_occupancy(monkeypatch):
     """A pair's arithmetic is independent of which wave / column / launch order it lands in: disabling the
     longest-first ordering or changing the number of resident workgroups must reproduce the same bits."""
     P, M = make_problem(**CONFIGS["c2"])
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x3", "f16x2"):
         ref, iref = engine.sinkhorn_grid(P, M, 0.1, precision=prec, return_info=True)
         for dbg in ("2", "16", "34"):          # no ordering; 1 workgroup per CU; both
             monkeypatch.setenv("PILOT_OT_DEBUG", dbg)
