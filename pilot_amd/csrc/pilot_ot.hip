@@ -458,13 +458,14 @@ bool stream_has_solo(int w, int RT, bool sym, int tv, bool split) {
 
 // LDS of one stream-kernel workgroup: operand image(s) + first-product table + tail weights + one ring of finished pairs
 // per wave.  The ring gets as many slots (<= 16) as fit while `want` workgroups stay resident per CU; at least 4.
+// min_ring: the parked-flush variants (pilot::parked_flush) need a full tile's worth of slots.
 struct StreamLds { size_t bytes; int ring, wgs_per_cu; };
-StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want) {
+StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want, int min_ring = 4) {
     StreamLds r;
     for (;;) {
         const size_t budget = LDS_BYTES / (size_t)want;
         long ring = budget > fixed ? (long)((budget - fixed) / ((size_t)pilot::WAVES_PER_WG * slot_bytes)) : 0;
-        if (ring >= 4 || want == 1) {
+        if (ring >= min_ring || want == 1) {
             if (ring > pilot::RING_MAX) ring = pilot::RING_MAX;
             if (ring < 1) ring = 0;
             r.ring = (int)ring; r.wgs_per_cu = want;
@@ -505,7 +506,9 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     size_t fixed = (size_t)(sym ? 1 : 2) * form * ts + (size_t)KP * ts;   // operand image(s) + first-product table
     // K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
     int tv = 0;
-    const int live1 = (split && RT >= 2 && K - (RT - 1) * TILE <= 4) ? 1 : 0;   // split: skip the dead registers of the last tile
+    // split: skip the dead registers of the last tile (beyond 4 row-tiles those variants run out of registers and spill
+    // 600-980 B per lane; the plain variants do not, and measure the same there)
+    const int live1 = (split && RT >= 2 && RT <= 4 && K - (RT - 1) * TILE <= 4) ? 1 : 0;
     if (!split) {
         const int n_tail = K - (RT - 1) * TILE;
         // (RT = 8 variants spill: left on the MFMA path)
@@ -590,7 +593,13 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if (!mixed) {
         int want = stream_min_waves(w, RT, sym, false, tv, split);
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
-        const StreamLds L = stream_lds(fixed, slot_bytes, want);
+        // split configurations up to 4 row-tiles flush their ring inline and park U in LDS meanwhile (pilot::parked_flush):
+        // one 16-byte line per lane and row-tile, and a ring of at least TILE slots
+        const bool park = split && RT <= 4;
+        const size_t park_bytes = park ? (size_t)pilot::WAVES_PER_WG * RT * 4 * 64 * ts : 0;
+        if (park && fixed + park_bytes + pilot::WAVES_PER_WG * slot_bytes * TILE > LDS_BYTES)
+            return fail(PILOT_OT_ENOTSUP, "K=%d: operand images + ring + park area exceed LDS", K);
+        const StreamLds L = stream_lds(fixed + park_bytes, slot_bytes, want, park ? TILE : 4);
         int wgs = pl->n_cu * L.wgs_per_cu;
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs > need) wgs = need;

@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_solo_track_kerne
 // Small reg in f32 (bf16-split configuration): with p.bands == 2 the cost product uses both exponent bands of G o M; with
 // p.fb_list set, a pair whose cost is not finite is not written out but appended to fb_list for the f64 kernel.
 template <class C, int RT>
-__device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, const GridParams &p, int cnt) {
+__device__ inline __attribute__((always_inline)) void ring_flush_body(const typename C::T *ring, const GridParams &p, int cnt) {
     using M = C;
     using T = typename C::T;
     using acc_t = typename C::acc_t;
@@ -846,6 +846,16 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slots are reused only after every lane has read them
     __builtin_amdgcn_wave_barrier();
 }
+template <class C, int RT>
+__device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, const GridParams &p, int cnt) {
+    ring_flush_body<C, RT>(ring, p, cnt);
+}
+// PARKED flush (split configurations, fast kernel, RT <= 4): the call above costs the kernel a stack (the callee saves the
+// registers it borrows: 224 B per lane, written back to HBM once per wave -- 37 MB per c3 launch).  Here the flush is inlined
+// instead and the wave makes room for it itself: U goes to a wave-private LDS line, A and B are read again from the slot-
+// ordered proportions (L2) and ACC = G^T u is recomputed with one more product (bit-identical: same inputs, same
+// instruction sequence), V is dead at the flush point.  No scratch memory at all.
+template <class C, int RT, bool TRACK> constexpr bool parked_flush() { return C::SPLIT && !TRACK && RT <= 4; }
 
 constexpr int GREG_MAX = 64;
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
@@ -928,6 +938,9 @@ sinkhorn_stream_kernel(GridParams p) {
     const T *img_g = SYM ? lds : lds + FORM;                       // out = G in
     // wave-private ring of finished pairs (u, v panels + scale / output index / flags in the slot's padding)
     T *ring = lds + n_img + KP + n_tail + (threadIdx.x / WAVE) * p.ring * RSTRIDE;
+    constexpr bool PARK = parked_flush<C, RT, TRACK>();
+    // (PARK) one 16-byte line per lane and row-tile behind the rings: U while the inlined flush runs
+    T *park = lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (threadIdx.x / WAVE) * (RT * NREG * WAVE) + (threadIdx.x % WAVE) * NREG;
     // small symmetric problems keep the whole operand image in registers (no LDS access in the loop)
     constexpr int NA = RT * NREG * RT;
     constexpr bool GREG = operands_in_regs<C, RT, SYM>();
@@ -993,6 +1006,7 @@ sinkhorn_stream_kernel(GridParams p) {
 
     int ring_cnt = 0;
     auto flush = [&](int cnt) { ring_flush<C, RT>(ring, p, cnt); };
+    // (the lambdas used below are defined after the per-column state they touch)
 
     // work queue: waves draw batches of TILE items from one device-wide counter, so a wave that got
     // long-running pairs simply draws fewer batches
@@ -1178,6 +1192,34 @@ sinkhorn_stream_kernel(GridParams p) {
                     if (p.iters) p.iters[q] = ii;
                     if (p.err) p.err[q] = double(errv) * double(T(1) / IN_SCALE);
                 }
+                if constexpr (PARK) {
+                    // make room BEFORE the finished columns are stored (the ring has TILE slots here, so they always fit
+                    // afterwards and V is not needed past the flush)
+                    if (ring_cnt + (int)__popcll(fmask) > p.ring) {      // wave-uniform
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) store_regs<C>(park + t * NREG * WAVE, U[t]);
+                        ring_flush_body<C, RT>(ring, p, ring_cnt);
+                        ring_cnt = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
+                        const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            load_regs<C>(park + t * NREG * WAVE, U[t]);
+#pragma unroll
+                            for (int r = 0; r < NREG; ++r) { A[t][r] = T(0); B[t][r] = T(0); }
+                            if (active) {
+                                load_regs<C>(pa + t * NGRP * NREG, A[t]);
+                                load_regs<C>(pb + t * NGRP * NREG, B[t]);
+#pragma unroll
+                                for (int r = 0; r < NREG; ++r) {
+                                    if constexpr (C::HALF) { A[t][r] *= IN_SCALE; B[t][r] *= IN_SCALE; }
+                                }
+                            }
+                        }
+                        product(a_gt, w_gt, U, ACC, PADC);
+                    }
+                }
                 while (fmask) {     // wave-uniform: usually one pass; a second one when the ring fills up in between
                     const int space = p.ring - ring_cnt;
                     const int rank = (int)__popcll(fmask & ((1ull << col) - 1ull));
@@ -1199,13 +1241,18 @@ sinkhorn_stream_kernel(GridParams p) {
                     const unsigned long long taken = __ballot(put) & colmask;
                     fmask &= ~taken;
                     ring_cnt = __builtin_amdgcn_readfirstlane(ring_cnt + (int)__popcll(taken));
-                    if (ring_cnt >= p.ring) { flush(ring_cnt); ring_cnt = 0; }
+                    if constexpr (!PARK) {
+                        if (ring_cnt >= p.ring) { flush(ring_cnt); ring_cnt = 0; }
+                    }
                 }
                 if (fin) { active = false; want = true; }
             }
         }
     }
-    if (ring_cnt > 0) flush(ring_cnt);
+    if (ring_cnt > 0) {
+        if constexpr (PARK) ring_flush_body<C, RT>(ring, p, ring_cnt);
+        else flush(ring_cnt);
+    }
 }
 
 // One-launch setup: Gibbs kernel images in MFMA operand order, first-product table, P converted to T.

@@ -133,10 +133,6 @@ hipError_t launch_stream_h32_l1(int RT, bool sym, dim3 grid, size_t lds, hipStre
     case 2: return sym ? stream_one<CfgH32x16, 2, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 2, false, false, 1>(grid, lds, s, p);
     case 3: return sym ? stream_one<CfgH32x16, 3, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 3, false, false, 1>(grid, lds, s, p);
     case 4: return sym ? stream_one<CfgH32x16, 4, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 4, false, false, 1>(grid, lds, s, p);
-    case 5: return sym ? stream_one<CfgH32x16, 5, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 5, false, false, 1>(grid, lds, s, p);
-    case 6: return sym ? stream_one<CfgH32x16, 6, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 6, false, false, 1>(grid, lds, s, p);
-    case 7: return sym ? stream_one<CfgH32x16, 7, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 7, false, false, 1>(grid, lds, s, p);
-    case 8: return sym ? stream_one<CfgH32x16, 8, true, false, 1>(grid, lds, s, p) : stream_one<CfgH32x16, 8, false, false, 1>(grid, lds, s, p);
     default: return hipErrorInvalidValue;
     }
 }
