@@ -180,7 +180,10 @@ def main():
         iters = info["iters"]
         grid_ms, gather_ms = mp.times_ms()
         kern_ms, track_ms = float(np.max(grid_ms)), None
-        per_rank = {"grid_ms_per_shard": [round(float(x), 4) for x in grid_ms], "gather_ms": round(gather_ms, 4)}
+        rn, rr = mp.rccl_info()
+        per_rank = {"grid_ms_per_shard": [round(float(x), 4) for x in grid_ms], "gather_ms": round(gather_ms, 4),
+                    "rccl_ranks": rn, "rccl_user_rank": rr,
+                    "rccl_note": "ncclCommCount / ncclCommUserRank of every shard's communicator (0 / -1: peer-copy gather, no RCCL)"}
     else:
         main_ms, track = plan.kernel_times_ms(max_n=min(args.steps, 64))
         kern_ms = float(np.mean(main_ms)) if len(main_ms) else float("nan")
@@ -192,7 +195,20 @@ def main():
         if comm:
             E = np.empty((N, N))
             _lib.check(L.pilot_ot_memcpy_d2h(E.ctypes.data, d_full.p, 8 * N * N))
-            per_rank = {"rank0_kernel_ms": round(kern_ms, 4), "rank0_step_minus_kernel_ms": round(ms_per_step - kern_ms, 4)}
+            cnt, urank = comm.info()
+            # the collective alone (all-gather + row interleave of this rank's block), host-timed over a few calls
+            fence()
+            tg = time.perf_counter()
+            for _ in range(10):
+                comm.all_gather_rows(plan.dE, n_pad, N, d_stage.p, d_full.p)
+            fence()
+            gather_ms = 1e2 * (time.perf_counter() - tg)
+            per_rank = {"rank0_kernel_ms": round(kern_ms, 4), "rank0_step_minus_kernel_ms": round(ms_per_step - kern_ms, 4),
+                        "max_kernel_ms_over_ranks": round(comm.all_reduce_max(kern_ms), 4),
+                        "gather_ms": round(comm.all_reduce_max(gather_ms), 4),
+                        "rccl_ranks": cnt, "rccl_user_rank": urank, "max_rank_seen": int(comm.all_reduce_max(float(rank))),
+                        "rccl_note": "ncclCommCount / ncclCommUserRank of rank 0's communicator; max_rank_seen = all-reduce(max) of "
+                                     "every rank's index"}
         else:
             E = plan.fetch(n_rows=N)[0]
     assert E.shape == (N, N) and np.isfinite(E).all(), "bench produced a non-finite matrix"
@@ -272,6 +288,12 @@ def main():
     }
     if per_rank:
         out["multi_gpu"] = per_rank
+        fl = shard_floor(args.config, n_gpus)
+        if fl:
+            per_rank["predicted_floor"] = fl
+        per_rank["scaling_note"] = ("strong scaling: total work fixed.  c3 (this line) is bounded by the serial update chain of its slowest "
+                                    "pairs, not by the collective (see predicted_floor); the `c4` key is the shape whose shards stay "
+                                    "long enough to scale linearly")
 
     extras = not args.no_extras
     if extras:
@@ -299,6 +321,20 @@ def main():
 
 
 # ---- extras ---------------------------------------------------------------------------------------------------------
+def shard_floor(config, n_gpus):
+    """What ONE GPU takes for a 1/G row shard of this workload (tools/shard_floor.py, measured on one MI355X): the time a
+    perfectly overlapped G-GPU run cannot beat.  None when the table has no entry."""
+    try:
+        with open(os.path.join(PROFILE_DIR, "shard_floor.json")) as fh:
+            e = json.load(fh)["floor"].get(config, {}).get(str(n_gpus))
+    except (OSError, ValueError, KeyError):
+        return None
+    if not e:
+        return None
+    return {"one_gpu_shard_kernel_ms": e["kernel_ms"], "one_gpu_shard_call_ms": e["call_ms"],
+            "source": "profiles/r03/shard_floor.json (tools/shard_floor.py: rows 0::%d on one GPU)" % n_gpus}
+
+
 def host_to_host(P, M, reg, prec, reps=10):
     """numpy in -> numpy out through the host-buffer entry point (H2D of P and M, all kernels, D2H of the matrix):
     SURVEY.md 8(d)'s definition of t.  PCIe-inclusive; never `value`."""
@@ -396,7 +432,8 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
         g, ga = mp.times_ms()
         mp.close()
         return {"workload": "c4: 2000 x 100, reg 0.1, precision auto", "ms_per_step": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1),
-                "grid_ms_per_shard": [round(float(x), 3) for x in g], "gather_ms": round(ga, 3)}
+                "grid_ms_per_shard": [round(float(x), 3) for x in g], "gather_ms": round(ga, 3),
+                "predicted_floor": shard_floor("c4", args.gpus)}
     rb, re_, rs = sharding.shard_rows(N, rank, world)
     n_pad = sharding.n_padded_rows(N, world)
     plan = engine.DevicePlan(P, M, n_rows_max=n_pad)
@@ -430,6 +467,15 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
         _, info = plan.fetch(n_rows=N)
         fl = algorithmic_flops(info["iters"], P.shape[1])
         res["roofline_frac_f32_mfma"] = round(fl / (float(np.mean(main_ms)) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    if comm:
+        res["max_kernel_ms_over_ranks"] = round(comm.all_reduce_max(float(np.mean(main_ms))), 3)
+        fence()
+        tg = time.perf_counter()
+        for _ in range(5):
+            comm.all_gather_rows(plan.dE, n_pad, N, d_stage.p, d_full.p)
+        fence()
+        res["gather_ms"] = round(comm.all_reduce_max(2e2 * (time.perf_counter() - tg)), 3)
+        res["predicted_floor"] = shard_floor("c4", world)
     plan.close()
     if comm:
         d_stage.free(); d_full.free()

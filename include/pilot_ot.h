@@ -43,6 +43,7 @@ extern "C" {
 #define PILOT_OT_ERCCL (-4)   /* RCCL error / librccl missing (multi-GPU entry points only) */
 
 /* precision of the Sinkhorn pair-grid kernel */
+#define PILOT_OT_MAX_COST_OVER_REG 600.0 /* beyond it exp(-M/reg) leaves the f64 range: every entry point runs PREC_GENERIC */
 #define PILOT_OT_PREC_AUTO 0 /* F16X2 while max(M)/reg <= 11.5, BF16X3 (both f32 values) while exp(-max(M)/reg) stays a normal f32
                               * far from underflow (<= 60), else AUTO_MIXED / f64 */
 #define PILOT_OT_PREC_F32 1    /* f32 values, products on the f32-input MFMA (v_mfma_f32_16x16x4_f32): IEEE f32 FMA chains */
@@ -199,7 +200,9 @@ int pilot_ot_mirror_upper_dev(double *d_emd, int N, void *stream);
  *     ncclAllGather).  devices[s] is the HIP device of shard s.  gather: PILOT_OT_GATHER_RCCL needs G distinct devices
  *     and leaves the full matrix on EVERY device; PILOT_OT_GATHER_COPY assembles it on the device of shard 0 with
  *     peer copies and also accepts repeated device ids (logical shards on one GPU); PILOT_OT_GATHER_AUTO picks RCCL
- *     when the devices are distinct.  All calls are asynchronous on the shards' own streams until _sync / _fetch. */
+ *     when the devices are distinct.  All calls are asynchronous on the shards' own streams until _sync / _fetch; every
+ *     shard's launches are enqueued by a host thread of its own (PILOT_OT_MULTI_SERIAL=1: by the calling thread).
+ *     _sinkhorn resolves the precision once for all shards from max(M) of the inputs given to _set_inputs. */
 #define PILOT_OT_GATHER_AUTO 0
 #define PILOT_OT_GATHER_RCCL 1
 #define PILOT_OT_GATHER_COPY 2
@@ -218,6 +221,9 @@ int pilot_ot_multi_device_matrix(pilot_ot_multi *m, int shard, double **d_full);
 /* HIP-event times of the last call: grid_ms[s] = shard s's kernels; gather_ms = all-gather (or peer copies) + interleave: the
  * smallest per-shard (gather start -> matrix assembled) time, since a shard's collective also waits for its slower peers */
 int pilot_ot_multi_times(pilot_ot_multi *m, float *grid_ms, float *gather_ms);
+/* what RCCL itself reports for every shard's communicator (ncclCommCount / ncclCommUserRank): n_ranks[s], ranks[s], G entries
+ * each; 0 / -1 with the peer-copy gather (no communicator).  A record that says "8 GPUs" can prove RCCL saw 8 ranks. */
+int pilot_ot_multi_rccl_info(pilot_ot_multi *m, int *n_ranks, int *ranks);
 /* host-buffer forms (context cached per calling thread, released by pilot_ot_shutdown) */
 int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const double *M, double reg, int num_iter_max,
                                  double stop_thr, double tau, int check_period, int precision, double f32_floor_ulps,
@@ -234,6 +240,7 @@ typedef struct pilot_ot_comm pilot_ot_comm;
 int pilot_ot_comm_unique_id(char *uid);                                   /* PILOT_OT_UNIQUE_ID_BYTES bytes out */
 int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pilot_ot_comm **comm);   /* on the current device */
 int pilot_ot_comm_destroy(pilot_ot_comm *comm);
+int pilot_ot_comm_info(pilot_ot_comm *comm, int *n_ranks, int *rank);     /* ncclCommCount / ncclCommUserRank of this communicator */
 /* d_local: n_pad x N row block of this rank (n_pad = ceil(N / n_ranks), unused rows zero); d_stage: n_ranks * n_pad x N
  * scratch; d_full: N x N result on every rank.  Enqueued on `stream`. */
 int pilot_ot_comm_all_gather_rows(pilot_ot_comm *comm, const double *d_local, int n_pad, int N, double *d_stage,

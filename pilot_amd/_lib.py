@@ -35,8 +35,8 @@ SYMBOLS = [
     "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
     "pilot_ot_multi_create", "pilot_ot_multi_destroy", "pilot_ot_multi_set_inputs", "pilot_ot_multi_sinkhorn",
     "pilot_ot_multi_emd", "pilot_ot_multi_sync", "pilot_ot_multi_fetch", "pilot_ot_multi_device_matrix",
-    "pilot_ot_multi_times", "pilot_ot_sinkhorn_grid_multi", "pilot_ot_emd_grid_multi",
-    "pilot_ot_comm_unique_id", "pilot_ot_comm_init_rank", "pilot_ot_comm_destroy",
+    "pilot_ot_multi_times", "pilot_ot_multi_rccl_info", "pilot_ot_sinkhorn_grid_multi", "pilot_ot_emd_grid_multi",
+    "pilot_ot_comm_unique_id", "pilot_ot_comm_init_rank", "pilot_ot_comm_destroy", "pilot_ot_comm_info",
     "pilot_ot_comm_all_gather_rows", "pilot_ot_comm_all_reduce_max",
 ]
 GATHER = {"auto": 0, "rccl": 1, "copy": 2}
@@ -112,6 +112,8 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_multi_fetch.argtypes = [c_vp, dp, ip, dp, ip]
     L.pilot_ot_multi_device_matrix.argtypes = [c_vp, c_int, ctypes.POINTER(c_vp)]
     L.pilot_ot_multi_times.argtypes = [c_vp, fp, fp]
+    L.pilot_ot_multi_rccl_info.argtypes = [c_vp, ip, ip]
+    L.pilot_ot_comm_info.argtypes = [c_vp, ip, ip]
     L.pilot_ot_sinkhorn_grid_multi.argtypes = [dp, c_int, c_int, dp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl,
                                                c_int, ip, c_int, c_int, dp, ip, dp, ip]
     L.pilot_ot_emd_grid_multi.argtypes = [dp, c_int, c_int, dp, c_int, ip, c_int, c_int, dp, ip]

@@ -10,8 +10,13 @@ namespace pilot {
 
 // record the calling thread's error message (pilot_ot_last_error) and return `code`
 int abi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-// release the calling thread's cached multi-GPU context (called by pilot_ot_shutdown)
+// release every cached multi-GPU context of the host-buffer entry points (called by pilot_ot_shutdown)
 void abi_multi_release();
+// cell-level cohort, internal face used by the multi-device form (pilot_ot_multi.hip)
+int cell_enqueue_rows(pilot_ot_cell_cohort *c, double scale, double reg, int num_iter_max, double stop_thr, int check_period,
+                      double f32_floor_ulps, int row_begin, int row_end, int row_step, size_t *n_out);
+int cell_collect(pilot_ot_cell_cohort *c, size_t n_out, double *w2 /* nullable */, int *iters, double *err, float *kernel_ms);
+void cell_buffers(pilot_ot_cell_cohort *c, double **d_w2, hipStream_t *stream);
 
 }  // namespace pilot
 

@@ -398,7 +398,7 @@ int check_grid_args(int N, int K, double reg, int num_iter_max, double stop_thr,
 // and only its bookkeeping is tracked), so max(M)/reg must stay inside the exponent range of the widest type: beyond ~600
 // an f64 Gibbs entry underflows / a total scaling overflows where POT's absorbed kernel would not.  Such calls, and K > 128,
 // go to the reference-semantics kernel (generic_kernels.hpp), which rebuilds the absorbed kernel like POT.
-constexpr double MAX_COST_OVER_REG = 600.0;
+constexpr double MAX_COST_OVER_REG = PILOT_OT_MAX_COST_OVER_REG;
 
 // list / list_len (device, nullable): only the listed pairs (NaN hand-over of the fast kernels); queue: zeroed counter
 int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max, double stop_thr, double tau,
@@ -876,6 +876,8 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
         precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
         if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
     }
+    // (the device entry point judges the range by 1/reg: here max(M) is known)
+    if (precision == PILOT_OT_PREC_F16X2 && pilot_ot_auto_precision(mx / reg) != PILOT_OT_PREC_F16X2) precision = PILOT_OT_PREC_BF16X3;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     const size_t n_out = (size_t)n_rows * N;
     if (n_out == 0) return PILOT_OT_OK;
@@ -1256,7 +1258,7 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
 int cell_w2_collect(pilot_ot_cell_cohort *c, size_t n_out, double *w2, int *iters, double *err, float *kernel_ms) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (n_out == 0) return PILOT_OT_OK;
-    HIP_TRY(hipMemcpy(w2, c->dW, sizeof(double) * n_out, hipMemcpyDeviceToHost));
+    if (w2) HIP_TRY(hipMemcpy(w2, c->dW, sizeof(double) * n_out, hipMemcpyDeviceToHost));
     if (iters) HIP_TRY(hipMemcpy(iters, c->dIt, sizeof(int) * n_out, hipMemcpyDeviceToHost));
     if (err) HIP_TRY(hipMemcpy(err, c->dErr, sizeof(double) * n_out, hipMemcpyDeviceToHost));
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
@@ -1291,41 +1293,14 @@ PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, in
     return rc;
 }
 
-// full N x N grid with the rows dealt round-robin over several devices; every device holds the whole cohort, the
-// shards run concurrently on their own streams and the (small) result rows are assembled on the host
-PILOT_API int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offsets, int N, int D, double scale, double reg,
-                                          int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
-                                          const int *devices, int n_devices, double *w2, int *iters, double *err) {
-    if (!X || !offsets || !w2 || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
-    if (n_devices < 1 || n_devices > 64) return fail(PILOT_OT_EINVAL, "n_devices=%d out of range", n_devices);
-    int saved = 0;
-    HIP_TRY(hipGetDevice(&saved));
-    std::vector<pilot_ot_cell_cohort *> co(n_devices, nullptr);
-    std::vector<size_t> n_out(n_devices, 0);
-    int rc = PILOT_OT_OK;
-    for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
-        if (hipSetDevice(devices[s]) != hipSuccess) { rc = fail(PILOT_OT_EINVAL, "device %d not visible", devices[s]); break; }
-        rc = pilot_ot_cell_cohort_create(X, offsets, N, D, &co[s]);
-    }
-    for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
-        (void)hipSetDevice(devices[s]);
-        rc = cell_w2_enqueue(co[s], scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, s < N ? s : N, N, n_devices, &n_out[s]);
-    }
-    std::vector<double> tw, te;
-    std::vector<int> ti;
-    for (int s = 0; s < n_devices && rc == PILOT_OT_OK; ++s) {
-        (void)hipSetDevice(devices[s]);
-        tw.resize(n_out[s]); te.resize(n_out[s]); ti.resize(n_out[s]);
-        rc = cell_w2_collect(co[s], n_out[s], tw.data(), ti.data(), te.data(), nullptr);
-        for (size_t t = 0; rc == PILOT_OT_OK && t < n_out[s] / (size_t)N; ++t) {
-            const size_t row = (size_t)s + t * n_devices;
-            memcpy(w2 + row * N, tw.data() + t * N, sizeof(double) * N);
-            if (iters) memcpy(iters + row * N, ti.data() + t * N, sizeof(int) * N);
-            if (err) memcpy(err + row * N, te.data() + t * N, sizeof(double) * N);
-        }
-    }
-    for (int s = 0; s < n_devices; ++s)
-        if (co[s]) { (void)hipSetDevice(devices[s]); pilot_ot_cell_cohort_destroy(co[s]); }
-    (void)hipSetDevice(saved);
-    return rc;
+// internal face of the cohort for the multi-device form (pilot_ot_multi.hip: row shards + device-side all-gather)
+namespace pilot {
+int cell_enqueue_rows(pilot_ot_cell_cohort *c, double scale, double reg, int num_iter_max, double stop_thr, int check_period,
+                      double f32_floor_ulps, int row_begin, int row_end, int row_step, size_t *n_out) {
+    return cell_w2_enqueue(c, scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, row_begin, row_end, row_step, n_out);
 }
+int cell_collect(pilot_ot_cell_cohort *c, size_t n_out, double *w2, int *iters, double *err, float *kernel_ms) {
+    return cell_w2_collect(c, n_out, w2, iters, err, kernel_ms);
+}
+void cell_buffers(pilot_ot_cell_cohort *c, double **d_w2, hipStream_t *stream) { *d_w2 = c->dW; *stream = c->stream; }
+}  // namespace pilot

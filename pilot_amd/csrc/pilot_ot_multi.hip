@@ -18,11 +18,16 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "abi_common.hpp"
@@ -41,6 +46,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -68,6 +75,8 @@ int rccl_load() {
     PILOT_SYM(AllReduce, "ncclAllReduce")
     PILOT_SYM(GroupStart, "ncclGroupStart")
     PILOT_SYM(GroupEnd, "ncclGroupEnd")
+    PILOT_SYM(CommCount, "ncclCommCount")
+    PILOT_SYM(CommUserRank, "ncclCommUserRank")
     PILOT_SYM(GetErrorString, "ncclGetErrorString")
 #undef PILOT_SYM
     g_rccl = a;
@@ -101,17 +110,25 @@ int launch_interleave(const double *stage, int G, int n_pad, int N, double *full
 }
 
 // RCCL prints a version banner to stdout when a communicator is created; a host program whose stdout is a data channel
-// (bench.py prints one JSON line) must not receive it: while the guard lives, fd 1 points at stderr.
+// (bench.py prints one JSON line) must not receive it: while the guard lives, fd 1 points at stderr.  fd 1 is process-wide:
+// communicator creation is serialised by g_banner_mutex, and another thread that writes to stdout during those
+// milliseconds lands on stderr -- PILOT_OT_KEEP_RCCL_STDOUT=1 leaves fd 1 alone (the banner then goes to stdout).
+std::mutex g_banner_mutex;
 struct StdoutToStderr {
     int saved = -1;
-    StdoutToStderr() {
+    std::unique_lock<std::mutex> lock;
+    StdoutToStderr() : lock(g_banner_mutex) {
+        const char *keep = getenv("PILOT_OT_KEEP_RCCL_STDOUT");
+        if (keep && *keep && *keep != '0') return;
         fflush(stdout);
         saved = dup(1);
         if (saved >= 0) dup2(2, 1);
     }
     ~StdoutToStderr() {
+        if (saved < 0) return;
         fflush(stdout);
-        if (saved >= 0) { dup2(saved, 1); close(saved); }
+        dup2(saved, 1);
+        close(saved);
     }
 };
 
@@ -163,6 +180,13 @@ PILOT_API int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pi
     return PILOT_OT_OK;
 }
 
+PILOT_API int pilot_ot_comm_info(pilot_ot_comm *c, int *n_ranks, int *rank) {
+    if (!c || !n_ranks || !rank) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    RCCL_TRY(g_rccl.CommCount(c->comm, n_ranks));       // what RCCL itself reports for this communicator
+    RCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
+    return PILOT_OT_OK;
+}
+
 PILOT_API int pilot_ot_comm_destroy(pilot_ot_comm *c) {
     if (!c) return PILOT_OT_OK;
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
@@ -198,18 +222,88 @@ struct Shard {
     hipEvent_t ev_begin = nullptr, ev_grid = nullptr, ev_gather = nullptr, ev_end = nullptr;
     ncclComm_t comm = nullptr;
 };
+
+// One host thread per shard.  A call's per-shard work is a handful of stream launches (memset, prep, scatter, two or three
+// kernels, events): ~40 us of host time, the same order as a c3 shard's kernel at G = 8, so ONE thread enqueueing shard
+// after shard would leave the last device idle for the first seven's enqueue time.  The calling thread posts the job to
+// every worker, the workers enqueue on their own streams concurrently, the caller waits for the ENQUEUES (not for the
+// GPUs) and then issues the gather.  PILOT_OT_MULTI_SERIAL=1 runs the jobs on the calling thread instead (A/B switch).
+class ShardWorkers {
+public:
+    explicit ShardWorkers(int n) : w_(n) {
+        for (int i = 0; i < n; ++i) w_[i].reset(new W());
+        for (int i = 0; i < n; ++i) w_[i]->th = std::thread([this, i] { loop(*w_[i]); });
+    }
+    ~ShardWorkers() {
+        for (auto &w : w_) {
+            { std::lock_guard<std::mutex> l(w->mu); w->quit = true; }
+            w->cv.notify_all();
+        }
+        for (auto &w : w_) if (w->th.joinable()) w->th.join();
+    }
+    // run job(s) for every shard s on its worker; returns the first non-zero status (its message becomes the caller's)
+    int run(const std::function<int(int)> &job) {
+        for (size_t i = 0; i < w_.size(); ++i) {
+            W &w = *w_[i];
+            { std::lock_guard<std::mutex> l(w.mu); w.job = &job; w.idx = (int)i; w.done = false; }
+            w.cv.notify_all();
+        }
+        int rc = PILOT_OT_OK;
+        for (auto &wp : w_) {
+            W &w = *wp;
+            std::unique_lock<std::mutex> l(w.mu);
+            w.cv.wait(l, [&] { return w.done; });
+            if (w.rc != PILOT_OT_OK && rc == PILOT_OT_OK) rc = pilot::abi_fail(w.rc, "%s", w.msg.c_str());
+        }
+        return rc;
+    }
+private:
+    struct W {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        const std::function<int(int)> *job = nullptr; int idx = 0; bool done = true, quit = false; int rc = 0; std::string msg;
+    };
+    static void loop(W &w) {
+        for (;;) {
+            std::unique_lock<std::mutex> l(w.mu);
+            w.cv.wait(l, [&] { return w.quit || (w.job && !w.done); });
+            if (w.quit) return;
+            const std::function<int(int)> *job = w.job;
+            const int idx = w.idx;
+            l.unlock();
+            const int rc = (*job)(idx);
+            l.lock();
+            w.rc = rc;
+            w.msg = rc != PILOT_OT_OK ? pilot_ot_last_error() : "";
+            w.job = nullptr; w.done = true;
+            l.unlock();
+            w.cv.notify_all();
+        }
+    }
+    std::vector<std::unique_ptr<W>> w_;
+};
 }  // namespace
 
 struct pilot_ot_multi {
     int N = 0, K = 0, G = 0, n_pad = 0, gather = 0;
     std::vector<Shard> sh;
     bool ran = false, exact = false;
+    double max_cost = 1.0;                 // max(M) of the current inputs (set_inputs): precision / fallback decisions
+    hipEvent_t ev_copied = nullptr;        // peer-copy gather: shard 0 has read every shard's rows (next call may overwrite them)
+    bool copied_valid = false;
+    std::unique_ptr<ShardWorkers> workers; // nullptr: jobs run on the calling thread
+    int for_each_shard(const std::function<int(int)> &job) {
+        if (workers) return workers->run(job);
+        for (int s = 0; s < G; ++s) { const int rc = job(s); if (rc != PILOT_OT_OK) return rc; }
+        return PILOT_OT_OK;
+    }
 };
 
 namespace {
 void multi_free(pilot_ot_multi *m) {
     if (!m) return;
+    m->workers.reset();         // joins the shard threads
     DeviceGuard guard;
+    if (m->ev_copied) { (void)hipSetDevice(m->sh[0].device); (void)hipEventDestroy(m->ev_copied); }
     for (Shard &s : m->sh) {
         (void)hipSetDevice(s.device);
         if (s.comm) (void)g_rccl.CommDestroy(s.comm);
@@ -283,8 +377,28 @@ PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shar
             else for (int s = 0; s < n_shards; ++s) m->sh[s].comm = comms[s];
         }
     }
+    if (rc == PILOT_OT_OK && gather == PILOT_OT_GATHER_COPY) {
+        hipError_t e = hipSetDevice(m->sh[0].device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_copied, hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "event: %s", hipGetErrorString(e));
+    }
+    if (rc == PILOT_OT_OK && n_shards > 1) {
+        const char *serial = getenv("PILOT_OT_MULTI_SERIAL");
+        if (!(serial && *serial && *serial != '0')) m->workers.reset(new (std::nothrow) ShardWorkers(n_shards));
+    }
     if (rc != PILOT_OT_OK) { multi_free(m); return rc; }
     *mp = m;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_multi_rccl_info(pilot_ot_multi *m, int *n_ranks, int *ranks) {
+    if (!m || !n_ranks || !ranks) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    for (int s = 0; s < m->G; ++s) {
+        n_ranks[s] = 0; ranks[s] = -1;             // peer-copy gather: no communicator
+        if (!m->sh[s].comm) continue;
+        RCCL_TRY(g_rccl.CommCount(m->sh[s].comm, &n_ranks[s]));
+        RCCL_TRY(g_rccl.CommUserRank(m->sh[s].comm, &ranks[s]));
+    }
     return PILOT_OT_OK;
 }
 
@@ -295,6 +409,9 @@ PILOT_API int pilot_ot_multi_destroy(pilot_ot_multi *m) {
 
 PILOT_API int pilot_ot_multi_set_inputs(pilot_ot_multi *m, const double *P, const double *M) {
     if (!m || !P || !M) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    double mx = 0.0;
+    for (size_t t = 0; t < (size_t)m->K * m->K; ++t) mx = M[t] > mx ? M[t] : mx;
+    m->max_cost = mx;
     DeviceGuard guard;
     for (Shard &h : m->sh) {
         HIP_TRY(hipSetDevice(h.device));
@@ -343,10 +460,22 @@ int multi_gather(pilot_ot_multi *m, bool mirror) {
         else
             HIP_TRY(hipMemcpyPeerAsync(h0.dStage + s * n_loc, h0.device, h.dLocal, h.device, sizeof(double) * n_loc, h0.stream));
     }
+    // the shards' row blocks have been read from here on: the next call's kernels may overwrite them (multi_begin waits)
+    HIP_TRY(hipEventRecord(m->ev_copied, h0.stream));
+    m->copied_valid = true;
     int rc = launch_interleave(h0.dStage, m->G, m->n_pad, m->N, h0.dFull, h0.stream);
     if (rc == PILOT_OT_OK && mirror) rc = pilot_ot_mirror_upper_dev(h0.dFull, m->N, h0.stream);
     if (rc != PILOT_OT_OK) return rc;
     HIP_TRY(hipEventRecord(h0.ev_end, h0.stream));
+    return PILOT_OT_OK;
+}
+
+// start of a shard's part of a call (on the shard's thread): its stream must not overwrite dLocal while shard 0's peer
+// copies of the PREVIOUS call are still reading it (back-to-back asynchronous calls, peer-copy gather)
+int shard_begin(pilot_ot_multi *m, Shard &h) {
+    HIP_TRY(hipSetDevice(h.device));
+    if (m->gather == PILOT_OT_GATHER_COPY && m->copied_valid && &h != &m->sh[0]) HIP_TRY(hipStreamWaitEvent(h.stream, m->ev_copied, 0));
+    HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
     return PILOT_OT_OK;
 }
 }  // namespace
@@ -354,17 +483,30 @@ int multi_gather(pilot_ot_multi *m, bool mirror) {
 PILOT_API int pilot_ot_multi_sinkhorn(pilot_ot_multi *m, double reg, int num_iter_max, double stop_thr, double tau,
                                       int check_period, int precision, double f32_floor_ulps, int cost_is_symmetric) {
     if (!m) return fail(PILOT_OT_EINVAL, "NULL pointer");
-    DeviceGuard guard;
-    for (int s = 0; s < m->G; ++s) {
-        Shard &h = m->sh[s];
-        HIP_TRY(hipSetDevice(h.device));
-        HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
-        int rc = pilot_ot_sinkhorn_grid_dev(h.plan, h.dP, h.dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
-                                            f32_floor_ulps, cost_is_symmetric, s < m->N ? s : m->N /* more shards than rows: empty */, m->N, m->G, h.dLocal, h.dIt, h.dErr,
-                                            h.dFl, h.stream);
-        if (rc != PILOT_OT_OK) return rc;
-        HIP_TRY(hipEventRecord(h.ev_grid, h.stream));
+    if (!(reg > 0.0)) return fail(PILOT_OT_EINVAL, "reg=%g must be positive", reg);
+    // Decide ONCE, from max(M) of the current inputs, what every shard runs -- the same decisions pilot_ot_sinkhorn_grid takes
+    // on one device (the device entry point itself assumes a cost matrix normalised by its maximum, Trajectory.py:101):
+    // exp(-M/reg) outside the f64 range -> POT-literal kernel, whatever precision was asked for.
+    const double mor = m->max_cost / reg;
+    if (mor > PILOT_OT_MAX_COST_OVER_REG) precision = PILOT_OT_PREC_GENERIC;
+    if (precision == PILOT_OT_PREC_AUTO) {
+        precision = pilot_ot_auto_precision_for(mor, m->K, cost_is_symmetric);
+        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
     }
+    if (precision == PILOT_OT_PREC_F16X2 && pilot_ot_auto_precision(mor) != PILOT_OT_PREC_F16X2) precision = PILOT_OT_PREC_BF16X3;
+    DeviceGuard guard;
+    int rc = m->for_each_shard([&](int s) -> int {
+        Shard &h = m->sh[s];
+        int r = shard_begin(m, h);
+        if (r != PILOT_OT_OK) return r;
+        r = pilot_ot_sinkhorn_grid_dev(h.plan, h.dP, h.dM, reg, num_iter_max, stop_thr, tau, check_period, precision, f32_floor_ulps,
+                                       cost_is_symmetric, s < m->N ? s : m->N /* more shards than rows: empty */, m->N, m->G, h.dLocal,
+                                       h.dIt, h.dErr, h.dFl, h.stream);
+        if (r != PILOT_OT_OK) return r;
+        HIP_TRY(hipEventRecord(h.ev_grid, h.stream));
+        return PILOT_OT_OK;
+    });
+    if (rc != PILOT_OT_OK) return rc;
     m->ran = true; m->exact = false;
     return multi_gather(m, false);
 }
@@ -373,17 +515,19 @@ PILOT_API int pilot_ot_multi_emd(pilot_ot_multi *m, int cost_is_symmetric) {
     if (!m) return fail(PILOT_OT_EINVAL, "NULL pointer");
     DeviceGuard guard;
     const size_t n_loc = (size_t)m->n_pad * m->N;
-    for (int s = 0; s < m->G; ++s) {
+    int rc = m->for_each_shard([&](int s) -> int {
         Shard &h = m->sh[s];
-        HIP_TRY(hipSetDevice(h.device));
-        HIP_TRY(hipEventRecord(h.ev_begin, h.stream));
+        int r = shard_begin(m, h);
+        if (r != PILOT_OT_OK) return r;
         HIP_TRY(hipMemsetAsync(h.dLocal, 0, sizeof(double) * n_loc, h.stream));
         HIP_TRY(hipMemsetAsync(h.dIt, 0, sizeof(int) * n_loc, h.stream));
-        int rc = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, cost_is_symmetric ? PILOT_OT_EMD_UPPER : PILOT_OT_EMD_ALL, s < m->N ? s : m->N, m->N,
-                                       m->G, h.dLocal, h.dIt, h.stream);
-        if (rc != PILOT_OT_OK) return rc;
+        r = pilot_ot_emd_grid_dev(h.plan, h.dP, h.dM, cost_is_symmetric ? PILOT_OT_EMD_UPPER : PILOT_OT_EMD_ALL, s < m->N ? s : m->N, m->N,
+                                  m->G, h.dLocal, h.dIt, h.stream);
+        if (r != PILOT_OT_OK) return r;
         HIP_TRY(hipEventRecord(h.ev_grid, h.stream));
-    }
+        return PILOT_OT_OK;
+    });
+    if (rc != PILOT_OT_OK) return rc;
     m->ran = true; m->exact = true;
     return multi_gather(m, cost_is_symmetric != 0);
 }
@@ -462,15 +606,43 @@ PILOT_API int pilot_ot_multi_times(pilot_ot_multi *m, float *grid_ms, float *gat
 // ================================================================================================
 // host-buffer convenience: numpy in, numpy out, over several devices (per-thread cached context)
 namespace {
+// One cached context per calling thread, kept in a process-wide registry: pilot_ot_shutdown() releases ALL of them (it must
+// not run concurrently with other calls), and the context of a thread that has exited is released by the next
+// host-buffer call of any thread -- never from a thread-exit or process-exit hook, where the HIP runtime may be gone.
 struct MultiCtx {
     pilot_ot_multi *m = nullptr;
     std::vector<int> devices;
     int gather = 0;
+    bool orphan = false;
 };
-thread_local MultiCtx g_multi;
+std::mutex g_ctx_mutex;
+std::vector<MultiCtx *> g_ctx_all;
+struct CtxOwner {      // thread-exit hook: only marks, no HIP calls
+    MultiCtx *c = nullptr;
+    ~CtxOwner() {
+        if (!c) return;
+        std::lock_guard<std::mutex> l(g_ctx_mutex);
+        c->orphan = true;
+    }
+};
+thread_local CtxOwner g_owner;
 
 int multi_ctx(int N, int K, const int *devices, int n_devices, int gather, pilot_ot_multi **out) {
-    MultiCtx &c = g_multi;
+    if (!g_owner.c) {
+        std::lock_guard<std::mutex> l(g_ctx_mutex);
+        for (size_t i = 0; i < g_ctx_all.size();) {          // contexts of threads that are gone
+            if (g_ctx_all[i]->orphan) {
+                if (g_ctx_all[i]->m) multi_free(g_ctx_all[i]->m);
+                delete g_ctx_all[i];
+                g_ctx_all.erase(g_ctx_all.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+        g_owner.c = new MultiCtx();
+        g_ctx_all.push_back(g_owner.c);
+    }
+    MultiCtx &c = *g_owner.c;
     const bool same = c.m && c.m->N == N && c.m->K == K && c.gather == gather && (int)c.devices.size() == n_devices &&
                       memcmp(c.devices.data(), devices, sizeof(int) * n_devices) == 0;
     if (!same) {
@@ -488,9 +660,13 @@ int multi_ctx(int N, int K, const int *devices, int n_devices, int gather, pilot
 
 namespace pilot {
 void abi_multi_release() {
-    if (g_multi.m) multi_free(g_multi.m);
-    g_multi.m = nullptr;
-    g_multi.devices.clear();
+    std::lock_guard<std::mutex> l(g_ctx_mutex);
+    for (MultiCtx *c : g_ctx_all) {
+        if (c->m) multi_free(c->m);
+        c->m = nullptr;
+        c->devices.clear();
+    }
+    // (the records themselves stay: their owner threads still point at them)
 }
 }  // namespace pilot
 
@@ -499,12 +675,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_multi(const double *P, int N, int K, const 
                                            double f32_floor_ulps, int cost_is_symmetric, const int *devices,
                                            int n_devices, int gather, double *emd, int *iters, double *err, int *flags) {
     if (!P || !M || !emd || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
-    if (precision == PILOT_OT_PREC_AUTO) {          // decide once, on the host, so every shard runs the same kernels
-        double mx = 0.0;
-        for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
-        precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
-        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
-    }
+    // (precision is resolved once for all shards by pilot_ot_multi_sinkhorn, from max(M) of these inputs)
     pilot_ot_multi *m = nullptr;
     int rc = multi_ctx(N, K, devices, n_devices, gather, &m);
     if (rc == PILOT_OT_OK) rc = pilot_ot_multi_set_inputs(m, P, M);
@@ -524,4 +695,143 @@ PILOT_API int pilot_ot_emd_grid_multi(const double *P, int N, int K, const doubl
     if (rc == PILOT_OT_OK) rc = pilot_ot_multi_emd(m, cost_is_symmetric);
     if (rc == PILOT_OT_OK) rc = pilot_ot_multi_fetch(m, emd, n_aug, nullptr, nullptr);
     return rc;
+}
+
+// ================================================================================================
+// cell-level W2 (extension): full N x N grid, rows dealt round-robin over several devices.  Every device
+// holds the whole cohort and solves its rows on its own stream (one host thread per device); the matrix is assembled ON THE
+// DEVICES like the proportion path's: ONE all-gather of the padded row blocks over RCCL (distinct devices) or peer copies
+// into the first device (repeated ids = logical shards), then the row interleave.  Per-pair diagnostics (iters, err) are
+// not part of the matrix and are collected shard by shard.
+PILOT_API int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offsets, int N, int D, double scale, double reg,
+                                          int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
+                                          const int *devices, int n_devices, double *w2, int *iters, double *err) {
+    if (!X || !offsets || !w2 || !devices) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (n_devices < 1 || n_devices > 64) return fail(PILOT_OT_EINVAL, "n_devices=%d out of range", n_devices);
+    if (N <= 0) return fail(PILOT_OT_EINVAL, "N=%d must be positive", N);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    bool distinct = true;
+    for (int s = 0; s < n_devices; ++s) {
+        if (devices[s] < 0 || devices[s] >= n_dev) return fail(PILOT_OT_EINVAL, "device %d not visible (%d devices)", devices[s], n_dev);
+        for (int t = 0; t < s; ++t) distinct = distinct && devices[t] != devices[s];
+    }
+    const bool rccl = distinct && n_devices > 1;
+    if (rccl) { const int rc = rccl_load(); if (rc != PILOT_OT_OK) return rc; }
+    const int G = n_devices, n_pad = (N + G - 1) / G;
+    const size_t n_loc = (size_t)n_pad * N;
+    struct CS {
+        pilot_ot_cell_cohort *co = nullptr;
+        double *dLocal = nullptr, *dStage = nullptr, *dFull = nullptr, *dW = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev = nullptr;
+        ncclComm_t comm = nullptr;
+        size_t n_out = 0;
+        int rc = PILOT_OT_OK;
+        std::string msg;
+    };
+    std::vector<CS> cs(G);
+    DeviceGuard guard;
+    // per device, concurrently: cohort (H2D of all cells), row shard enqueued, rows copied into the padded block
+    auto shard_job = [&](int s) {
+        CS &c = cs[s];
+        auto body = [&]() -> int {
+            HIP_TRY(hipSetDevice(devices[s]));
+            int rc = pilot_ot_cell_cohort_create(X, offsets, N, D, &c.co);
+            if (rc != PILOT_OT_OK) return rc;
+            rc = pilot::cell_enqueue_rows(c.co, scale, reg, num_iter_max, stop_thr, check_period, f32_floor_ulps, s < N ? s : N, N, G, &c.n_out);
+            if (rc != PILOT_OT_OK) return rc;
+            pilot::cell_buffers(c.co, &c.dW, &c.stream);
+            HIP_TRY(hipMalloc(&c.dLocal, sizeof(double) * n_loc));
+            if (rccl || s == 0) {
+                HIP_TRY(hipMalloc(&c.dStage, sizeof(double) * n_loc * G));
+                HIP_TRY(hipMalloc(&c.dFull, sizeof(double) * (size_t)N * N));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+            HIP_TRY(hipMemsetAsync(c.dLocal, 0, sizeof(double) * n_loc, c.stream));
+            if (c.n_out) HIP_TRY(hipMemcpyAsync(c.dLocal, c.dW, sizeof(double) * c.n_out, hipMemcpyDeviceToDevice, c.stream));
+            HIP_TRY(hipEventRecord(c.ev, c.stream));
+            return PILOT_OT_OK;
+        };
+        c.rc = body();
+        if (c.rc != PILOT_OT_OK) c.msg = pilot_ot_last_error();
+    };
+    {
+        std::vector<std::thread> th;
+        for (int s = 1; s < G; ++s) th.emplace_back(shard_job, s);
+        shard_job(0);
+        for (auto &t : th) t.join();
+    }
+    int rc = PILOT_OT_OK;
+    for (int s = 0; s < G && rc == PILOT_OT_OK; ++s)
+        if (cs[s].rc != PILOT_OT_OK) rc = fail(cs[s].rc, "%s", cs[s].msg.c_str());
+    auto gather = [&]() -> int {
+        if (rccl) {
+            std::vector<ncclComm_t> comms(G, nullptr);
+            ncclResult_t r;
+            {
+                StdoutToStderr quiet;
+                r = g_rccl.CommInitAll(comms.data(), G, devices);
+            }
+            if (r != ncclSuccess) return fail(PILOT_OT_ERCCL, "ncclCommInitAll over %d devices: %s", G, g_rccl.GetErrorString(r));
+            for (int s = 0; s < G; ++s) cs[s].comm = comms[s];
+            RCCL_TRY(g_rccl.GroupStart());
+            for (int s = 0; s < G; ++s) {
+                ncclResult_t a = g_rccl.AllGather(cs[s].dLocal, cs[s].dStage, n_loc, ncclDouble, cs[s].comm, cs[s].stream);
+                if (a != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(PILOT_OT_ERCCL, "ncclAllGather: %s", g_rccl.GetErrorString(a)); }
+            }
+            RCCL_TRY(g_rccl.GroupEnd());
+            for (int s = 0; s < G; ++s) {
+                HIP_TRY(hipSetDevice(devices[s]));
+                const int ir = launch_interleave(cs[s].dStage, G, n_pad, N, cs[s].dFull, cs[s].stream);
+                if (ir != PILOT_OT_OK) return ir;
+            }
+        } else {
+            HIP_TRY(hipSetDevice(devices[0]));
+            for (int s = 1; s < G; ++s) HIP_TRY(hipStreamWaitEvent(cs[0].stream, cs[s].ev, 0));
+            for (int s = 0; s < G; ++s) {
+                if (devices[s] == devices[0])
+                    HIP_TRY(hipMemcpyAsync(cs[0].dStage + s * n_loc, cs[s].dLocal, sizeof(double) * n_loc, hipMemcpyDeviceToDevice, cs[0].stream));
+                else
+                    HIP_TRY(hipMemcpyPeerAsync(cs[0].dStage + s * n_loc, devices[0], cs[s].dLocal, devices[s], sizeof(double) * n_loc, cs[0].stream));
+            }
+            const int ir = launch_interleave(cs[0].dStage, G, n_pad, N, cs[0].dFull, cs[0].stream);
+            if (ir != PILOT_OT_OK) return ir;
+        }
+        for (int s = 0; s < G; ++s) {
+            HIP_TRY(hipSetDevice(devices[s]));
+            HIP_TRY(hipStreamSynchronize(cs[s].stream));
+        }
+        HIP_TRY(hipSetDevice(devices[0]));
+        HIP_TRY(hipMemcpy(w2, cs[0].dFull, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost));
+        if (iters || err) {
+            std::vector<int> ti;
+            std::vector<double> te;
+            for (int s = 0; s < G; ++s) {
+                HIP_TRY(hipSetDevice(devices[s]));
+                ti.resize(cs[s].n_out); te.resize(cs[s].n_out);
+                const int cr = pilot::cell_collect(cs[s].co, cs[s].n_out, nullptr, iters ? ti.data() : nullptr, err ? te.data() : nullptr, nullptr);
+                if (cr != PILOT_OT_OK) return cr;
+                for (size_t t = 0; t < cs[s].n_out / (size_t)N; ++t) {
+                    const size_t row = (size_t)s + t * G;
+                    if (iters) memcpy(iters + row * N, ti.data() + t * N, sizeof(int) * N);
+                    if (err) memcpy(err + row * N, te.data() + t * N, sizeof(double) * N);
+                }
+            }
+        }
+        return PILOT_OT_OK;
+    };
+    if (rc == PILOT_OT_OK) rc = gather();
+    std::string keep = rc != PILOT_OT_OK ? pilot_ot_last_error() : "";
+    for (int s = 0; s < G; ++s) {
+        CS &c = cs[s];
+        (void)hipSetDevice(devices[s]);
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        if (c.comm) (void)g_rccl.CommDestroy(c.comm);
+        for (void *p : {(void *)c.dLocal, (void *)c.dStage, (void *)c.dFull}) if (p) (void)hipFree(p);
+        if (c.ev) (void)hipEventDestroy(c.ev);
+        if (c.co) pilot_ot_cell_cohort_destroy(c.co);
+    }
+    if (rc != PILOT_OT_OK) return fail(rc, "%s", keep.c_str());
+    return PILOT_OT_OK;
 }

@@ -59,11 +59,9 @@ class MultiPlan:
     def sinkhorn(self, reg, precision="auto", num_iter_max=NUM_ITER_MAX, stop_thr=STOP_THR, tau=TAU,
                  check_period=CHECK_PERIOD, f32_floor_ulps=0.0):
         """Enqueue shard grids + the gather on every device (asynchronous)."""
+        # (the library resolves "auto" -- and the max(M)/reg > 600 fallback -- once for all shards from the max(M) it recorded
+        # in pilot_ot_multi_set_inputs, exactly like the single-device host entry point)
         prec = _lib.PREC[precision]
-        if prec == 0:       # decide once so that every shard runs the same kernels
-            prec = self.L.pilot_ot_auto_precision_for(self.max_cost / float(reg), self.K, self.sym)
-            if prec == 2:
-                prec = 4        # PILOT_OT_PREC_AUTO_MIXED: f32 first, f64 for the pairs that need it
         _lib.check(self.L.pilot_ot_multi_sinkhorn(self.h, float(reg), int(num_iter_max), float(stop_thr), float(tau),
                                                   int(check_period), prec, float(f32_floor_ulps), self.sym))
 
@@ -83,6 +81,13 @@ class MultiPlan:
         flags = np.zeros((self.N, self.N), dtype=np.int32)
         _lib.check(self.L.pilot_ot_multi_fetch(self.h, _lib.dptr(E), _lib.iptr(iters), _lib.dptr(err), _lib.iptr(flags)))
         return E, dict(iters=iters, err=err, flags=flags)
+
+    def rccl_info(self):
+        """(n_ranks, rank) per shard as RCCL reports them (ncclCommCount / ncclCommUserRank); (0, -1) with the peer-copy gather."""
+        n = np.zeros(self.G, dtype=np.int32)
+        r = np.zeros(self.G, dtype=np.int32)
+        _lib.check(self.L.pilot_ot_multi_rccl_info(self.h, _lib.iptr(n), _lib.iptr(r)))
+        return [int(x) for x in n], [int(x) for x in r]
 
     def times_ms(self):
         """(per-shard kernel ms, gather ms) of the last call (HIP events on the shards' streams)."""
@@ -151,9 +156,31 @@ def emd_grid_multi(P, M, devices=None, n_devices=None, gather="auto", return_inf
 
 
 # ---- one process per device ---------------------------------------------------------------------------------------------
+def _process_start_ticks(pid):
+    """Start time of a process in clock ticks since boot (/proc/<pid>/stat field 22); 0 when unavailable."""
+    try:
+        with open("/proc/%d/stat" % pid, "rb") as fh:
+            return int(fh.read().rsplit(b")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
 def rendezvous_key():
-    """Name shared by the ranks of ONE launch on this node: the launcher is the common parent of all ranks."""
-    return "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    """Name shared by the ranks of ONE launch on this node: the launcher is the common parent of all ranks.  Its pid AND its
+    start time are part of the name, so a file left behind by a crashed launch whose pid was reused can never match."""
+    ppid = os.getppid()
+    return "%s_%s_%d_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), ppid,
+                            _process_start_ticks(ppid))
+
+
+def rendezvous_dir():
+    """A directory only this user can write to (0700, owned by us) under the temp directory."""
+    d = os.path.join(tempfile.gettempdir(), "pilot_ot_%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError("rendezvous directory %s is not private to uid %d" % (d, os.getuid()))
+    return d
 
 
 def exchange_unique_id(rank, world, make_id, key=None, timeout=300.0, directory=None):
@@ -161,10 +188,12 @@ def exchange_unique_id(rank, world, make_id, key=None, timeout=300.0, directory=
 
     Single-node rendezvous through an atomically renamed file in the temp directory -- the launcher only has to start
     the processes (RANK / WORLD_SIZE in the environment); no torch, no MPI, no TCP store."""
-    directory = directory or tempfile.gettempdir()
+    directory = directory or rendezvous_dir()
     path = os.path.join(directory, "pilot_ot_uid_" + (key or rendezvous_key()))
     if rank == 0:
         uid = bytes(make_id())
+        if len(uid) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique id of %d bytes (expected %d)" % (len(uid), _lib.UNIQUE_ID_BYTES))
         tmp = "%s.%d.tmp" % (path, os.getpid())
         with open(tmp, "wb") as fh:
             fh.write(uid)
@@ -175,7 +204,7 @@ def exchange_unique_id(rank, world, make_id, key=None, timeout=300.0, directory=
         try:
             with open(path, "rb") as fh:
                 uid = fh.read()
-            if len(uid) > 0:
+            if len(uid) == _lib.UNIQUE_ID_BYTES:       # (written atomically by rename: anything else is not ours)
                 return uid, path
         except OSError:
             pass
@@ -207,6 +236,12 @@ class Comm:
                 os.unlink(path)
             except OSError:
                 pass
+
+    def info(self):
+        """(n_ranks, rank) as RCCL itself reports them for this communicator."""
+        n, r = ctypes.c_int(0), ctypes.c_int(-1)
+        _lib.check(self.L.pilot_ot_comm_info(self.h, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
 
     def all_gather_rows(self, d_local, n_pad, N, d_stage, d_full, stream=None):
         _lib.check(self.L.pilot_ot_comm_all_gather_rows(self.h, d_local, int(n_pad), int(N), d_stage, d_full,

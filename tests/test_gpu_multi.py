@@ -133,3 +133,64 @@ def test_more_shards_than_patients():
     for G in (4, 8):
         np.testing.assert_array_equal(multi.sinkhorn_grid_multi(P, M, 0.1, devices=[0] * G), ref)
         np.testing.assert_array_equal(multi.emd_grid_multi(P, M, devices=[0] * G), engine.emd_grid(P, M))
+
+
+def test_unnormalised_cost_takes_the_same_kernels_on_one_and_on_several_devices():
+    """the device entry point assumes cost / max; the multi-device forms must take the single-device host entry
+    point's decisions from max(M) of the inputs -- max(M)/reg = 1000 runs the POT-literal kernel in both, whatever precision
+    was asked for, and an explicit f16x2 outside its range becomes bf16x3 in both."""
+    P, M = make_problem(12, 8, 4, seed=5, cells_per_patient=300)
+    for scale, reg, prec in ((5.0, 0.005, "auto"), (5.0, 0.005, "fp64"), (5.0, 0.2, "f16x2"), (3.0, 0.1, "auto")):
+        ref, ri = engine.sinkhorn_grid(P, scale * M, reg, precision=prec, return_info=True)
+        got, gi = multi.sinkhorn_grid_multi(P, scale * M, reg, devices=[0, 0, 0], precision=prec, return_info=True)
+        np.testing.assert_array_equal(got, ref)
+        np.testing.assert_array_equal(gi["iters"], ri["iters"])
+        np.testing.assert_array_equal(gi["flags"], ri["flags"])
+        assert np.isfinite(ref).all()
+        mp = multi.MultiPlan(P, scale * M, devices=[0, 0])
+        mp.sinkhorn(reg, precision=prec)
+        np.testing.assert_array_equal(mp.fetch(), ref)
+        mp.close()
+
+
+def test_shard_threads_serial_switch_and_back_to_back_calls(monkeypatch):
+    """Every shard is enqueued by its own host thread; PILOT_OT_MULTI_SERIAL=1 enqueues from the calling thread instead.
+    Same bits either way, and back-to-back asynchronous calls with the peer-copy gather (the next call's kernels must wait
+    for shard 0's copies of the previous rows) leave the right matrix after every call."""
+    P, M = make_problem(**CONFIGS["c2"])
+    ref1 = engine.sinkhorn_grid(P, M, 0.1)
+    ref2 = engine.sinkhorn_grid(P, M, 0.5)
+    for serial in ("0", "1"):
+        monkeypatch.setenv("PILOT_OT_MULTI_SERIAL", serial)
+        mp = multi.MultiPlan(P, M, devices=[0] * 5)
+        for _ in range(6):
+            mp.sinkhorn(0.5)
+            mp.sinkhorn(0.1)
+        np.testing.assert_array_equal(mp.fetch(), ref1)
+        mp.sinkhorn(0.5)
+        np.testing.assert_array_equal(mp.fetch(), ref2)
+        mp.emd()
+        np.testing.assert_array_equal(mp.fetch(), engine.emd_grid(P, M))
+        mp.close()
+
+
+def test_rccl_reports_its_rank_count():
+    """ncclCommCount / ncclCommUserRank are echoed so that a bench record can prove how many ranks RCCL saw."""
+    P, M = make_problem(**CONFIGS["c1"])
+    mp = multi.MultiPlan(P, M, devices=[0], gather="rccl")
+    assert mp.rccl_info() == ([1], [0])
+    mp.close()
+    mp = multi.MultiPlan(P, M, devices=[0, 0], gather="copy")
+    assert mp.rccl_info() == ([0, 0], [-1, -1])
+    mp.close()
+    comm = multi.Comm(0, 1, key="pytest_info_%d" % os.getpid())
+    assert comm.info() == (1, 0)
+    comm.close()
+
+
+def test_errors_on_a_shard_thread_reach_the_caller():
+    P, M = make_problem(**CONFIGS["c1"])
+    mp = multi.MultiPlan(P, M, devices=[0, 0])
+    with pytest.raises(ValueError, match="tau"):
+        mp.sinkhorn(0.1, tau=0.5)
+    mp.close()
