@@ -469,24 +469,32 @@ __device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel
         }
 }
 // one 16-row output tile of X * panel; `form` = the [part][k-block][out tile][lane] x 16-byte image of X (LDS or global)
-template <class C, int RT>
+// TP: pieces that take part (default: all).  TP = 2 of a 3-piece bf16 image = the leading 16 bits of both operands, three
+// piece products -- what the band-1 products use (below).
+template <class C, int RT, int TP = C::NP>
 __device__ inline typename C::acc_t split_tile_product(const typename C::T *form, int lane, int t, const SplitPanel<RT, C::NP> &B,
                                                        typename C::acc_t acc) {
     constexpr int KB = split_kblocks(RT), NP = C::NP;
     const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        u32x4_t a[NP];
+        u32x4_t a[TP];
 #pragma unroll
-        for (int part = 0; part < NP; ++part) a[part] = img[((part * KB + kb) * RT + t) * WAVE + lane];
+        for (int part = 0; part < TP; ++part) a[part] = img[((part * KB + kb) * RT + t) * WAVE + lane];
 #pragma unroll
-        for (int i = 0; i < n_terms<NP>(); ++i) acc = mfma_pieces<C>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], acc);
+        for (int i = 0; i < n_terms<TP>(); ++i) acc = mfma_pieces<C>(a[term_a<TP>(i)], B.p[term_b<TP>(i)][kb], acc);
     }
     return acc;
 }
 // OUT = X_form * IN for the whole panel.  The operand pieces of step (t, kb + 1) are requested from LDS before the
 // MFMAs of step (t, kb) are issued, so a wave never sits on an LDS round trip between MFMA groups.
 // form1 (nullable, wave-uniform): the band-1 image of the same operand; OUT = X0 * IN + 2^-128 (X1 * IN).
+// Band 1 holds the Gibbs entries below 2^-110: what they contribute to a product is a small part of it (the plans of the
+// 600 x 50 benchmark at reg 0.01 put 1e-8 .. 1e-2 of their mass there), so the band-1 partial product is taken from the
+// leading TWO bf16 pieces of both operands (16 bits, three piece products instead of six): the dropped
+// piece of the stationary operand is a fixed relative perturbation <= 2^-16 of those entries -- a cost change of
+// reg * 2^-16 on entries that carry <= 1e-2 of the mass -- and the panel's is rounding noise of the same size on that part
+// (c3 at reg 0.01: 37.8 -> 32.0 ms per matrix, max distance to the fp64 oracle on 12 000 pairs 1.5e-7 -> 4.4e-7).
 template <class C, int RT, bool LIVE1 = false>
 __device__ inline void panel_product_split(const typename C::T *form, const typename C::T *form1, int lane,
                                            const typename C::acc_t (&IN)[RT], typename C::acc_t (&OUT)[RT],
@@ -528,7 +536,7 @@ __device__ inline void panel_product_split(const typename C::T *form, const type
             typename C::acc_t zero;
 #pragma unroll
             for (int r = 0; r < 4; ++r) zero[r] = 0.f;
-            const typename C::acc_t lo = split_tile_product<C, RT>(form1, lane, t, B, zero);
+            const typename C::acc_t lo = split_tile_product<C, RT, 2>(form1, lane, t, B, zero);
 #pragma unroll
             for (int r = 0; r < 4; ++r) OUT[t][r] = fmaf(lo[r], BAND1_DOWN, OUT[t][r]);
         }
