@@ -95,6 +95,7 @@ int pilot_ot_version(void);
 const char *pilot_ot_last_error(void);
 int pilot_ot_device_count(int *count);            /* number of visible HIP devices (0 is not an error) */
 int pilot_ot_set_device(int device);              /* device used by the calling thread's later calls   */
+int pilot_ot_get_device(int *device);             /* the calling thread's current device (a new host thread starts on device 0) */
 int pilot_ot_device_name(char *buf, int buflen);  /* gcnArchName of the current device                 */
 int pilot_ot_shutdown(void);                      /* free the calling thread's cached host-API workspace */
 
@@ -112,6 +113,10 @@ int pilot_ot_stream_sync(void *stream);
  * P: N x K fp64, bit-identical to the reference's dict values (every fp64 operation in the same order). */
 int pilot_ot_proportions(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
                          int N, int K, double regulizer, int normalization, double *P);
+/* first_row (nullable, N entries): additionally the smallest row number of every sample (-1: no row), i.e. the row whose
+ * status return_real_labels reports (Trajectory.py:617-642) -- one more atomic in the same pass over the codes. */
+int pilot_ot_proportions_ex(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
+                            int N, int K, double regulizer, int normalization, double *P, long long *first_row);
 /* Per-cell-type column-wise median of the n_cells x D embedding X (Trajectory.py:465-466), exact.
  * dtype: 0 = float32, 1 = float64 (the median of an even count is averaged in that dtype, like
  * numpy/pandas, then widened).  centroids: K x D fp64; a cell type without cells yields NaN. */
@@ -119,6 +124,13 @@ int pilot_ot_proportions(const int *cell_code, const int *sample_code, long long
 #define PILOT_OT_F64 1
 int pilot_ot_centroid_medians(const void *X, int dtype, long long n_cells, int D, const int *cell_code, int K,
                               double *centroids);
+/* The same with the embedding already resident: pilot_ot_embedding_upload copies the C x D array to the current device
+ * (synchronously -- call it from a helper thread to overlap the transfer with host work on the label columns, which is
+ * what pilot_amd.tl does); _medians_dev then only moves the codes. */
+typedef struct pilot_ot_embedding pilot_ot_embedding;
+int pilot_ot_embedding_upload(const void *X, int dtype, long long n_cells, int D, pilot_ot_embedding **emb);
+int pilot_ot_embedding_destroy(pilot_ot_embedding *emb);
+int pilot_ot_centroid_medians_dev(pilot_ot_embedding *emb, const int *cell_code, int K, double *centroids);
 
 /* ---- cost matrix: replaces scipy pdist+squareform at Trajectory.py:468-469 ------------------ */
 /* centroids: K x D row-major (per-cell-type medians, Trajectory.py:465-466).  cost: K x K,
@@ -289,10 +301,15 @@ int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offsets, int N,
                                 int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
                                 const int *devices, int n_devices, double *w2, int *iters, double *err);
 
-/* precision selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (PILOT_OT_PREC_BF16X3 or PILOT_OT_PREC_F64; a shape whose
- * split operand image does not fit LDS runs PILOT_OT_PREC_F32 instead) */
+/* precision selected by PILOT_OT_PREC_AUTO for a given max(M)/reg (PILOT_OT_PREC_F16X2, PILOT_OT_PREC_BF16X3 or
+ * PILOT_OT_PREC_F64; a shape whose split operand image does not fit LDS runs PILOT_OT_PREC_F32 instead) */
 int pilot_ot_auto_precision(double max_cost_over_reg);
 int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int cost_is_symmetric);   /* with the LDS fit of this K */
+/* the precision a call with these arguments RUNS (every Sinkhorn entry point goes through it): GENERIC beyond
+ * PILOT_OT_MAX_COST_OVER_REG; AUTO by range; an explicit f32-class precision (F32, BF16X3, F16X2) beyond the f32 range
+ * (max(M)/reg > 60) runs AUTO_MIXED -- explicit precisions are honoured inside their valid range only; F16X2 outside its
+ * scaled domain (max(M)/reg > 11.5 or tau > 2000) runs BF16X3. */
+int pilot_ot_resolve_precision(int precision, double max_cost_over_reg, int K, int cost_is_symmetric, double tau);
 
 #ifdef __cplusplus
 }

@@ -23,13 +23,14 @@ FLAG_CONVERGED, FLAG_NAN, FLAG_ABSORB_LAST, FLAG_ABSORBED, FLAG_F64 = 1, 2, 4, 8
 
 # every symbol include/pilot_ot.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "pilot_ot_version", "pilot_ot_last_error", "pilot_ot_device_count", "pilot_ot_set_device",
+    "pilot_ot_version", "pilot_ot_last_error", "pilot_ot_device_count", "pilot_ot_set_device", "pilot_ot_get_device",
     "pilot_ot_device_name", "pilot_ot_dev_alloc", "pilot_ot_dev_free", "pilot_ot_memcpy_h2d",
     "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
     "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
-    "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
+    "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_resolve_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_plan_enable_graph", "pilot_ot_shutdown",
-    "pilot_ot_proportions", "pilot_ot_centroid_medians", "pilot_ot_cell_w2_grid",
+    "pilot_ot_proportions", "pilot_ot_proportions_ex", "pilot_ot_centroid_medians", "pilot_ot_embedding_upload",
+    "pilot_ot_embedding_destroy", "pilot_ot_centroid_medians_dev", "pilot_ot_cell_w2_grid",
     "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
     "pilot_ot_mirror_upper_dev",
     "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
@@ -66,6 +67,7 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_last_error.restype = ctypes.c_char_p
     L.pilot_ot_device_count.argtypes = [ip]
     L.pilot_ot_set_device.argtypes = [c_int]
+    L.pilot_ot_get_device.argtypes = [ip]
     L.pilot_ot_device_name.argtypes = [ctypes.c_char_p, c_int]
     L.pilot_ot_dev_alloc.argtypes = [ctypes.POINTER(c_vp), ctypes.c_ulonglong]
     L.pilot_ot_dev_free.argtypes = [c_vp]
@@ -82,12 +84,18 @@ def load() -> ctypes.CDLL:
                                              c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.pilot_ot_auto_precision.argtypes = [c_dbl]
     L.pilot_ot_auto_precision_for.argtypes = [c_dbl, c_int, c_int]
+    L.pilot_ot_resolve_precision.argtypes = [c_int, c_dbl, c_int, c_int, c_dbl]
     L.pilot_ot_plan_enable_timing.argtypes = [c_vp, c_int]
     L.pilot_ot_plan_enable_graph.argtypes = [c_vp, c_int]
     L.pilot_ot_plan_kernel_times.argtypes = [c_vp, c_int, ctypes.POINTER(ctypes.c_float),
                                              ctypes.POINTER(ctypes.c_float), ip]
     L.pilot_ot_proportions.argtypes = [ip, ip, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int, c_dbl, c_int, dp]
     L.pilot_ot_centroid_medians.argtypes = [c_vp, c_int, ctypes.c_longlong, c_int, ip, c_int, dp]
+    L.pilot_ot_proportions_ex.argtypes = [ip, ip, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int, c_dbl, c_int, dp,
+                                          ctypes.POINTER(ctypes.c_longlong)]
+    L.pilot_ot_embedding_upload.argtypes = [c_vp, c_int, ctypes.c_longlong, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_embedding_destroy.argtypes = [c_vp]
+    L.pilot_ot_centroid_medians_dev.argtypes = [c_vp, ip, c_int, dp]
     L.pilot_ot_cell_w2_grid.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, c_int, c_int, c_int,
                                         dp, ip, dp]
     L.pilot_ot_cell_cohort_create.argtypes = [c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]

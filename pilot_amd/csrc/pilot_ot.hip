@@ -217,6 +217,12 @@ PILOT_API int pilot_ot_device_count(int *count) {
     return PILOT_OT_OK;
 }
 
+PILOT_API int pilot_ot_get_device(int *device) {
+    if (!device) return fail(PILOT_OT_EINVAL, "device is NULL");
+    HIP_TRY(hipGetDevice(device));
+    return PILOT_OT_OK;
+}
+
 PILOT_API int pilot_ot_set_device(int device) {
     HIP_TRY(hipSetDevice(device));
     return PILOT_OT_OK;
@@ -305,6 +311,28 @@ PILOT_API int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int c
     int prec = pilot_ot_auto_precision(max_cost_over_reg);
     if ((prec == PILOT_OT_PREC_BF16X3 || prec == PILOT_OT_PREC_F16X2) && !split_fits_lds(K, cost_is_symmetric != 0, 1)) prec = PILOT_OT_PREC_F32;
     return prec;
+}
+
+// The one place where a requested precision becomes the precision a call runs (host, multi-device and device entry points):
+//  * exp(-max(M)/reg) outside the f64 range, or on request -> POT-literal kernel;
+//  * AUTO -> F16X2 / BF16X3 by range (F32 where the split images do not fit LDS), AUTO_MIXED beyond the f32 range;
+//  * an explicit f32-class precision beyond the f32 range (max(M)/reg > 60) would be off by up to 1e-4 on this path's
+//    distributions: it runs AUTO_MIXED as well -- explicit precisions are honoured inside their valid range only;
+//  * F16X2 outside its scaled domain (cost range, tau) -> BF16X3.
+PILOT_API int pilot_ot_resolve_precision(int precision, double max_cost_over_reg, int K, int cost_is_symmetric, double tau) {
+    if (precision == PILOT_OT_PREC_GENERIC || max_cost_over_reg > PILOT_OT_MAX_COST_OVER_REG) return PILOT_OT_PREC_GENERIC;
+    const bool f32_class = precision == PILOT_OT_PREC_F32 || precision == PILOT_OT_PREC_BF16X3 || precision == PILOT_OT_PREC_F16X2;
+    // (PILOT_OT_RAW_PRECISION=1, tests only: run an explicit f32-class precision outside its range as asked)
+    const char *raw = getenv("PILOT_OT_RAW_PRECISION");
+    const bool promote = f32_class && max_cost_over_reg > 60.0 && !(raw && *raw && *raw != '0');
+    if (precision == PILOT_OT_PREC_AUTO || promote) {
+        precision = pilot_ot_auto_precision_for(max_cost_over_reg, K, cost_is_symmetric);
+        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
+    }
+    if (precision == PILOT_OT_PREC_F16X2 &&
+        (max_cost_over_reg > pilot::H_MAX_COST_OVER_REG || tau > pilot::H_MAX_TAU || !split_fits_lds(K, cost_is_symmetric != 0, 1)))
+        precision = split_fits_lds(K, cost_is_symmetric != 0, 1) ? PILOT_OT_PREC_BF16X3 : PILOT_OT_PREC_F32;
+    return precision;
 }
 
 PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
@@ -687,20 +715,15 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
             return run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows_g, row_step, d_emd,
                                d_iters, d_err, d_flags, static_cast<hipStream_t>(stream));
     }
+    // (M is /max, Trajectory.py:101: the range is judged by 1/reg here; host callers have resolved with the true max(M) already)
+    precision = pilot_ot_resolve_precision(precision, 1.0 / reg, pl->K, cost_is_symmetric, tau);
     bool mixed = false;
-    if (precision == PILOT_OT_PREC_AUTO) {
-        precision = pilot_ot_auto_precision_for(1.0 / reg, pl->K, cost_is_symmetric);  // M is /max (Trajectory.py:101)
-        mixed = precision == PILOT_OT_PREC_F64;
-    } else if (precision == PILOT_OT_PREC_AUTO_MIXED) {       // (what the host entry point passes after looking at max(M))
+    if (precision == PILOT_OT_PREC_AUTO_MIXED) {
         precision = PILOT_OT_PREC_F64;
         mixed = true;
     }
     // beyond the f32 range AUTO still tries f32 first, pair by pair, where the split images fit and POT's defaults hold
     mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && 1.0 / reg <= 140.0 && !getenv("PILOT_OT_NO_MIXED");
-    // the fp16-split kernel works in a fixed scaled domain: outside it (cost range, hand-over threshold, LDS) the bf16 split takes over
-    if (precision == PILOT_OT_PREC_F16X2 &&
-        (1.0 / reg > pilot::H_MAX_COST_OVER_REG || tau > pilot::H_MAX_TAU || !split_fits_lds(pl->K, cost_is_symmetric != 0, 1)))
-        precision = PILOT_OT_PREC_BF16X3;
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -871,13 +894,7 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     if (rc != PILOT_OT_OK) return rc;
     double mx = 0.0;
     for (size_t t = 0; t < (size_t)K * K; ++t) mx = M[t] > mx ? M[t] : mx;
-    if (mx / reg > MAX_COST_OVER_REG) precision = PILOT_OT_PREC_GENERIC;     // exp(-M/reg) would leave the f64 range
-    if (precision == PILOT_OT_PREC_AUTO) {
-        precision = pilot_ot_auto_precision_for(mx / reg, K, cost_is_symmetric);
-        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
-    }
-    // (the device entry point judges the range by 1/reg: here max(M) is known)
-    if (precision == PILOT_OT_PREC_F16X2 && pilot_ot_auto_precision(mx / reg) != PILOT_OT_PREC_F16X2) precision = PILOT_OT_PREC_BF16X3;
+    precision = pilot_ot_resolve_precision(precision, mx / reg, K, cost_is_symmetric, tau);     // (max(M) is known here)
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     const size_t n_out = (size_t)n_rows * N;
     if (n_out == 0) return PILOT_OT_OK;
@@ -1027,14 +1044,22 @@ int current_cu_count() {
 
 PILOT_API int pilot_ot_proportions(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
                                    int N, int K, double regulizer, int normalization, double *P) {
+    return pilot_ot_proportions_ex(cell_code, sample_code, n_cells, n_total, N, K, regulizer, normalization, P, nullptr);
+}
+
+PILOT_API int pilot_ot_proportions_ex(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
+                                      int N, int K, double regulizer, int normalization, double *P, long long *first_row) {
     if (!cell_code || !sample_code || !P) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (first_row && n_cells > 0xfffffffeLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", n_cells);
     if (N <= 0 || K <= 0 || n_cells < 0 || n_total < 2)
         return fail(PILOT_OT_EINVAL, "N=%d K=%d n_cells=%lld n_total=%lld out of range", N, K, n_cells, n_total);
     if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
-    DevBuf dc, ds, dcnt, dP;
+    DevBuf dc, ds, dcnt, dP, dfirst;
     hipError_t e = dc.alloc(sizeof(int) * (size_t)n_cells);
     if (e == hipSuccess) e = ds.alloc(sizeof(int) * (size_t)n_cells);
     if (e == hipSuccess) e = dcnt.alloc(sizeof(unsigned int) * (size_t)N * K);
+    if (e == hipSuccess && first_row) e = dfirst.alloc(sizeof(unsigned int) * (size_t)N);
+    if (e == hipSuccess && first_row) e = hipMemset(dfirst.p, 0xff, sizeof(unsigned int) * (size_t)N);
     if (e == hipSuccess) e = dP.alloc(sizeof(double) * (size_t)N * K);
     if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ds.p, sample_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
@@ -1042,23 +1067,60 @@ PILOT_API int pilot_ot_proportions(const int *cell_code, const int *sample_code,
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
     const int n_cu = current_cu_count();
     hipLaunchKernelGGL(pilot::count_kernel, dim3(grid_for(n_cells, 256, n_cu)), dim3(256), 0, nullptr, dc.as<int>(),
-                       ds.as<int>(), (long)n_cells, K, dcnt.as<unsigned int>());
+                       ds.as<int>(), (long)n_cells, K, dcnt.as<unsigned int>(), first_row ? dfirst.as<unsigned int>() : nullptr);
     hipLaunchKernelGGL(pilot::proportions_kernel, dim3(1), dim3(256), sizeof(double) * (K + 1), nullptr,
                        dcnt.as<unsigned int>(), N, K, (long)n_total, regulizer, normalization, dP.as<double>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(P, dP.p, sizeof(double) * (size_t)N * K, hipMemcpyDeviceToHost));
+    if (first_row) {
+        std::vector<unsigned int> fr((size_t)N);
+        HIP_TRY(hipMemcpy(fr.data(), dfirst.p, sizeof(unsigned int) * (size_t)N, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) first_row[n] = fr[(size_t)n] == 0xffffffffu ? -1 : (long long)fr[(size_t)n];
+    }
+    return PILOT_OT_OK;
+}
+
+// the embedding resident on the device: uploaded once (from a helper thread of the host language, beside its own work on
+// the label columns), read by pilot_ot_centroid_medians_dev
+struct pilot_ot_embedding {
+    void *dX = nullptr;
+    int dtype = 0, D = 0, device = 0;
+    long long C = 0;
+};
+
+PILOT_API int pilot_ot_embedding_upload(const void *X, int dtype, long long n_cells, int D, pilot_ot_embedding **emb) {
+    if (!X || !emb) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (n_cells <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "n_cells=%lld D=%d must be positive", n_cells, D);
+    if (dtype != PILOT_OT_F32 && dtype != PILOT_OT_F64) return fail(PILOT_OT_EINVAL, "unknown dtype id %d", dtype);
+    pilot_ot_embedding *e = new (std::nothrow) pilot_ot_embedding();
+    if (!e) return fail(PILOT_OT_EINVAL, "out of host memory");
+    e->dtype = dtype; e->D = D; e->C = n_cells;
+    const size_t bytes = (size_t)n_cells * D * (dtype == PILOT_OT_F32 ? 4 : 8);
+    hipError_t he = hipGetDevice(&e->device);
+    if (he == hipSuccess) he = hipMalloc(&e->dX, bytes);
+    if (he == hipSuccess) he = hipMemcpy(e->dX, X, bytes, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { pilot_ot_embedding_destroy(e); return fail(PILOT_OT_EHIP, "embedding upload failed: %s", hipGetErrorString(he)); }
+    *emb = e;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_embedding_destroy(pilot_ot_embedding *e) {
+    if (!e) return PILOT_OT_OK;
+    if (e->dX) (void)hipFree(e->dX);
+    delete e;
     return PILOT_OT_OK;
 }
 
 namespace {
+// dXdev (nullable): the embedding already on the device; else X is copied in
 template <typename T>
-int centroid_medians_impl(const void *X, long long C, int D, const int *cell_code, int K, double *centroids) {
+int centroid_medians_impl(const void *X, const void *dXdev, long long C, int D, const int *cell_code, int K, double *centroids) {
     using U = typename pilot::OrderedKey<T>::U;
     using State = pilot::SelectState<U>;
     const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;      // dimensions per histogram launch
     const size_t lds = sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
     DevBuf dX, dc, dn, doffs, dcur, dperm, dst, dh, dout;
-    hipError_t e = dX.alloc(sizeof(T) * (size_t)C * D);
+    hipError_t e = dXdev ? hipSuccess : dX.alloc(sizeof(T) * (size_t)C * D);
     if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
     if (e == hipSuccess) e = dn.alloc(sizeof(unsigned int) * K);
     if (e == hipSuccess) e = doffs.alloc(sizeof(unsigned int) * (K + 1));
@@ -1067,7 +1129,8 @@ int centroid_medians_impl(const void *X, long long C, int D, const int *cell_cod
     if (e == hipSuccess) e = dst.alloc(sizeof(State) * (size_t)K * D * 2);
     if (e == hipSuccess) e = dh.alloc(sizeof(unsigned int) * (size_t)K * D * 2 * 256);
     if (e == hipSuccess) e = dout.alloc(sizeof(double) * (size_t)K * D);
-    if (e == hipSuccess) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !dXdev) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
+    const T *dXp = static_cast<const T *>(dXdev ? dXdev : dX.p);
     if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(dn.p, 0, sizeof(unsigned int) * K);
     if (e == hipSuccess) e = hipMemset(dcur.p, 0, sizeof(unsigned int) * K);
@@ -1093,7 +1156,7 @@ int centroid_medians_impl(const void *X, long long C, int D, const int *cell_cod
         for (int dbeg = 0; dbeg < D; dbeg += Dw_max) {           // any D: the dimensions in windows that fit the LDS histograms
             const int Dw = D - dbeg < Dw_max ? D - dbeg : Dw_max;
             hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)splits, (unsigned)K), dim3(256),
-                               sizeof(unsigned int) * (size_t)Dw * 2 * 256, nullptr, static_cast<const T *>(dX.p), D, dbeg, Dw,
+                               sizeof(unsigned int) * (size_t)Dw * 2 * 256, nullptr, dXp, D, dbeg, Dw,
                                dperm.as<unsigned int>(), doffs.as<unsigned int>(), shift, dst.as<State>(), dh.as<unsigned int>());
         }
         hipLaunchKernelGGL(pilot::select_pick_kernel<T>, dim3((nq + 255) / 256), dim3(256), 0, nullptr, K, D, shift,
@@ -1112,9 +1175,20 @@ PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_ce
     if (!X || !cell_code || !centroids) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (n_cells <= 0 || D <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "n_cells=%lld D=%d K=%d must be positive", n_cells, D, K);
     if (n_cells > 0xffffffffLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", n_cells);
-    if (dtype == PILOT_OT_F32) return centroid_medians_impl<float>(X, n_cells, D, cell_code, K, centroids);
-    if (dtype == PILOT_OT_F64) return centroid_medians_impl<double>(X, n_cells, D, cell_code, K, centroids);
+    if (dtype == PILOT_OT_F32) return centroid_medians_impl<float>(X, nullptr, n_cells, D, cell_code, K, centroids);
+    if (dtype == PILOT_OT_F64) return centroid_medians_impl<double>(X, nullptr, n_cells, D, cell_code, K, centroids);
     return fail(PILOT_OT_EINVAL, "unknown dtype id %d", dtype);
+}
+
+PILOT_API int pilot_ot_centroid_medians_dev(pilot_ot_embedding *e, const int *cell_code, int K, double *centroids) {
+    if (!e || !cell_code || !centroids) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (K <= 0) return fail(PILOT_OT_EINVAL, "K=%d must be positive", K);
+    if (e->C > 0xffffffffLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", e->C);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != e->device) return fail(PILOT_OT_EINVAL, "the embedding lives on device %d, the current device is %d", e->device, dev);
+    if (e->dtype == PILOT_OT_F32) return centroid_medians_impl<float>(nullptr, e->dX, e->C, e->D, cell_code, K, centroids);
+    return centroid_medians_impl<double>(nullptr, e->dX, e->C, e->D, cell_code, K, centroids);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -487,13 +487,7 @@ PILOT_API int pilot_ot_multi_sinkhorn(pilot_ot_multi *m, double reg, int num_ite
     // Decide ONCE, from max(M) of the current inputs, what every shard runs -- the same decisions pilot_ot_sinkhorn_grid takes
     // on one device (the device entry point itself assumes a cost matrix normalised by its maximum, Trajectory.py:101):
     // exp(-M/reg) outside the f64 range -> POT-literal kernel, whatever precision was asked for.
-    const double mor = m->max_cost / reg;
-    if (mor > PILOT_OT_MAX_COST_OVER_REG) precision = PILOT_OT_PREC_GENERIC;
-    if (precision == PILOT_OT_PREC_AUTO) {
-        precision = pilot_ot_auto_precision_for(mor, m->K, cost_is_symmetric);
-        if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
-    }
-    if (precision == PILOT_OT_PREC_F16X2 && pilot_ot_auto_precision(mor) != PILOT_OT_PREC_F16X2) precision = PILOT_OT_PREC_BF16X3;
+    precision = pilot_ot_resolve_precision(precision, m->max_cost / reg, m->K, cost_is_symmetric, tau);
     DeviceGuard guard;
     int rc = m->for_each_shard([&](int s) -> int {
         Shard &h = m->sh[s];

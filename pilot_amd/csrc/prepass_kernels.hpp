@@ -12,11 +12,15 @@
 namespace pilot {
 
 // ---- proportions --------------------------------------------------------------------------------------------
+// first_row (nullable, N entries preset to 0xffffffff): smallest row number of every sample -- the row whose status value
+// return_real_labels reports (Trajectory.py:617-642).  The plain read in front of the atomic keeps all but the first few
+// cells of a sample off the atomic unit.
 __global__ void count_kernel(const int *__restrict__ cell_code, const int *__restrict__ sample_code, long C, int K,
-                             unsigned int *__restrict__ counts /* N*K */) {
+                             unsigned int *__restrict__ counts /* N*K */, unsigned int *__restrict__ first_row) {
     for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
         const int k = cell_code[c], s = sample_code[c];
         if (k >= 0 && s >= 0) atomicAdd(&counts[(size_t)s * K + k], 1u);
+        if (first_row && s >= 0 && (unsigned int)c < __builtin_nontemporal_load(&first_row[s])) atomicMin(&first_row[s], (unsigned int)c);
     }
 }
 

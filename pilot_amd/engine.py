@@ -96,6 +96,79 @@ def proportions(cell_code, sample_code, n_samples, n_types, regulizer=0.2, norma
     return P
 
 
+def proportions_and_first_rows(cell_code, sample_code, n_samples, n_types, regulizer=0.2, normalization=True, n_total=None):
+    """:func:`proportions` plus, from the same pass over the codes, the first row of every sample (int64, -1: none) --
+    the row ``return_real_labels`` reads (pilotpy/tools/Trajectory.py:617-642)."""
+    cc = np.ascontiguousarray(cell_code, dtype=np.int32)
+    sc = np.ascontiguousarray(sample_code, dtype=np.int32)
+    if cc.shape != sc.shape or cc.ndim != 1:
+        raise ValueError("cell_code and sample_code must be 1-D arrays of equal length")
+    n_total = cc.size if n_total is None else int(n_total)
+    P = np.zeros((n_samples, n_types), dtype=np.float64)
+    first = np.full(n_samples, -1, dtype=np.int64)
+    _lib.check(_lib.load().pilot_ot_proportions_ex(
+        _lib.iptr(cc), _lib.iptr(sc), cc.size, n_total, int(n_samples), int(n_types), float(regulizer), int(bool(normalization)),
+        _lib.dptr(P), first.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
+    return P, first
+
+
+class EmbeddingUpload:
+    """The C x D embedding on its way to the device: the copy runs on a helper thread (ctypes releases the GIL) while the
+    caller factorises the label columns; :meth:`medians` joins it and runs the device radix select."""
+
+    def __init__(self, X):
+        import threading
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("X must be 2-D (cells, dims)")
+        if X.dtype == np.float32:
+            self.dt = 0
+        else:
+            X = X.astype(np.float64, copy=False)
+            self.dt = 1
+        self.X = np.ascontiguousarray(X)
+        self.L = _lib.load()
+        self.h = ctypes.c_void_p()
+        self.err = None
+        dev = ctypes.c_int(0)
+        _lib.check(self.L.pilot_ot_get_device(ctypes.byref(dev)))
+        self.device = dev.value
+
+        def work():
+            try:
+                _lib.check(self.L.pilot_ot_set_device(self.device))      # (a new host thread starts on device 0)
+                _lib.check(self.L.pilot_ot_embedding_upload(ctypes.c_void_p(self.X.ctypes.data), self.dt, self.X.shape[0],
+                                                            self.X.shape[1], ctypes.byref(self.h)))
+            except BaseException as e:      # re-raised by the caller's thread in medians()
+                self.err = e
+
+        self.thread = threading.Thread(target=work, name="pilot_ot_embedding_upload")
+        self.thread.start()
+
+    def medians(self, cell_code, n_types):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        cc = np.ascontiguousarray(cell_code, dtype=np.int32)
+        if cc.shape != (self.X.shape[0],):
+            raise ValueError("cell_code must have one entry per row of X")
+        out = np.zeros((int(n_types), self.X.shape[1]), dtype=np.float64)
+        _lib.check(self.L.pilot_ot_centroid_medians_dev(self.h, _lib.iptr(cc), int(n_types), _lib.dptr(out)))
+        return out
+
+    def close(self):
+        self.thread.join()
+        if self.h:
+            self.L.pilot_ot_embedding_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def centroid_medians(X, cell_code, n_types):
     """K x D per-cell-type column-wise medians of the C x D embedding (device radix select; replaces
     ``data[annot.cell_type == k].median(axis=0)``, pilotpy/tools/Trajectory.py:465-466).  float32 / float64 input is

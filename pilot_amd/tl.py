@@ -23,7 +23,9 @@ diffusion_kernel                               plot/ploting.py:95-110 (the dense
 """
 from __future__ import annotations
 
+import ctypes
 import os
+import threading
 
 import numpy as np
 import pandas as pd
@@ -56,8 +58,10 @@ def extract_data_anno_scRNA_from_h5ad(adata, emb_matrix="PCA", clusters_col="cel
     global path_to_results
     data = adata.obsm[emb_matrix]
     col_add = ["PCA_" + str(i) for i in range(1, data.shape[1] + 1)]
-    # (the reference's reset_index(drop=True) on a frame that already has a fresh RangeIndex only copies it -- 0.3 s per
-    # 1.8 M x 30 cells; the frame here is a view of adata.obsm[emb_matrix])
+    # The reference's frame is an independent copy of the embedding (DataFrame(...).reset_index(drop=True), :249-252).  The
+    # frame built here VIEWS adata.obsm[emb_matrix]; wasserstein_distance replaces its array by a private copy (made on a
+    # helper thread beside the device work) before it stores the frame in adata.uns['data'].  Direct callers of this helper
+    # get the view.
     data = pd.DataFrame(data, columns=col_add)
     annot = _annot_frame(adata.obs, clusters_col, sample_col, status)
     path_to_results = set_path_for_results()
@@ -77,15 +81,42 @@ def extract_data_anno_pathomics_from_h5ad(adata, var_names=[], clusters_col="Cel
 
 def _annot_frame(obs, clusters_col, sample_col, status):
     """``obs[[clusters_col, sample_col, status]]`` renamed to ``cell_type, sampleID, status`` with a fresh RangeIndex
-    (Trajectory.py:257-262): one column selection (a new frame, dtypes kept), no further copies."""
-    annot = obs[[clusters_col, sample_col, status]]
+    (Trajectory.py:257-262): one column selection (new arrays, dtypes kept); the shallow copy on top only drops pandas'
+    "this is a slice of another frame" marker, so that later column assignments on ``adata.uns['annot']`` neither warn
+    (SettingWithCopyWarning under the reference's pandas 2.0) nor touch ``adata.obs``."""
+    annot = obs[[clusters_col, sample_col, status]].copy(deep=False)
     annot.columns = ["cell_type", "sampleID", "status"]
     annot.index = pd.RangeIndex(len(annot))
     return annot
 
 
 def _first_appearance_codes(series):
-    """(codes, uniques) with uniques in first-appearance order, as ``Series.unique()`` gives."""
+    """(codes, uniques) with uniques in first-appearance order, as ``Series.unique()`` gives; missing values get -1.
+
+    Two shortcuts around hashing millions of Python objects (what ``pd.factorize`` does on an object column, ~25 ms per
+    1.8 M cells and column):
+
+    * categorical columns (what AnnData gives for ``obs`` labels): the integer codes are there already, only their
+      numbering is changed to first appearance;
+    * object columns: the labels of 1.8 M cells are a few hundred distinct Python objects repeated (AnnData / pandas /
+      numpy fancy indexing copy POINTERS), so the column is factorised by object identity -- a hash of 8-byte integers --
+      and only the distinct objects are then factorised by value (equal strings at different addresses merge there).
+    """
+    if isinstance(series.dtype, pd.CategoricalDtype):
+        cat = series.cat
+        raw = cat.codes.to_numpy()
+        seen = pd.unique(raw[raw >= 0]) if (raw < 0).any() else pd.unique(raw)       # category numbers, first appearance
+        remap = np.full(len(cat.categories) + 1, -1, dtype=np.int64)                 # (slot -1 serves the missing code)
+        remap[seen] = np.arange(len(seen))
+        return remap[raw], np.asarray(cat.categories[seen])
+    arr = series.to_numpy()
+    if arr.dtype == object and arr.ndim == 1 and arr.strides == (arr.itemsize,) and arr.size:
+        ptrs = np.ctypeslib.as_array((ctypes.c_size_t * arr.size).from_address(arr.ctypes.data))      # (arr stays alive here)
+        pcodes, puniq = pd.factorize(ptrs, sort=False)
+        objs = np.empty(len(puniq), dtype=object)
+        objs[:] = [ctypes.cast(int(a), ctypes.py_object).value for a in puniq]
+        vcodes, uniques = pd.factorize(objs, sort=False, use_na_sentinel=True)
+        return vcodes[pcodes], np.asarray(uniques)
     codes, uniques = pd.factorize(series, sort=False, use_na_sentinel=True)
     return codes, np.asarray(uniques)
 
@@ -130,7 +161,10 @@ def cost_matrix(annot, data, metric="cosine"):
 
 def _cost_from_codes(X, codes, cells, metric):
     centroids = engine.centroid_medians(X, codes, len(cells))
-    dis = engine.pdist_square(centroids, metric=metric)
+    return _cost_frame(engine.pdist_square(centroids, metric=metric), cells)
+
+
+def _cost_frame(dis, cells):
     cost = pd.DataFrame.from_dict(dis).T
     names = cells
     cost.columns = names
@@ -196,6 +230,42 @@ def _labels_from_codes(scodes, n_samples, cond):
     return [cond[r] for r in first_row]
 
 
+def _leiden_backend():
+    """scanpy (neighbors + leiden), needed only for the ARI of ``return_sil_ari=True``; downstream of the accelerated path
+    (SURVEY.md section 2 #6) and not a dependency of this package."""
+    try:
+        import scanpy
+    except ImportError as e:
+        raise NotImplementedError("return_sil_ari=True: the ARI needs scanpy/leidenalg for the Leiden clustering of the finished "
+                                  "matrix (Trajectory.py:525-588); the silhouette alone is tl.Sil_computing(EMD / EMD.max(), "
+                                  "adata.uns['real_labels'])") from e
+    return scanpy
+
+
+def Clustering(EMD, df, category="status", sample_col=1, res=0.01, metric="cosine", steper=0.01):
+    """Leiden clustering of the samples on the distance matrix until the number of clusters equals the number of status
+    values, and its Rand index against the true labels (Trajectory.py:525-588).  A consumer of the finished matrix: runs
+    scanpy on the host exactly like the reference; returns ``(labels, rand_index, true_labels)``."""
+    sc = _leiden_backend()
+    from sklearn.metrics import rand_score
+    n_status = len(df[category].unique())
+    while True:
+        ad = sc.AnnData(EMD)
+        sc.pp.neighbors(ad, metric=metric)
+        sc.tl.leiden(ad, resolution=res)
+        labels = np.array(ad.obs.leiden)
+        n_found = len(np.unique(labels))
+        if n_status > n_found:
+            res = res + steper
+        elif n_status < n_found:
+            res = res - 0.001
+        else:
+            labels = labels.astype(int)
+            break
+    true_labels = return_real_labels(df, category=category, sample_col=sample_col)
+    return labels, rand_score(true_labels, labels), true_labels
+
+
 def Sil_computing(EMD, real_labels, metric="cosine"):
     """Silhouette score of a labelling of the samples, the rows of ``EMD`` being the points (Trajectory.py:592-612:
     ``sklearn.metrics.silhouette_score(EMD, real_labels, metric=metric)``; callers pass ``EMD / EMD.max()``,
@@ -223,6 +293,8 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     ``{"precision": "fp64"}``; ``{"n_devices": G}`` (or ``{"devices": [0, 1, ...]}``) row-shards the pair grid over G GPUs
     of this node with one RCCL all-gather -- same bits as the single-GPU matrix.
     """
+    if return_sil_ari:
+        _leiden_backend()      # ARI needs scanpy's Leiden clustering (Trajectory.py:108-113): refuse BEFORE any device work
     if data_type == "scRNA":
         data, annot = extract_data_anno_scRNA_from_h5ad(adata, emb_matrix=emb_matrix, clusters_col=clusters_col,
                                                         sample_col=sample_col, status=status)
@@ -230,29 +302,48 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
         data, annot = extract_data_anno_pathomics_from_h5ad(adata, var_names=list(adata.var_names),
                                                             clusters_col=clusters_col, sample_col=sample_col,
                                                             status=status)
-    adata.uns["data"] = data
+    # While the label columns are factorised on this thread (GIL-bound object hashing), two helper threads move bytes:
+    # the embedding to the device (H2D) and into the private copy that adata.uns['data'] holds, like the reference's.
+    X = data.to_numpy()
+    upload = engine.EmbeddingUpload(X)
+    own = {}
+
+    def copy_embedding():
+        own["X"] = np.array(X, copy=True)
+    copier = threading.Thread(target=copy_embedding, name="pilot_amd_data_copy")
+    copier.start()
+    try:
+        # the two label columns are factorised ONCE (first-appearance order, Trajectory.py:402,412) and shared by the three
+        # steps that the reference runs as separate pandas scans
+        ccodes, cells = _first_appearance_codes(annot["cell_type"])
+        scodes, samples = _first_appearance_codes(annot["sampleID"])
+        P, first_rows = engine.proportions_and_first_rows(ccodes, scodes, len(samples), len(cells), regulizer=regulizer,
+                                                          normalization=normalization, n_total=len(annot))
+        proportions = {samples[n]: P[n].copy() for n in range(len(samples))}
+        centroids = upload.medians(ccodes, len(cells))
+    finally:
+        upload.close()
+        copier.join()
+    adata.uns["data"] = pd.DataFrame(own["X"], columns=data.columns, copy=False)
     adata.uns["annot"] = annot
-    # the two label columns are factorised ONCE (first-appearance order, Trajectory.py:402,412) and shared by the three
-    # steps that the reference runs as separate pandas scans; the embedding goes to the device straight from the array
-    # the frame views
-    ccodes, cells = _first_appearance_codes(annot["cell_type"])
-    scodes, samples = _first_appearance_codes(annot["sampleID"])
-    proportions = _proportions_from_codes(ccodes, scodes, samples, len(cells), len(annot), regulizer, normalization)
     adata.uns["proportions"] = proportions
 
-    cost, cost_df = _cost_from_codes(data.to_numpy(), ccodes, cells, metric)
+    cost, cost_df = _cost_frame(engine.pdist_square(centroids, metric=metric), cells)
     adata.uns["cost"] = cost_df
 
     EMD, emd_df = wasserstein_d(proportions, cost / cost.max(), regularized=regularized, reg=reg,
                                 engine_options=engine_options)
     adata.uns["EMD_df"] = emd_df
     adata.uns["EMD"] = EMD
+    # first status value of every sample (return_real_labels, :617-642): the first row of a sample came out of the
+    # device pass over the codes
+    status_col = annot["status"]
+    real_labels = [status_col.iloc[int(r)] for r in first_rows]
+    adata.uns["real_labels"] = real_labels
     if return_sil_ari:
-        # Leiden clustering + silhouette of the finished matrix (Trajectory.py:108-113) are downstream
-        # consumers that need scanpy/leidenalg; outside the accelerated path.
-        raise NotImplementedError("return_sil_ari=True needs scanpy/leidenalg (downstream of the EMD matrix); "
-                                  "run pilotpy's Clustering/Sil_computing on adata.uns['EMD']")
-    adata.uns["real_labels"] = _labels_from_codes(scodes, len(samples), annot["status"].to_numpy())
+        labels, ARI, _ = Clustering(EMD / EMD.max(), annot, metric=metric, res=res, steper=steper)
+        adata.uns["Sil"] = Sil_computing(EMD / EMD.max(), real_labels, metric=metric)
+        adata.uns["ARI"] = ARI
 
 
 def Precomputed_distance(adata, distances, cost_df, features_matrix, emb_matrix="X_PCA",

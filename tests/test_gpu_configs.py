@@ -41,7 +41,7 @@ def test_c3_reg001_twenty_rows_f64_follow_the_oracle_update_for_update(c3_small_
     assert ((io["flags"] & O.FLAG_ABSORBED) > 0).mean() > 0.9         # and nearly every pair tau-absorbs
 
 
-def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle):
+def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle, monkeypatch):
     """precision='auto' at max(M)/reg = 100 (PILOT_OT_PREC_AUTO_MIXED): f32 values on the bf16-split tracking kernel with the
     Gibbs kernel in two exponent bands, f64 only for pairs that leave the f32 range.  A fifth of exp(-M/reg) lies below what
     one f32 band represents and most plans use those entries, so this is the test of the second band: every pair -- capped,
@@ -63,31 +63,31 @@ def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle):
     if f64.any():                                                  # pairs solved in f64 match update for update
         np.testing.assert_array_equal(ig["iters"][f64], io["iters"][f64])
         assert np.abs(Eg - Eo)[f64].max() <= 1e-9
-    # one exponent band alone is NOT enough here (what the second band is for)
+    # an explicit f32-class precision beyond the f32 range (max(M)/reg = 100 > 60) runs the same mixed path ...
+    for prec in ("bf16x3", "fp32", "f16x2"):
+        np.testing.assert_array_equal(engine.sinkhorn_grid(P, M, 0.01, precision=prec, **rows), Eg)
+    # ... because one exponent band alone is NOT enough here (what the second band is for; PILOT_OT_RAW_PRECISION: tests only)
+    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
     E1 = engine.sinkhorn_grid(P, M, 0.01, precision="bf16x3", **rows)
     assert np.abs(E1 - Eo)[~last_o].max() > 5 * TOL32
 
 
-def test_c3_reg001_twenty_rows_f32(c3_small_reg_oracle):
+def test_c3_reg001_twenty_rows_raw_f32_kernel(c3_small_reg_oracle, monkeypatch):
+    """The f32-input MFMA kernel forced outside its range (PILOT_OT_RAW_PRECISION, tests only): what an explicit
+    precision="fp32" would give at max(M)/reg = 100 if it were not promoted to AUTO_MIXED -- finite, the oracle's update counts
+    or an earlier check, but up to 1e-4 off on the pairs that stop early.  Kept as the measurement behind the promotion rule
+    (pilot_ot_resolve_precision); user-facing calls are held to 1e-5 by test_c3_reg001_twenty_rows_auto_precision."""
+    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
     P, M, rows, Eo, io = c3_small_reg_oracle
     Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="fp32", return_info=True, **rows)
     assert np.isfinite(Eg).all()
     last_o = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0
     last_g = (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
-    capped_o, capped_g = io["iters"] == 1000, ig["iters"] == 1000
+    capped_g = ig["iters"] == 1000
     same = ig["iters"] == io["iters"]
-    print("c3 reg 0.01 f32, %d pairs: capped oracle %d / gpu %d, absorb-on-last oracle %d / gpu %d, same update count %d"
-          % (Eo.size, capped_o.sum(), capped_g.sum(), last_o.sum(), last_g.sum(), same.sum()))
     ok = ~last_o & ~last_g
     d = np.abs(Eg - Eo)
-    early = ok & ~same
-    print("max|gpu - oracle|: same update count %.3e, stopped at an earlier check %.3e (of which oracle-capped %.3e)"
-          % (d[ok & same].max(), d[early].max() if early.any() else 0.0,
-             d[early & capped_o].max() if (early & capped_o).any() else 0.0))
     assert d[ok & same].max() <= TOL32
-    # About half of the oracle's capped pairs sit between f32's resolution and POT's stopThr = 1e-9 for hundreds of
-    # updates: the f32 kernel (threshold floored at 8 ulp * ||b||_2) declares them converged at an earlier check.  The
-    # cost moves by at most the residual marginal error of that plan.
     assert np.all(ig["iters"] <= io["iters"])
     assert d[ok].max() <= 1e-4
     assert np.all(ig["iters"][~capped_g] % 20 == 1)

@@ -75,7 +75,9 @@ def test_small_reg_goes_through_absorption_tracking_f64():
     assert 0.2 < capped.mean() < 0.9
 
 
-def test_small_reg_f32_stays_within_tolerance_on_this_distribution():
+def test_small_reg_f32_stays_within_tolerance_on_this_distribution(monkeypatch):
+    """The raw f32-input MFMA kernel at max(M)/reg = 100 (outside its range; normal calls run AUTO_MIXED there)."""
+    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
     P, M = make_problem(**CONFIGS["c3"])
     rows = dict(row_begin=100, row_end=102, row_step=1)
     Eo, io = O.sinkhorn_grid(P, M, 0.01, n_threads=16, return_info=True, **rows)
@@ -155,13 +157,15 @@ def test_small_reg_two_exponent_bands_other_shapes(K, sym):
     assert f64.all() if K == 100 else f64.mean() < 0.2
 
 
-def test_pairs_that_go_nan_are_resolved_like_pot():
+def test_pairs_that_go_nan_are_resolved_like_pot(monkeypatch):
     """POT breaks out of a pair whose scalings become NaN and returns the cost of the last good iterate.  The
     fast kernels hand such pairs to the POT-literal kernel instead of writing NaN: forcing the f32 kernel far outside its
     range (max(M)/reg = 400: exp(-M/reg) underflows in f32) must leave no NaN behind, and every pair that was handed over
     (flag F64) must carry the oracle's value, update count and flags."""
     P, M = make_problem(**CONFIGS["c1"])
     Eo, io = O.sinkhorn_grid(P, M, 0.0025, n_threads=16, return_info=True)
+    # (an explicit f32-class precision beyond max(M)/reg = 60 normally runs AUTO_MIXED: the raw kernels are forced here)
+    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
     for prec in ("fp32", "bf16x3", "f16x2"):
         Eg, ig = engine.sinkhorn_grid(P, M, 0.0025, precision=prec, return_info=True)
         assert not np.isnan(Eg).any()

@@ -85,12 +85,47 @@ def test_set_path_for_results_creates_dir(tmp_path, monkeypatch):
     assert (tmp_path / "Results_PILOT" / "plots").is_dir()
 
 
-def test_return_sil_ari_is_rejected_loudly_before_any_device_work():
+def test_a_wrong_embedding_key_fails_in_the_extraction_step():
     # argument handling only: the engine is never reached because extraction fails first on a bad key
     g = load_golden("c1_20x10x10")
     ad, _ = golden_adata(g)
     with pytest.raises(KeyError):
         tl.wasserstein_distance(ad, emb_matrix="X_PCA")            # reference default key, absent here
+    assert ad.uns == {}
+
+
+def test_return_sil_ari_is_refused_before_any_device_work():
+    """return_sil_ari=True (Trajectory.py:108-113) needs scanpy's Leiden clustering for the ARI; without scanpy the call is
+    refused up front -- nothing computed, nothing written to adata.uns, no GPU touched (this test runs on the CPU box)."""
+    try:
+        import scanpy  # noqa: F401
+        pytest.skip("scanpy is installed here")
+    except ImportError:
+        pass
+    g = load_golden("c1_20x10x10")
+    ad, _ = golden_adata(g)
+    with pytest.raises(NotImplementedError, match="scanpy"):
+        tl.wasserstein_distance(ad, emb_matrix="X_pca", return_sil_ari=True)
+    assert ad.uns == {}
+
+
+def test_label_columns_are_factorised_like_pandas_unique():
+    """The shortcuts of tl._first_appearance_codes (categorical codes renumbered; object columns hashed by object identity,
+    the few distinct objects by value) against pd.factorize: first-appearance order, missing values -> -1, equal strings at
+    different addresses merged."""
+    import pandas as pd
+    rng = np.random.default_rng(0)
+    names = np.array(["ct%03d" % i for i in range(40)], dtype=object)
+    col = names[rng.integers(0, 40, 5000)]
+    col[7] = "ct" + "%03d" % 1                  # an equal string that is a different object
+    col[11] = None
+    col[12] = float("nan")
+    for s in (pd.Series(col), pd.Series(col).astype("category"), pd.Series(rng.integers(0, 9, 300)), pd.Series(col)[::2],
+              pd.Series(col[:0])):
+        ref_codes, ref_uniques = pd.factorize(s, sort=False, use_na_sentinel=True)
+        codes, uniques = tl._first_appearance_codes(s)
+        np.testing.assert_array_equal(codes, ref_codes)
+        assert list(uniques) == list(ref_uniques)
 
 
 def test_unequal_masses_stop_the_exact_mode_like_pot():

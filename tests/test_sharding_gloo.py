@@ -45,14 +45,15 @@ WORKER = textwrap.dedent("""
     import numpy as np
     import torch, torch.distributed as dist
     sys.path.insert(0, %(root)r)
+    sys.path.insert(0, %(root)r + "/tests")
     from oracle import oracle as O
-    from pilot_amd import sharding
+    import gloo_harness as harness
     from pilot_amd.synthetic import make_problem
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     P, M = make_problem(23, 9, 6, seed=5, cells_per_patient=150)     # N=23: ragged over 2 ranks
     N = P.shape[0]
-    full = sharding.grid_sharded(lambda b, e, s: O.sinkhorn_grid(P, M, 0.1, row_begin=b, row_end=e, row_step=s),
+    full = harness.grid_sharded(lambda b, e, s: O.sinkhorn_grid(P, M, 0.1, row_begin=b, row_end=e, row_step=s),
                                  N, rank, world)
     ref = O.sinkhorn_grid(P, M, 0.1)
     assert full.shape == (N, N) and np.array_equal(full, ref), "sinkhorn shards differ"
@@ -60,11 +61,11 @@ WORKER = textwrap.dedent("""
         E = O.emd_grid(P, M, row_begin=b, row_end=e, row_step=s)
         rows = np.arange(b, e, s)[:, None]
         return np.where(np.arange(N)[None, :] >= rows, E, 0.0)
-    full = sharding.grid_sharded(upper, N, rank, world, symmetric_upper=True)
+    full = harness.grid_sharded(upper, N, rank, world, symmetric_upper=True)
     ref = O.emd_grid(P, M)
     assert np.allclose(full, ref, atol=1e-14) and np.array_equal(full, full.T), "emd shards differ"
     t = torch.from_numpy(ref[rank::world].copy())
-    again = sharding.all_gather_rows(t, N)
+    again = harness.all_gather_rows(t, N)
     assert torch.equal(again, torch.from_numpy(ref))
     dist.barrier()
     if rank == 0:
