@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -784,6 +785,35 @@ PILOT_API int pilot_ot_plan_enable_graph(pilot_ot_plan *pl, int enable) {
 // Host-buffer entry points keep one plan + staging buffers per calling thread and reuse them while the
 // shape stays the same (a PILOT session calls with one (N, K)); pilot_ot_shutdown() releases them.
 namespace {
+// Temporaries of the pre-pass host calls come from a per-thread pool that only grows (hipMalloc / hipFree cost about a
+// millisecond a pair and hipFree synchronises the device: nine of them were most of a 22 ms medians call); released by
+// pilot_ot_shutdown().  Slot i of the pool backs the i-th DevBuf a call declares.
+struct WsPool {
+    static constexpr int SLOTS = 12;
+    void *p[SLOTS] = {};
+    size_t cap[SLOTS] = {};
+    int device = -1;
+    void release() {
+        for (int i = 0; i < SLOTS; ++i) { if (p[i]) (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+        device = -1;
+    }
+    hipError_t get(int slot, size_t bytes, void **out) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev != device) { release(); device = dev; }
+        if (bytes > cap[slot]) {
+            if (p[slot]) (void)hipFree(p[slot]);
+            p[slot] = nullptr; cap[slot] = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            e = hipMalloc(&p[slot], want);
+            if (e != hipSuccess) return e;
+            cap[slot] = want;
+        }
+        *out = p[slot];
+        return hipSuccess;
+    }
+};
 struct HostCtx {
     pilot_ot_plan *plan = nullptr;
     int N = 0, K = 0, device = -1;
@@ -809,7 +839,42 @@ struct HostCtx {
     }
     ~HostCtx() {}   // device memory is released by pilot_ot_shutdown() or at process exit
 };
-thread_local HostCtx g_host;
+// Per-thread caches (host-entry workspace + pre-pass pool) live in a process-wide registry, not in thread_local objects:
+// pilot_ot_shutdown() releases the caches of EVERY thread (it must not run concurrently with other calls), and the caches
+// of a thread that has exited are released by the next thread that creates its own -- never from a thread-exit or
+// process-exit hook, where the HIP runtime may already be gone.
+struct ThreadCtx { HostCtx host; WsPool ws; bool orphan = false; };
+std::mutex g_tctx_mutex;
+std::vector<ThreadCtx *> g_tctx_all;
+struct TctxOwner {
+    ThreadCtx *c = nullptr;
+    ~TctxOwner() {
+        if (!c) return;
+        std::lock_guard<std::mutex> l(g_tctx_mutex);
+        c->orphan = true;           // (no HIP calls here)
+    }
+};
+thread_local TctxOwner g_tctx_owner;
+ThreadCtx &tctx() {
+    if (!g_tctx_owner.c) {
+        std::lock_guard<std::mutex> l(g_tctx_mutex);
+        for (size_t i = 0; i < g_tctx_all.size();) {
+            if (g_tctx_all[i]->orphan) {
+                g_tctx_all[i]->host.release();
+                g_tctx_all[i]->ws.release();
+                delete g_tctx_all[i];
+                g_tctx_all.erase(g_tctx_all.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+        g_tctx_owner.c = new ThreadCtx();
+        g_tctx_all.push_back(g_tctx_owner.c);
+    }
+    return *g_tctx_owner.c;
+}
+#define g_host (tctx().host)
+#define g_ws (tctx().ws)
 
 int host_ctx_prepare(int N, int K, size_t n_out) {
     int dev = 0;
@@ -879,7 +944,10 @@ int host_fetch(const Fetch *f, int n) {
 }  // namespace
 
 PILOT_API int pilot_ot_shutdown(void) {
-    g_host.release();
+    {
+        std::lock_guard<std::mutex> l(g_tctx_mutex);
+        for (ThreadCtx *c : g_tctx_all) { c->host.release(); c->ws.release(); }
+    }
     pilot::abi_multi_release();
     return PILOT_OT_OK;
 }
@@ -1023,10 +1091,11 @@ PILOT_API int pilot_ot_plan_kernel_times(pilot_ot_plan *pl, int max_n, float *ma
 // ------------------------------------------------------------------------------------------------
 // pre-pass (host-buffer entry points; the inputs are read once, so they are staged per call)
 namespace {
-struct DevBuf {   // RAII for the temporaries of one host call
+struct DevBuf {
     void *p = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    int slot;
+    explicit DevBuf(int slot_) : slot(slot_) {}
+    hipError_t alloc(size_t bytes) { return g_ws.get(slot, bytes ? bytes : 1, &p); }
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 int grid_for(long n, int block, int n_cu) {
@@ -1054,7 +1123,7 @@ PILOT_API int pilot_ot_proportions_ex(const int *cell_code, const int *sample_co
     if (N <= 0 || K <= 0 || n_cells < 0 || n_total < 2)
         return fail(PILOT_OT_EINVAL, "N=%d K=%d n_cells=%lld n_total=%lld out of range", N, K, n_cells, n_total);
     if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
-    DevBuf dc, ds, dcnt, dP, dfirst;
+    DevBuf dc(0), ds(1), dcnt(2), dP(3), dfirst(4);
     hipError_t e = dc.alloc(sizeof(int) * (size_t)n_cells);
     if (e == hipSuccess) e = ds.alloc(sizeof(int) * (size_t)n_cells);
     if (e == hipSuccess) e = dcnt.alloc(sizeof(unsigned int) * (size_t)N * K);
@@ -1119,7 +1188,7 @@ int centroid_medians_impl(const void *X, const void *dXdev, long long C, int D, 
     using State = pilot::SelectState<U>;
     const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;      // dimensions per histogram launch
     const size_t lds = sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
-    DevBuf dX, dc, dn, doffs, dcur, dperm, dst, dh, dout;
+    DevBuf dX(0), dc(1), dn(2), doffs(3), dcur(4), dperm(5), dst(6), dh(7), dout(8);
     hipError_t e = dXdev ? hipSuccess : dX.alloc(sizeof(T) * (size_t)C * D);
     if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
     if (e == hipSuccess) e = dn.alloc(sizeof(unsigned int) * K);

@@ -180,40 +180,46 @@ def wasserstein_d(Clu_rep, cost, regularized="unreg", reg=0.1, engine_options=No
     ``sinkhorn_stabilized`` semantics (``ot.sinkhorn2``).  Returns ``(EMD float64 N x N, DataFrame)``;
     the frame is ``DataFrame.from_dict(EMD).T`` indexed by sample id, exactly as the reference builds it.
     """
-    opts = dict(_DEFAULT_ENGINE_OPTIONS)
-    opts.update(engine_options or {})
     samples_id = list(Clu_rep.keys())
-    n_samples = len(samples_id)
-    if n_samples == 0:
+    if len(samples_id) == 0:
         EMD = np.zeros((0, 0))
     else:
         P = np.stack([np.asarray(Clu_rep[s], dtype=np.float64) for s in samples_id])
-        cost = np.asarray(cost, dtype=np.float64)
+        EMD = _pair_grid(P, cost, regularized, reg, engine_options)
+    return EMD, _emd_frame(EMD, samples_id)
+
+
+def _pair_grid(P, cost, regularized, reg, engine_options):
+    """The N x N matrix of all ordered pairs on the device(s): the loop of Trajectory.py:505-515."""
+    opts = dict(_DEFAULT_ENGINE_OPTIONS)
+    opts.update(engine_options or {})
+    cost = np.asarray(cost, dtype=np.float64)
+    if regularized == "unreg":
+        # ot.emd2 (POT 0.9: check_marginals=True) refuses histograms of different mass before it rescales them:
+        # np.testing.assert_almost_equal(a.sum(0), b.sum(0), decimal=6).  With normalization=False the reference's
+        # proportions are raw counts and this is what stops it (Trajectory.py:428-436, :511).
+        sums = P.sum(1)
+        if sums.size and float(sums.max() - sums.min()) >= 1.5e-6:
+            raise AssertionError("a and b vector must have the same sum (sample masses range from %g to %g)"
+                                 % (sums.min(), sums.max()))
+    multi = {k: opts.pop(k) for k in ("devices", "n_devices", "gather") if k in opts}
+    if multi.get("devices") is not None or (multi.get("n_devices") or 1) > 1:
+        # the pair grid row-sharded over several GPUs of this node, one RCCL all-gather (pilot_amd.multi)
+        from . import multi as _multi
         if regularized == "unreg":
-            # ot.emd2 (POT 0.9: check_marginals=True) refuses histograms of different mass before it rescales them:
-            # np.testing.assert_almost_equal(a.sum(0), b.sum(0), decimal=6).  With normalization=False the reference's
-            # proportions are raw counts and this is what stops it (Trajectory.py:428-436, :511).
-            sums = P.sum(1)
-            if sums.size and float(sums.max() - sums.min()) >= 1.5e-6:
-                raise AssertionError("a and b vector must have the same sum (sample masses range from %g to %g)"
-                                     % (sums.min(), sums.max()))
-        multi = {k: opts.pop(k) for k in ("devices", "n_devices", "gather") if k in opts}
-        if multi.get("devices") is not None or (multi.get("n_devices") or 1) > 1:
-            # the pair grid row-sharded over several GPUs of this node, one RCCL all-gather (pilot_amd.multi)
-            from . import multi as _multi
-            if regularized == "unreg":
-                EMD = _multi.emd_grid_multi(P, cost, **multi)
-            else:
-                EMD = _multi.sinkhorn_grid_multi(P, cost, reg, **multi, **opts)
-        elif regularized == "unreg":
-            EMD = engine.emd_grid(P, cost)
-        else:
-            EMD = engine.sinkhorn_grid(P, cost, reg, **opts)
+            return _multi.emd_grid_multi(P, cost, **multi)
+        return _multi.sinkhorn_grid_multi(P, cost, reg, **multi, **opts)
+    if regularized == "unreg":
+        return engine.emd_grid(P, cost)
+    return engine.sinkhorn_grid(P, cost, reg, **opts)
+
+
+def _emd_frame(EMD, samples_id):
     emd = pd.DataFrame.from_dict(EMD).T
     emd.columns = samples_id
     emd["sampleID"] = samples_id
     emd = emd.set_index("sampleID")
-    return EMD, emd
+    return emd
 
 
 def return_real_labels(df, category="status", sample_col=1):
@@ -228,6 +234,54 @@ def _labels_from_codes(scodes, n_samples, cond):
     # first occurrence of each sample code: assign the row numbers back to front, the earliest row is written last
     first_row[scodes[idx][::-1]] = idx[::-1]
     return [cond[r] for r in first_row]
+
+
+class _DeviceWorker:
+    """ONE long-lived helper thread that runs the device chain of ``wasserstein_distance`` (the library caches its
+    workspace per calling thread: a fresh thread per call would rebuild it every time)."""
+
+    class _Job:
+        def __init__(self):
+            self.done = threading.Event()
+            self.error = None
+
+        def wait(self):
+            self.done.wait()
+
+    def __init__(self):
+        import queue
+        self.q = queue.SimpleQueue()
+        self.thread = threading.Thread(target=self._loop, name="pilot_amd_device_chain", daemon=True)
+        self.thread.start()
+
+    def _loop(self):
+        from . import _lib
+        while True:
+            job, device, fn, args = self.q.get()
+            try:
+                _lib.check(_lib.load().pilot_ot_set_device(device))      # (the caller's current device)
+                fn(*args)
+            except BaseException as e:                                     # handed to the submitting thread
+                job.error = e
+            finally:
+                job.done.set()
+
+    def submit(self, device, fn, *args):
+        job = self._Job()
+        self.q.put((job, device, fn, args))
+        return job
+
+
+_worker = None
+_worker_lock = threading.Lock()
+
+
+def _device_worker():
+    global _worker
+    with _worker_lock:
+        if _worker is None or not _worker.thread.is_alive():
+            _worker = _DeviceWorker()
+        return _worker
 
 
 def _leiden_backend():
@@ -295,45 +349,65 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     """
     if return_sil_ari:
         _leiden_backend()      # ARI needs scanpy's Leiden clustering (Trajectory.py:108-113): refuse BEFORE any device work
+    global path_to_results
+    # the embedding frame first (extract_data_anno_*_from_h5ad, :234-299): its bytes start moving at once
     if data_type == "scRNA":
-        data, annot = extract_data_anno_scRNA_from_h5ad(adata, emb_matrix=emb_matrix, clusters_col=clusters_col,
-                                                        sample_col=sample_col, status=status)
+        X = adata.obsm[emb_matrix]
+        data = pd.DataFrame(X, columns=["PCA_" + str(i) for i in range(1, X.shape[1] + 1)])
     else:
-        data, annot = extract_data_anno_pathomics_from_h5ad(adata, var_names=list(adata.var_names),
-                                                            clusters_col=clusters_col, sample_col=sample_col,
-                                                            status=status)
-    # While the label columns are factorised on this thread (GIL-bound object hashing), two helper threads move bytes:
+        var_names = list(adata.var_names)
+        data = pd.DataFrame(adata[:, var_names].X, columns=var_names)
+    # While the label columns are selected and factorised on this thread (GIL-bound object work), helper threads move bytes:
     # the embedding to the device (H2D) and into the private copy that adata.uns['data'] holds, like the reference's.
     X = data.to_numpy()
     upload = engine.EmbeddingUpload(X)
-    own = {}
+    own = np.empty_like(X)
+    n_copy = 4 if X.size >= (1 << 22) else 1
+    bounds = np.linspace(0, X.shape[0], n_copy + 1).astype(np.int64)
+    copiers = [threading.Thread(target=np.copyto, args=(own[a:b], X[a:b]), name="pilot_amd_data_copy")
+               for a, b in zip(bounds[:-1], bounds[1:])]
+    for t in copiers:
+        t.start()
+    dev = {}
 
-    def copy_embedding():
-        own["X"] = np.array(X, copy=True)
-    copier = threading.Thread(target=copy_embedding, name="pilot_amd_data_copy")
-    copier.start()
+    def device_chain(ccodes, scodes, n_samples, n_types):
+        # runs with the GIL released almost throughout (ctypes calls): proportions + first rows, medians, pdist, pair grid
+        try:
+            dev["P"], dev["first"] = engine.proportions_and_first_rows(ccodes, scodes, n_samples, n_types, regulizer=regulizer,
+                                                                       normalization=normalization, n_total=len(ccodes))
+            cost = engine.pdist_square(upload.medians(ccodes, n_types), metric=metric)
+            dev["cost"] = cost
+            dev["EMD"] = _pair_grid(dev["P"], cost / cost.max(), regularized, reg, engine_options) if n_samples else np.zeros((0, 0))
+        except BaseException as e:          # re-raised on the calling thread
+            dev["error"] = e
+    chain = None
     try:
-        # the two label columns are factorised ONCE (first-appearance order, Trajectory.py:402,412) and shared by the three
-        # steps that the reference runs as separate pandas scans
-        ccodes, cells = _first_appearance_codes(annot["cell_type"])
-        scodes, samples = _first_appearance_codes(annot["sampleID"])
-        P, first_rows = engine.proportions_and_first_rows(ccodes, scodes, len(samples), len(cells), regulizer=regulizer,
-                                                          normalization=normalization, n_total=len(annot))
-        proportions = {samples[n]: P[n].copy() for n in range(len(samples))}
-        centroids = upload.medians(ccodes, len(cells))
+        # the two label columns are factorised ONCE (first-appearance order, Trajectory.py:402,412), straight from adata.obs,
+        # and shared by the three steps that the reference runs as separate pandas scans ...
+        ccodes, cells = _first_appearance_codes(adata.obs[clusters_col])
+        scodes, samples = _first_appearance_codes(adata.obs[sample_col])
+        chain = _device_worker().submit(upload.device, device_chain, ccodes, scodes, len(samples), len(cells))
+        # ... and while the device works, this thread does the GIL-bound part: the annotation frame (a copy of three object
+        # columns of adata.obs, Trajectory.py:257-262)
+        annot = _annot_frame(adata.obs, clusters_col, sample_col, status)
+        path_to_results = set_path_for_results()
     finally:
+        if chain is not None:
+            chain.wait()
         upload.close()
-        copier.join()
-    adata.uns["data"] = pd.DataFrame(own["X"], columns=data.columns, copy=False)
+        for t in copiers:
+            t.join()
+    if "error" in dev or chain.error is not None:
+        raise dev.get("error") or chain.error
+    proportions = {samples[n]: dev["P"][n].copy() for n in range(len(samples))}
+    first_rows = dev["first"]
+    adata.uns["data"] = pd.DataFrame(own, columns=data.columns, copy=False)
     adata.uns["annot"] = annot
     adata.uns["proportions"] = proportions
-
-    cost, cost_df = _cost_frame(engine.pdist_square(centroids, metric=metric), cells)
+    cost, cost_df = _cost_frame(dev["cost"], cells)
     adata.uns["cost"] = cost_df
-
-    EMD, emd_df = wasserstein_d(proportions, cost / cost.max(), regularized=regularized, reg=reg,
-                                engine_options=engine_options)
-    adata.uns["EMD_df"] = emd_df
+    EMD = dev["EMD"]
+    adata.uns["EMD_df"] = _emd_frame(EMD, list(proportions.keys()))
     adata.uns["EMD"] = EMD
     # first status value of every sample (return_real_labels, :617-642): the first row of a sample came out of the
     # device pass over the codes
