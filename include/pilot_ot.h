@@ -89,6 +89,17 @@ extern "C" {
 #define PILOT_OT_METRIC_BRAYCURTIS 8
 #define PILOT_OT_METRIC_CANBERRA 9
 #define PILOT_OT_METRIC_HAMMING 10
+/* scipy's boolean dissimilarities (pdist converts the rows to bool: non-zero = True) and the rest of scipy 1.15's pdist names */
+#define PILOT_OT_METRIC_JACCARD 11
+#define PILOT_OT_METRIC_DICE 12           /* (evaluated on the values, like scipy: ntt = sum u v, ...) */
+#define PILOT_OT_METRIC_YULE 13
+#define PILOT_OT_METRIC_RUSSELLRAO 14
+#define PILOT_OT_METRIC_SOKALSNEATH 15
+#define PILOT_OT_METRIC_ROGERSTANIMOTO 16
+#define PILOT_OT_METRIC_SOKALMICHENER 17
+#define PILOT_OT_METRIC_KULCZYNSKI1 18
+#define PILOT_OT_METRIC_JENSENSHANNON 19
+#define PILOT_OT_METRIC_MAHALANOBIS 20    /* needs aux = VI, the D x D inverse covariance (cost_matrix_ex) */
 
 /* ---- library / device --------------------------------------------------------------------- */
 int pilot_ot_version(void);
@@ -138,6 +149,11 @@ int pilot_ot_centroid_medians_dev(pilot_ot_embedding *emb, const int *cell_code,
 int pilot_ot_cost_matrix(const double *centroids, int K, int D, int metric, double *cost);
 int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric, double *d_cost,
                              void *stream);
+/* aux: metric-specific extra input, NULL otherwise -- mahalanobis: VI = inv(cov(centroids^T))^T, D x D, which the host
+ * computes like scipy does (numpy.linalg.inv) */
+int pilot_ot_cost_matrix_ex(const double *centroids, int K, int D, int metric, const double *aux, double *cost);
+int pilot_ot_cost_matrix_dev_ex(const double *d_centroids, int K, int D, int metric, const double *d_aux, double *d_cost,
+                                void *stream);
 
 /* ---- Sinkhorn pair grid: replaces the loop at Trajectory.py:512-515 ------------------------- */
 /* Each pair follows POT 0.9.x sinkhorn_stabilized control flow (v-update then u-update; marginal
@@ -157,7 +173,8 @@ int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, doubl
                            double *emd, int *iters, double *err, int *flags);
 
 /* Device-resident form.  A plan owns the device workspace for one (N, K) shape so the call itself
- * allocates nothing (HIP-graph capturable). */
+ * allocates nothing (HIP-graph capturable) -- with one exception: the scratch of the POT-literal kernel (PREC_GENERIC,
+ * 2 K^2 doubles per resident workgroup) is allocated by the first call that runs that kernel. */
 typedef struct pilot_ot_plan pilot_ot_plan;
 int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan);
 int pilot_ot_plan_destroy(pilot_ot_plan *plan);

@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "libpilot_ot.so")
 OK, EINVAL, EHIP, ENOTSUP, ERCCL = 0, -1, -2, -3, -4
 PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2, "bf16x3": 3, "generic": 5, "f16x2": 6}
 METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3, "chebyshev": 4, "correlation": 5,
-           "minkowski": 6, "seuclidean": 7, "braycurtis": 8, "canberra": 9, "hamming": 10}
+           "minkowski": 6, "seuclidean": 7, "braycurtis": 8, "canberra": 9, "hamming": 10, "jaccard": 11, "dice": 12, "yule": 13,
+           "russellrao": 14, "sokalsneath": 15, "rogerstanimoto": 16, "sokalmichener": 17, "kulczynski1": 18, "jensenshannon": 19,
+           "mahalanobis": 20}
 
 EMD_ALL, EMD_UPPER, EMD_MIRROR = 0, 1, 2
 FLAG_CONVERGED, FLAG_NAN, FLAG_ABSORB_LAST, FLAG_ABSORBED, FLAG_F64 = 1, 2, 4, 8, 16
@@ -26,6 +28,7 @@ SYMBOLS = [
     "pilot_ot_version", "pilot_ot_last_error", "pilot_ot_device_count", "pilot_ot_set_device", "pilot_ot_get_device",
     "pilot_ot_device_name", "pilot_ot_dev_alloc", "pilot_ot_dev_free", "pilot_ot_memcpy_h2d",
     "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
+    "pilot_ot_cost_matrix_ex", "pilot_ot_cost_matrix_dev_ex",
     "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_resolve_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_plan_enable_graph", "pilot_ot_shutdown",
@@ -76,6 +79,8 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_stream_sync.argtypes = [c_vp]
     L.pilot_ot_cost_matrix.argtypes = [dp, c_int, c_int, c_int, dp]
     L.pilot_ot_cost_matrix_dev.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp]
+    L.pilot_ot_cost_matrix_ex.argtypes = [dp, c_int, c_int, c_int, dp, dp]
+    L.pilot_ot_cost_matrix_dev_ex.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]
     L.pilot_ot_sinkhorn_grid.argtypes = [dp, c_int, c_int, dp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int,
                                          c_dbl, c_int, c_int, c_int, c_int, dp, ip, dp, ip]
     L.pilot_ot_plan_create.argtypes = [c_int, c_int, ctypes.POINTER(c_vp)]

@@ -42,7 +42,8 @@ namespace {
 // K1: centroid cost matrix (scipy pdist + squareform, Trajectory.py:468-469).  K <= a few hundred,
 // D <= a few hundred: one workgroup, one thread per unordered pair, fp64 like scipy.  Far below the
 // size where an MFMA contraction pays (K*K*D = 75k FMAs at c3).
-__global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, int metric,
+// aux: metric-specific extra input (mahalanobis: the D x D inverse covariance VI, computed by the host like scipy does)
+__global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, int metric, const double *__restrict__ aux,
                                    double *__restrict__ C) {
     extern __shared__ double stat[];  // per-row norm (cosine) or mean + centred norm (correlation); per-dimension variance (seuclidean)
     double *nrm = stat, *mean = stat + K, *var = stat + 2 * K;
@@ -127,6 +128,53 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
             double s = 0.0;
             for (int d = 0; d < D; ++d) s += fabs(u[d] - v[d]);
             out = s;
+            break;
+        }
+        // scipy's "boolean" dissimilarities: pdist converts the rows to bool (non-zero = True) and counts agreements
+        case PILOT_OT_METRIC_JACCARD: case PILOT_OT_METRIC_YULE: case PILOT_OT_METRIC_RUSSELLRAO: case PILOT_OT_METRIC_SOKALSNEATH:
+        case PILOT_OT_METRIC_ROGERSTANIMOTO: case PILOT_OT_METRIC_SOKALMICHENER: case PILOT_OT_METRIC_KULCZYNSKI1: {
+            double ntt = 0, ntf = 0, nft = 0, nff = 0;
+            for (int d = 0; d < D; ++d) {
+                const bool a = u[d] != 0.0, b = v[d] != 0.0;
+                ntt += a && b; ntf += a && !b; nft += !a && b; nff += !a && !b;
+            }
+            const double R = ntf + nft;
+            if (metric == PILOT_OT_METRIC_JACCARD) out = (ntt + R) > 0.0 ? R / (ntt + R) : 0.0;
+            else if (metric == PILOT_OT_METRIC_YULE) { const double h = ntf * nft; out = h == 0.0 ? 0.0 : 2.0 * h / (ntt * nff + h); }
+            else if (metric == PILOT_OT_METRIC_RUSSELLRAO) out = (double(D) - ntt) / double(D);
+            else if (metric == PILOT_OT_METRIC_SOKALSNEATH) out = 2.0 * R / (ntt + 2.0 * R);
+            else if (metric == PILOT_OT_METRIC_KULCZYNSKI1) out = ntt / R;
+            else out = 2.0 * R / (ntt + nff + 2.0 * R);           // rogerstanimoto == sokalmichener
+            break;
+        }
+        case PILOT_OT_METRIC_DICE: {            // (scipy evaluates this one on the values: ntt = sum u v, ...)
+            double ntt = 0.0, nd = 0.0;
+            for (int d = 0; d < D; ++d) { ntt += u[d] * v[d]; nd += u[d] * (1.0 - v[d]) + (1.0 - u[d]) * v[d]; }
+            out = nd / (2.0 * ntt + nd);
+            break;
+        }
+        case PILOT_OT_METRIC_JENSENSHANNON: {
+            double su = 0.0, sv = 0.0;
+            bool neg = false;
+            for (int d = 0; d < D; ++d) { neg = neg || u[d] < 0.0 || v[d] < 0.0; su += u[d]; sv += v[d]; }
+            if (neg) { out = HUGE_VAL; break; }
+            double js = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double p = u[d] / su, q = v[d] / sv, m = (p + q) / 2.0;
+                if (p > 0.0) js += p * log(p / m);
+                if (q > 0.0) js += q * log(q / m);
+            }
+            out = sqrt(js / 2.0);
+            break;
+        }
+        case PILOT_OT_METRIC_MAHALANOBIS: {     // sqrt((u - v) VI (u - v)^T)
+            double s = 0.0;
+            for (int a = 0; a < D; ++a) {
+                double t = 0.0;
+                for (int b = 0; b < D; ++b) t += (u[b] - v[b]) * aux[(size_t)b * D + a];
+                s += t * (u[a] - v[a]);
+            }
+            out = sqrt(s);
             break;
         }
         default: {  // chebyshev
@@ -262,35 +310,48 @@ PILOT_API int pilot_ot_stream_sync(void *stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-PILOT_API int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric, double *d_cost,
-                                       void *stream) {
+namespace { hipError_t ws_get(int slot, size_t bytes, void **out); }    // the calling thread's pool of temporaries (below)
+
+PILOT_API int pilot_ot_cost_matrix_dev_ex(const double *d_centroids, int K, int D, int metric, const double *d_aux, double *d_cost,
+                                          void *stream) {
     if (!d_centroids || !d_cost) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (K <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "K=%d D=%d must be positive", K, D);
-    if (metric < PILOT_OT_METRIC_COSINE || metric > PILOT_OT_METRIC_HAMMING)
+    if (metric < PILOT_OT_METRIC_COSINE || metric > PILOT_OT_METRIC_MAHALANOBIS)
         return fail(PILOT_OT_EINVAL, "unknown metric id %d", metric);
+    if (metric == PILOT_OT_METRIC_MAHALANOBIS && !d_aux) return fail(PILOT_OT_EINVAL, "mahalanobis needs the D x D inverse covariance (aux)");
     if (K > 4096 || D > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d D=%d: at most 4096 centroids / dimensions", K, D);
     hipLaunchKernelGGL(cost_matrix_kernel, dim3(1), dim3(1024), sizeof(double) * (2 * K + D),
-                       static_cast<hipStream_t>(stream), d_centroids, K, D, metric, d_cost);
+                       static_cast<hipStream_t>(stream), d_centroids, K, D, metric, d_aux, d_cost);
     HIP_TRY(hipGetLastError());
     return PILOT_OT_OK;
 }
 
-PILOT_API int pilot_ot_cost_matrix(const double *centroids, int K, int D, int metric, double *cost) {
+PILOT_API int pilot_ot_cost_matrix_dev(const double *d_centroids, int K, int D, int metric, double *d_cost, void *stream) {
+    return pilot_ot_cost_matrix_dev_ex(d_centroids, K, D, metric, nullptr, d_cost, stream);
+}
+
+PILOT_API int pilot_ot_cost_matrix_ex(const double *centroids, int K, int D, int metric, const double *aux, double *cost) {
     if (!centroids || !cost) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (K <= 0 || D <= 0) return fail(PILOT_OT_EINVAL, "K=%d D=%d must be positive", K, D);
-    double *dx = nullptr, *dc = nullptr;
-    HIP_TRY(hipMalloc(&dx, sizeof(double) * K * D));
-    hipError_t e = hipMalloc(&dc, sizeof(double) * K * K);
-    if (e != hipSuccess) { (void)hipFree(dx); return fail(PILOT_OT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
-    int rc = PILOT_OT_OK;
-    if ((e = hipMemcpy(dx, centroids, sizeof(double) * K * D, hipMemcpyHostToDevice)) != hipSuccess)
-        rc = fail(PILOT_OT_EHIP, "hipMemcpy H2D: %s", hipGetErrorString(e));
-    if (rc == PILOT_OT_OK) rc = pilot_ot_cost_matrix_dev(dx, K, D, metric, dc, nullptr);
-    if (rc == PILOT_OT_OK && (e = hipMemcpy(cost, dc, sizeof(double) * K * K, hipMemcpyDeviceToHost)) != hipSuccess)
-        rc = fail(PILOT_OT_EHIP, "hipMemcpy D2H: %s", hipGetErrorString(e));
-    (void)hipFree(dx);
-    (void)hipFree(dc);
-    return rc;
+    const bool has_aux = metric == PILOT_OT_METRIC_MAHALANOBIS;
+    if (has_aux && !aux) return fail(PILOT_OT_EINVAL, "mahalanobis needs the D x D inverse covariance (aux)");
+    // staging from the calling thread's pool (slots 9 .. 11: the pre-pass calls use 0 .. 8)
+    void *dx = nullptr, *dc = nullptr, *da = nullptr;
+    HIP_TRY(ws_get(9, sizeof(double) * (size_t)K * D, &dx));
+    HIP_TRY(ws_get(10, sizeof(double) * (size_t)K * K, &dc));
+    HIP_TRY(hipMemcpy(dx, centroids, sizeof(double) * (size_t)K * D, hipMemcpyHostToDevice));
+    if (has_aux) {
+        HIP_TRY(ws_get(11, sizeof(double) * (size_t)D * D, &da));
+        HIP_TRY(hipMemcpy(da, aux, sizeof(double) * (size_t)D * D, hipMemcpyHostToDevice));
+    }
+    const int rc = pilot_ot_cost_matrix_dev_ex(static_cast<double *>(dx), K, D, metric, static_cast<double *>(da), static_cast<double *>(dc), nullptr);
+    if (rc != PILOT_OT_OK) return rc;
+    HIP_TRY(hipMemcpy(cost, dc, sizeof(double) * (size_t)K * K, hipMemcpyDeviceToHost));
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_cost_matrix(const double *centroids, int K, int D, int metric, double *cost) {
+    return pilot_ot_cost_matrix_ex(centroids, K, D, metric, nullptr, cost);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,6 +435,12 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
+    // per-pair work lists of the full grid, so that no grid call allocates (the POT-literal kernel's scratch, 2 K^2 doubles per
+    // resident workgroup, is the exception: allocated by the first call that needs that kernel)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->nan_list), sizeof(int) * (size_t)N * N);
+    if (e == hipSuccess) pl->nan_list_n = (size_t)N * N;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->flags_ws), sizeof(int) * (size_t)N * N);
+    if (e == hipSuccess) pl->flags_ws_n = (size_t)N * N;
     if (e == hipSuccess && K <= EMD_MAX_K)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
                       sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)));
@@ -875,6 +942,7 @@ ThreadCtx &tctx() {
 }
 #define g_host (tctx().host)
 #define g_ws (tctx().ws)
+hipError_t ws_get(int slot, size_t bytes, void **out) { return g_ws.get(slot, bytes, out); }
 
 int host_ctx_prepare(int N, int K, size_t n_out) {
     int dev = 0;

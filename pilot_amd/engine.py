@@ -75,10 +75,18 @@ def pdist_square(centroids, metric="cosine"):
     if X.ndim != 2:
         raise ValueError("centroids must be 2-D (K, D)")
     if metric not in _lib.METRICS:
-        raise NotImplementedError("metric %r: the device kernel implements %s" % (metric, sorted(_lib.METRICS)))
+        raise NotImplementedError("metric %r: the device kernel implements scipy's pdist names %s" % (metric, sorted(_lib.METRICS)))
     K, D = X.shape
     out = np.zeros((K, K), dtype=np.float64)
-    _lib.check(_lib.load().pilot_ot_cost_matrix(_lib.dptr(X), K, D, _lib.METRICS[metric], _lib.dptr(out)))
+    aux = None
+    if metric == "mahalanobis":
+        # scipy's own preparation (scipy/spatial/distance.py::_validate_mahalanobis_kwargs): VI = inv(cov(X^T))^T on the host
+        if K <= D:
+            raise ValueError("The number of observations (%d) is too small; the covariance matrix is singular. For observations "
+                             "with %d dimensions, at least %d observations are required." % (K, D, D + 1))
+        aux = np.ascontiguousarray(np.linalg.inv(np.atleast_2d(np.cov(X.T))).T, dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_cost_matrix_ex(_lib.dptr(X), K, D, _lib.METRICS[metric], _lib.dptr(aux) if aux is not None else None,
+                                                   _lib.dptr(out)))
     return out
 
 

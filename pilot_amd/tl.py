@@ -349,6 +349,8 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     """
     if return_sil_ari:
         _leiden_backend()      # ARI needs scanpy's Leiden clustering (Trajectory.py:108-113): refuse BEFORE any device work
+    if metric not in engine._lib.METRICS:
+        raise NotImplementedError("metric %r: the device kernel implements scipy's pdist names %s" % (metric, sorted(engine._lib.METRICS)))
     global path_to_results
     # the embedding frame first (extract_data_anno_*_from_h5ad, :234-299): its bytes start moving at once
     if data_type == "scRNA":

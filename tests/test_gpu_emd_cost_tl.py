@@ -233,6 +233,35 @@ def test_pdist_kernel_vs_scipy(metric, K, D):
     assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0)
 
 
+@pytest.mark.parametrize("metric", ["jaccard", "dice", "yule", "russellrao", "sokalsneath", "rogerstanimoto", "sokalmichener",
+                                    "kulczynski1", "jensenshannon", "mahalanobis"])
+@pytest.mark.parametrize("K,D", [(3, 2), (50, 30), (130, 7)])
+def test_pdist_kernel_vs_scipy_the_remaining_names(metric, K, D):
+    """The rest of scipy 1.15's pdist names (Trajectory.py:468 forwards any of them): the boolean dissimilarities on rows with
+    actual zeros, Jensen-Shannon on non-negative rows, Mahalanobis with scipy's own VI = inv(cov(X^T))^T (needs K > D).
+    0/0 cases must give scipy's NaN / inf, not something else."""
+    import warnings
+    rng = np.random.default_rng(K * D + len(metric))
+    X = rng.random((K, D))
+    if metric not in ("jensenshannon", "mahalanobis"):
+        X[rng.random((K, D)) < 0.45] = 0.0          # non-zero = True
+        X[0] = 0.0                                     # an all-False row: the 0/0 cases
+        if K > 2:
+            X[2] = X[1]
+    if metric == "mahalanobis" and K <= D:
+        with pytest.raises(ValueError, match="observations"):
+            engine.pdist_square(X, metric=metric)
+        with pytest.raises(ValueError, match="observations"):
+            ssd.pdist(X, metric=metric)
+        return
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ssd.squareform(ssd.pdist(X, metric=metric))
+    got = engine.pdist_square(X, metric=metric)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14, equal_nan=True)
+    assert np.all(np.diag(got) == 0)
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_cost_matrix_golden(name):
     g = load_golden(name)
@@ -343,7 +372,9 @@ def test_wasserstein_distance_default_precision_c2_shape(tmp_path, monkeypatch):
 def test_unsupported_metric_and_sil_ari_raise(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     ad = make_cells(6, 4, 3, seed=2, cells_per_patient=30)
-    with pytest.raises(NotImplementedError):
-        tl.wasserstein_distance(ad, emb_matrix="X_pca", metric="mahalanobis")
+    with pytest.raises(NotImplementedError, match="pdist names"):
+        tl.wasserstein_distance(ad, emb_matrix="X_pca", metric="wminkowski")       # (removed from scipy; a callable is not a name either)
+    assert ad.uns == {}
     with pytest.raises(NotImplementedError):
         tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized="reg", return_sil_ari=True)
+    assert ad.uns == {}
