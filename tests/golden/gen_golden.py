@@ -9,11 +9,14 @@ What is reference-executed: ``pilotpy/tools/Trajectory.py`` is imported from /ro
 ``extract_data_anno_*``, ``Cluster_Representations``, ``cost_matrix``, ``return_real_labels`` and the
 ``wasserstein_d`` double loop run on pandas/numpy/scipy.
 
-What is NOT reference-executed: the per-pair OT arithmetic.  POT is not installable here, so the
-``ot`` module the reference imports is a shim whose ``emd2`` / ``sinkhorn2`` call the CPU oracle
-(oracle/pilot_oracle.c).  The fixtures therefore pin the reference's data handling, ordering, loop
-and output layout -- and record the oracle's numbers, so a later oracle change is caught -- but do
-not pin POT itself ("parity unpinned").
+What is NOT reference-executed while POT is absent: the per-pair OT arithmetic.  A real ``ot`` (POT) is
+used whenever it can be imported; otherwise the ``ot`` module the reference imports is a shim whose
+``emd2`` / ``sinkhorn2`` call the CPU oracle (oracle/pilot_oracle.c).  Every fixture records which one
+produced its numbers in ``ot_source`` ("pot==<version>" or "oracle-shim"); the tests print it.  With the
+shim the fixtures pin the reference's data handling, ordering, loop and output layout -- and record the
+oracle's numbers, so a later oracle change is caught -- but do not pin POT itself ("parity unpinned", see
+DESIGN.md).  The day POT is importable here: regenerate, diff the capped and absorb-on-last pairs against
+the oracle, and only then call the parity pinned.
 """
 import importlib.abc
 import importlib.machinery
@@ -32,6 +35,7 @@ from oracle import oracle as O  # noqa: E402
 from pilot_amd.synthetic import make_cells  # noqa: E402
 
 REFERENCE = "/root/reference"
+OT_SOURCE = None
 MISSING = ["scanpy", "anndata", "seaborn", "pydiffmap", "sknetwork", "elpigraph", "adjustText", "gprofiler",
            "plotnine", "joypy", "shap", "rpy2", "gseapy", "leidenalg", "igraph", "statsmodels", "h5py",
            "matplotlib_venn", "networkx", "upsetplot", "pingouin"]
@@ -76,15 +80,24 @@ def import_reference():
             MISSING.remove(name)
         except Exception:
             pass
-    sys.meta_path.insert(0, _StubFinder())
-    ot = types.ModuleType("ot")          # POT shim -> CPU oracle (see module docstring)
-    ot.emd2 = lambda a, b, M, *args, **kw: O.emd2(a, b, M)
+    global OT_SOURCE
+    try:
+        import ot as real_ot                                   # the real thing, if it ever becomes available
+        if not (hasattr(real_ot, "emd2") and hasattr(real_ot, "sinkhorn2")):
+            raise ImportError("not POT")
+        OT_SOURCE = "pot==%s" % getattr(real_ot, "__version__", "unknown")
+    except Exception:
+        ot = types.ModuleType("ot")          # POT shim -> CPU oracle (see module docstring)
+        ot.emd2 = lambda a, b, M, *args, **kw: O.emd2(a, b, M)
 
-    def sinkhorn2(a, b, M, reg, method="sinkhorn", **kw):
-        assert method == "sinkhorn_stabilized", method
-        return O.sinkhorn2(a, b, M, reg)
-    ot.sinkhorn2 = sinkhorn2
-    sys.modules["ot"] = ot
+        def sinkhorn2(a, b, M, reg, method="sinkhorn", **kw):
+            assert method == "sinkhorn_stabilized", method
+            return O.sinkhorn2(a, b, M, reg)
+        ot.sinkhorn2 = sinkhorn2
+        sys.modules["ot"] = ot
+        OT_SOURCE = "oracle-shim"
+    print("ot_source:", OT_SOURCE)
+    sys.meta_path.insert(0, _StubFinder())
     sys.path.insert(0, REFERENCE)
     import pilotpy.tools.Trajectory as T
     return T
@@ -116,6 +129,7 @@ def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.
         emd_df_index_name=np.asarray(str(u["EMD_df"].index.name)),
         reg=np.asarray(reg), data_type=np.asarray(data_type), metric=np.asarray(metric), regulizer=np.asarray(regulizer),
         uns_keys=np.asarray(sorted(u.keys()), dtype=str),
+        ot_source=np.asarray(OT_SOURCE),
     )
     print(name, "N=%d K=%d C=%d" % (len(samples), len(cells), len(obs)), "EMD unreg max", u["EMD"].max(),
           "reg max", results["reg"]["EMD"].max())

@@ -116,3 +116,15 @@ def test_grid_row_selection_and_threads_are_consistent():
     full = O.sinkhorn_grid(P, M, 0.1)
     part = O.sinkhorn_grid(P, M, 0.1, row_begin=1, row_end=20, row_step=3, n_threads=3)
     np.testing.assert_array_equal(part, full[1:20:3])
+
+
+def test_golden_fixtures_record_what_produced_their_ot_numbers(capsys):
+    """Every fixture says whether a real POT or the oracle shim stood behind ``import ot`` when the reference's code ran
+    (tests/golden/gen_golden.py prefers a real POT when one can be imported).  While this prints "oracle-shim" the parity of
+    the OT arithmetic is UNPINNED; it may only be called pinned for fixtures that say "pot==...". """
+    from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, load_golden, load_golden_pack
+    sources = {name: str(load_golden(name)["ot_source"]) for name in GOLDEN_CASES + GOLDEN_OPTION_CASES}
+    sources.update({"random_pack[%d]" % i: str(g["ot_source"]) for i, g in enumerate(load_golden_pack())})
+    with capsys.disabled():
+        print("\ngolden fixtures, ot_source: %s" % sorted(set(sources.values())))
+    assert all(s == "oracle-shim" or s.startswith("pot==") for s in sources.values()), sources
