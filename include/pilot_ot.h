@@ -39,7 +39,7 @@ extern "C" {
 #define PILOT_OT_OK 0
 #define PILOT_OT_EINVAL (-1)  /* bad argument                                              */
 #define PILOT_OT_EHIP (-2)    /* HIP runtime error / no gfx950 device                      */
-#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support (K > 2048, exact OT with K > 256, ...) */
+#define PILOT_OT_ENOTSUP (-3) /* shape outside what the kernels support (K > 2048, ...) */
 #define PILOT_OT_ERCCL (-4)   /* RCCL error / librccl missing (multi-GPU entry points only) */
 
 /* precision of the Sinkhorn pair-grid kernel */

@@ -77,6 +77,8 @@ def lib() -> ctypes.CDLL:
         L.pilot_oracle_emd_grid.restype = ctypes.c_int
         L.pilot_oracle_emd_grid.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
+        L.pilot_oracle_emd_grid_fast.restype = ctypes.c_int
+        L.pilot_oracle_emd_grid_fast.argtypes = L.pilot_oracle_emd_grid.argtypes
         _lib = L
     return _lib
 
@@ -144,13 +146,15 @@ def emd2(a, b, M, return_plan=False):
     return (val, G) if return_plan else val
 
 
-def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, n_threads=1):
-    """All ordered pairs, exact OT -- Trajectory.py:507-511."""
+def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, n_threads=1, fast=False):
+    """All ordered pairs, exact OT -- Trajectory.py:507-511.  ``fast``: the quicker successive-shortest-path solver
+    (the HIP kernel's algorithm on one CPU thread; the CPU baseline of ``bench.py --mode emd``), same LP value."""
     P, M = _f64(P), _f64(M)
     N, K = P.shape
     row_end, nrows = _rows(N, row_begin, row_end, row_step)
     emd = np.zeros((nrows, N))
-    rc = lib().pilot_oracle_emd_grid(_dptr(P), N, K, _dptr(M), row_begin, row_end, row_step,
+    fn = lib().pilot_oracle_emd_grid_fast if fast else lib().pilot_oracle_emd_grid
+    rc = fn(_dptr(P), N, K, _dptr(M), row_begin, row_end, row_step,
                                      int(n_threads), _dptr(emd))
     if rc != 0:
         raise ValueError("pilot_oracle_emd_grid: bad arguments")

@@ -311,7 +311,128 @@ ORACLE_API double pilot_oracle_emd2(const double *a, const double *b_in, const d
     return cost;
 }
 
+/*
+ * The same LP value by a FASTER successive-shortest-path solver -- the algorithm of the HIP kernel (emd_kernels.hpp) restated
+ * for one CPU thread: diagonal warm start on the zero-reduced-cost arcs (i, i), multi-source searches (from every row with
+ * supply left) over column labels only (rows are reached over tight backward arcs and scanned at once), initial labels
+ * A_j = min over sources of (M_ij - pu_i) kept while the source set does not change.  One augmentation per search.
+ * Used as the CPU baseline of `bench.py --mode emd` (kind "port": POT's LEMON network simplex is not available here and
+ * would be the reference's own solver); checked against pilot_oracle_emd2 and HiGHS in tests/test_oracle_emd.py.
+ * Square problems only (na == nb == K), which is all the reference path produces.
+ */
+ORACLE_API double pilot_oracle_emd2_fast(const double *a, const double *b_in, const double *M, int K)
+{
+    double *F = (double *)calloc((size_t)K * K, sizeof(double));
+    double *w = (double *)malloc(sizeof(double) * (size_t)8 * K);
+    int *iw = (int *)malloc(sizeof(int) * (size_t)5 * K);
+    double *pu = w, *pv = w + K, *ra = w + 2 * K, *rb = w + 3 * K, *A = w + 4 * K, *dC = w + 5 * K, *fR = w + 6 * K, *fC = w + 7 * K;
+    int *Apar = iw, *parC = iw + K, *parR = iw + 2 * K, *openC = iw + 3 * K, *src = iw + 4 * K;
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < K; ++i) { sa += a[i]; sb += b_in[i]; }
+    const double tol = 1e-15 * (sa > 0 ? sa : 1.0);
+    for (int i = 0; i < K; ++i) {
+        double m = M[(size_t)i * K];
+        for (int j = 1; j < K; ++j) if (M[(size_t)i * K + j] < m) m = M[(size_t)i * K + j];
+        pu[i] = m; pv[i] = 0.0; ra[i] = a[i]; rb[i] = b_in[i] * (sa / sb);
+    }
+    for (int i = 0; i < K; ++i)
+        if (M[(size_t)i * K + i] - pu[i] == 0.0) {
+            const double f = ra[i] < rb[i] ? ra[i] : rb[i];
+            if (f > 0.0) { F[(size_t)i * K + i] = f; ra[i] -= f; rb[i] -= f; }
+        }
+    int n_src_prev = -1;
+    for (int guard = 0; guard < 64 * K + 64; ++guard) {
+        int n_src = 0, changed = 0;
+        for (int i = 0; i < K; ++i) {
+            const int is = ra[i] > tol;
+            if (is != src[i] || n_src_prev < 0) changed = 1;
+            src[i] = is; n_src += is;
+        }
+        if (!n_src) break;
+        if (changed) {
+            for (int j = 0; j < K; ++j) { A[j] = INFINITY; Apar[j] = -1; }
+            for (int i = 0; i < K; ++i) {
+                if (!src[i]) continue;
+                const double *Mi = M + (size_t)i * K;
+                for (int j = 0; j < K; ++j) { const double v = Mi[j] - pu[i]; if (v < A[j]) { A[j] = v; Apar[j] = i; } }
+            }
+        }
+        n_src_prev = n_src;
+        for (int j = 0; j < K; ++j) {
+            double rc = A[j] - pv[j]; if (rc < 0.0) rc = 0.0;
+            dC[j] = rc; fC[j] = INFINITY; parC[j] = Apar[j]; openC[j] = 1;
+            fR[j] = src[j] ? 0.0 : INFINITY; parR[j] = -1;
+        }
+        int target = -1;
+        double dstar = 0.0;
+        for (;;) {
+            int best = -1; double bd = INFINITY;
+            for (int j = 0; j < K; ++j) if (openC[j] && dC[j] < bd) { bd = dC[j]; best = j; }
+            if (best < 0) break;
+            openC[best] = 0; fC[best] = bd;
+            if (rb[best] > 0.0) { target = best; dstar = bd; break; }
+            for (int i = 0; i < K; ++i) {          /* rows that ship to this column: reduced cost 0, scanned at once */
+                if (fR[i] != INFINITY || F[(size_t)i * K + best] <= 0.0) continue;
+                fR[i] = bd; parR[i] = best;
+                const double *Mi = M + (size_t)i * K;
+                for (int j = 0; j < K; ++j) {
+                    if (!openC[j]) continue;
+                    double rc = Mi[j] - pu[i] - pv[j]; if (rc < 0.0) rc = 0.0;
+                    const double nd = bd + rc;
+                    if (nd < dC[j]) { dC[j] = nd; parC[j] = i; }
+                }
+            }
+        }
+        if (target < 0) break;                      /* only rounding dust left */
+        for (int i = 0; i < K; ++i) {
+            pu[i] -= (fR[i] < dstar ? fR[i] : dstar);
+            pv[i] += (fC[i] < dstar ? fC[i] : dstar);
+        }
+        int s_row = -1;
+        double delta = rb[target];
+        for (int j = target;;) {
+            const int i = parC[j];
+            const int jb = parR[i];
+            if (jb < 0) { s_row = i; break; }
+            if (F[(size_t)i * K + jb] < delta) delta = F[(size_t)i * K + jb];
+            j = jb;
+        }
+        if (ra[s_row] < delta) delta = ra[s_row];
+        for (int j = target;;) {
+            const int i = parC[j];
+            F[(size_t)i * K + j] += delta;
+            const int jb = parR[i];
+            if (jb < 0) break;
+            F[(size_t)i * K + jb] -= delta;
+            j = jb;
+        }
+        ra[s_row] -= delta; rb[target] -= delta;
+    }
+    double cost = 0.0;
+    for (size_t t = 0; t < (size_t)K * K; ++t) cost += F[t] * M[t];
+    free(F); free(w); free(iw);
+    return cost;
+}
+
 /* The reference's exact pair loop, Trajectory.py:507-511. */
+ORACLE_API int pilot_oracle_emd_grid_fast(const double *P, int N, int K, const double *M,
+                                          int row_begin, int row_end, int row_step, int n_threads, double *emd)
+{
+    if (N <= 0 || K <= 0 || row_step <= 0 || row_begin < 0 || row_end > N) return -1;
+    const int nrows = row_end > row_begin ? (row_end - row_begin + row_step - 1) / row_step : 0;
+    const long total = (long)nrows * N;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+#endif
+    for (long t = 0; t < total; ++t) {
+        const int i = row_begin + (int)(t / N) * row_step, j = (int)(t % N);
+        emd[t] = pilot_oracle_emd2_fast(P + (size_t)i * K, P + (size_t)j * K, M, K);
+    }
+    (void)n_threads;
+    return 0;
+}
+
 ORACLE_API int pilot_oracle_emd_grid(const double *P, int N, int K, const double *M,
                                      int row_begin, int row_end, int row_step, int n_threads,
                                      double *emd)

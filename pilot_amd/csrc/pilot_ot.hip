@@ -19,6 +19,7 @@
 #include "prepass_kernels.hpp"
 #include "cellw2_kernels.hpp"
 #include "generic_kernels.hpp"
+#include "emd_generic_kernel.hpp"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -225,6 +226,8 @@ struct pilot_ot_plan {
     size_t flags_ws_n;
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
     double *f_slab;    // exact-EMD flow values: one K*K block per resident wave
+    double *emdg_slab; // K > 256: flow + label slab per resident workgroup of emd_generic_kernel, then K row minima (lazy)
+    int emdg_wgs;
     double *kws;       // generic Sinkhorn kernel: K' and its transpose per workgroup (allocated on first use)
     int generic_wgs;
     int *nan_list;     // pairs that ended in NaN (grown on demand)
@@ -406,7 +409,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
     pl->N = N; pl->K = K;
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
-    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
+    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->emdg_slab = nullptr; pl->emdg_wgs = 0; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
@@ -463,6 +466,7 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->flags_ws) (void)hipFree(pl->flags_ws);
     if (pl->emd_counter) (void)hipFree(pl->emd_counter);
     if (pl->f_slab) (void)hipFree(pl->f_slab);
+    if (pl->emdg_slab) (void)hipFree(pl->emdg_slab);
     if (pl->kws) (void)hipFree(pl->kws);
     if (pl->nan_list) (void)hipFree(pl->nan_list);
     if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
@@ -1070,8 +1074,29 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab; p.queue = pl->emd_counter;
     HIP_TRY(hipMemsetAsync(pl->emd_counter, 0, sizeof(int), s));
     const long total = (long)n_rows * N;
-    {
-        if (K > EMD_MAX_K || !pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: K=%d > %d cell types", K, EMD_MAX_K);
+    if (K > EMD_MAX_K) {
+        // beyond the one-wave-per-pair kernel: one workgroup per pair, vectors in LDS, flows in a global slab per resident
+        // workgroup (emd_generic_kernel.hpp) -- the reference has no limit on the number of cell types
+        if (K > pilot::EMDG_MAX_K) return fail(PILOT_OT_ENOTSUP, "exact OT: K=%d > %d cell types", K, pilot::EMDG_MAX_K);
+        const size_t per_wg = sizeof(double) * pilot::emdg_slab_doubles(K);
+        const long n_items = p.upper_only ? (long)n_rows * (N - row_begin) - (long)row_step * n_rows * (n_rows - 1) / 2 : total;
+        long wgs = 2L * pl->n_cu;
+        while (wgs > 1 && per_wg * (size_t)wgs > ((size_t)8 << 30)) wgs /= 2;
+        if (!pl->emdg_slab || pl->emdg_wgs < wgs) {          // (first call that needs this kernel: the one allocation of the path)
+            if (pl->emdg_slab) HIP_TRY(hipFree(pl->emdg_slab));
+            pl->emdg_slab = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->emdg_slab), per_wg * (size_t)wgs + sizeof(double) * (size_t)K));
+            pl->emdg_wgs = (int)wgs;
+        }
+        if (wgs > n_items) wgs = n_items > 0 ? n_items : 1;
+        double *rowmin = pl->emdg_slab + pilot::emdg_slab_doubles(K) * (size_t)pl->emdg_wgs;
+        hipLaunchKernelGGL(pilot::emd_rowmin_kernel, dim3((K + 255) / 256), dim3(256), 0, s, d_M, K, rowmin);
+        p.f_slab = pl->emdg_slab;
+        const size_t lds = pilot::emdg_lds_bytes(K);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::emd_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pilot::emd_generic_kernel, dim3((unsigned)wgs), dim3(pilot::EMDG_WG), lds, s, p, rowmin);
+    } else {
+        if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
         const size_t lds = K > 128 ? sizeof(double) * (size_t)K : sizeof(double) * ((size_t)K * K + K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
         const int waves = pilot::emd_waves(emd_nk(K));

@@ -49,6 +49,27 @@ def test_emd_every_k_regime(K):
     assert np.abs(Eg - Eo).max() <= 1e-12
 
 
+@pytest.mark.parametrize("K", [257, 300, 520])
+def test_emd_beyond_256_cell_types_runs_the_workgroup_kernel(K):
+    """The reference's ot.emd2 loop has no limit on the number of cell types (Trajectory.py:507-511): beyond the
+    one-wave-per-pair kernel's 256 a pair is solved by one workgroup (emd_generic_kernel.hpp).  Same LP value as the oracle;
+    the symmetric shortcut (upper triangle + mirror), row shards and sparse / non-symmetric inputs included."""
+    P, M = make_problem(7, K, 5, seed=K, cells_per_patient=4000)
+    Eo = O.emd_grid(P, M, n_threads=16, fast=True)
+    Eg, info = engine.emd_grid(P, M, return_info=True)                # auto: symmetric cost -> upper triangle + mirror
+    assert np.abs(Eg - Eo).max() <= 1e-12 and (info["n_aug"] >= 0).all()
+    Ea = engine.emd_grid(P, M, mode="all")
+    assert np.abs(Ea - Eo).max() <= 1e-12
+    np.testing.assert_array_equal(engine.emd_grid(P, M, mode="all", row_begin=2, row_end=7, row_step=3), Ea[2:7:3])      # row shards: same bits
+    rng = np.random.default_rng(K)
+    Mn = rng.random((K, K))
+    Ps = P.copy()
+    Ps[rng.random(P.shape) < 0.6] = 0.0
+    Ps[:, 0] += 1e-3
+    Ps /= Ps.sum(1, keepdims=True)
+    assert np.abs(engine.emd_grid(Ps, Mn) - O.emd_grid(Ps, Mn, n_threads=16, fast=True)).max() <= 1e-12
+
+
 def test_emd_nonsymmetric_cost_and_sparse_histograms():
     rng = np.random.default_rng(8)
     K = 24

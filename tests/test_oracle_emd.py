@@ -69,3 +69,27 @@ def test_golden_unreg_matrix_is_reproduced(name):
     E = O.emd_grid(P, M, n_threads=4)
     np.testing.assert_allclose(E, g["emd_unreg"], rtol=0, atol=1e-14)
     np.testing.assert_array_equal(g["emd_unreg_df"], g["emd_unreg"].T)
+
+
+def test_fast_solver_of_the_cpu_baseline_returns_the_same_lp_value():
+    """oracle.emd_grid(fast=True) -- the HIP kernel's algorithm on one CPU thread, what `bench.py --mode emd` times as its CPU
+    baseline -- against the plain oracle solver and against HiGHS: random non-symmetric costs, sparse histograms, ties."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(11)
+    for K in (1, 2, 3, 8, 21, 50):
+        P = rng.random((7, K))
+        P[rng.random((7, K)) < 0.35] = 0.0
+        P[:, 0] += 0.05
+        P /= P.sum(1, keepdims=True)
+        M = np.round(rng.random((K, K)) * 8) / 8 if K % 2 else rng.random((K, K))       # (quantised: many ties)
+        slow, fast = O.emd_grid(P, M), O.emd_grid(P, M, fast=True)
+        assert np.abs(slow - fast).max() <= 1e-13
+        if K <= 21:
+            A = np.zeros((2 * K, K * K))
+            for i in range(K):
+                A[i, i * K:(i + 1) * K] = 1.0
+                A[K + i, i::K] = 1.0
+            res = linprog(M.ravel(), A_eq=A, b_eq=np.concatenate([P[0], P[3]]), bounds=(0, None), method="highs")
+            assert abs(res.fun - fast[0, 3]) <= 1e-10
+    Pc, Mc = make_problem(**CONFIGS["c2"])
+    assert np.abs(O.emd_grid(Pc, Mc, row_end=3) - O.emd_grid(Pc, Mc, row_end=3, fast=True)).max() <= 1e-13
