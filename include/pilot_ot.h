@@ -292,6 +292,19 @@ int pilot_ot_row_distances_dev(const double *d_E, int N, int normalize_by_max, i
                                double *d_max_scratch /* 8 bytes, needed when normalize_by_max */, void *stream);
 int pilot_ot_silhouette(const double *D, const int *labels, int N, int n_clusters, double *score, double *samples);
 int pilot_ot_knn_kernel(const double *D, int N, int k, double epsilon, double *Kmat);
+/* device-resident forms: device pointers + a stream, nothing allocated, nothing synchronised.  d_sizes_scratch: n_clusters
+ * ints; d_samples: N doubles (silhouette_samples; the score is their mean).  knn_kernel keeps EXACTLY k entries per row
+ * (rows tied at the k-th distance in index order). */
+int pilot_ot_silhouette_dev(const double *d_D, const int *d_labels, int N, int n_clusters, int *d_sizes_scratch,
+                            double *d_samples, void *stream);
+int pilot_ot_knn_kernel_dev(const double *d_D, int N, int k, double epsilon, double *d_Kmat, void *stream);
+/* fused chains: the matrix goes to the device once (E_is_device != 0: it is there already, e.g. the pair grid's output or
+ * pilot_ot_multi_device_matrix), the N x N row distances never leave it.
+ * silhouette_of_rows       = Sil_computing(E [/ max(E)], labels, metric)                    (Trajectory.py:592-612, ploting.py:324)
+ * diffusion_kernel_of_rows = E / max(E) -> Euclidean row distances -> k-nn Gaussian kernel   (ploting.py:95-110); D_out nullable */
+int pilot_ot_silhouette_of_rows(const double *E, int E_is_device, int N, int normalize_by_max, int metric, const int *labels,
+                                int n_clusters, double *score, double *samples);
+int pilot_ot_diffusion_kernel_of_rows(const double *E, int E_is_device, int N, int k, double epsilon, double *D_out, double *Kmat);
 
 /* ---- cell-level W2 pair grid (EXTENSION: not in the reference; BASELINE config 5) ------ */
 /* Compares patients by their raw cell clouds instead of cell-type proportions.  X: n_cells x D float32 embedding

@@ -37,6 +37,7 @@ SYMBOLS = [
     "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
     "pilot_ot_mirror_upper_dev",
     "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
+    "pilot_ot_silhouette_dev", "pilot_ot_knn_kernel_dev", "pilot_ot_silhouette_of_rows", "pilot_ot_diffusion_kernel_of_rows",
     "pilot_ot_multi_create", "pilot_ot_multi_destroy", "pilot_ot_multi_set_inputs", "pilot_ot_multi_sinkhorn",
     "pilot_ot_multi_emd", "pilot_ot_multi_sync", "pilot_ot_multi_fetch", "pilot_ot_multi_device_matrix",
     "pilot_ot_multi_times", "pilot_ot_multi_rccl_info", "pilot_ot_sinkhorn_grid_multi", "pilot_ot_emd_grid_multi",
@@ -116,6 +117,10 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_row_distances_dev.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]
     L.pilot_ot_silhouette.argtypes = [dp, ip, c_int, c_int, dp, dp]
     L.pilot_ot_knn_kernel.argtypes = [dp, c_int, c_int, c_dbl, dp]
+    L.pilot_ot_silhouette_dev.argtypes = [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]
+    L.pilot_ot_knn_kernel_dev.argtypes = [c_vp, c_int, c_int, c_dbl, c_vp, c_vp]
+    L.pilot_ot_silhouette_of_rows.argtypes = [c_vp, c_int, c_int, c_int, c_int, ip, c_int, dp, dp]
+    L.pilot_ot_diffusion_kernel_of_rows.argtypes = [c_vp, c_int, c_int, c_int, c_dbl, dp, dp]
     L.pilot_ot_multi_create.argtypes = [c_int, c_int, ip, c_int, c_int, ctypes.POINTER(c_vp)]
     L.pilot_ot_multi_destroy.argtypes = [c_vp]
     L.pilot_ot_multi_set_inputs.argtypes = [c_vp, dp, dp]

@@ -71,17 +71,26 @@ row_distance_kernel(const double *__restrict__ X, int N, int metric, const doubl
 
 // sklearn.metrics.silhouette_samples on a precomputed distance matrix: for sample i, a = mean distance to the other members
 // of its cluster, b = smallest mean distance to another cluster, s = (b - a) / max(a, b), 0 for a singleton cluster.
-// One workgroup per sample; per-cluster sums in LDS (n_clusters <= 4096).  s_out[i] = s_i; the host averages.
+// One workgroup per sample.  The row and the labels are staged in LDS; thread c then adds up cluster c's distances IN INDEX
+// ORDER -- the order of sklearn's np.bincount(labels, weights=row) -- so the sums are reproducible bit for bit (LDS float
+// atomics would make them depend on the arrival order).  LDS: N doubles + N ints + C doubles.  s_out[i] = s_i.
 static __global__ void silhouette_kernel(const double *__restrict__ D, const int *__restrict__ labels, const int *__restrict__ sizes,
                                          int N, int C, double *__restrict__ s_out) {
-    extern __shared__ double csum[];          // C per-cluster distance sums
+    extern __shared__ double sil_smem[];
+    double *row = sil_smem, *csum = row + N;
+    int *lab = reinterpret_cast<int *>(csum + C);
     const int i = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) csum[c] = 0.0;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) { row[j] = D[(size_t)i * N + j]; lab[j] = labels[j]; }
     __syncthreads();
-    for (int j = threadIdx.x; j < N; j += blockDim.x) atomicAdd(&csum[labels[j]], D[(size_t)i * N + j]);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0;
+        if (sizes[c] > 0)
+            for (int j = 0; j < N; ++j) if (lab[j] == c) s += row[j];       // (LDS broadcast reads)
+        csum[c] = s;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int li = labels[i];
+        const int li = lab[i];
         double s = 0.0;
         if (sizes[li] > 1) {
             const double a = csum[li] / (sizes[li] - 1);
@@ -95,11 +104,15 @@ static __global__ void silhouette_kernel(const double *__restrict__ D, const int
     }
 }
 
-// Row i of the k-nearest-neighbour Gaussian kernel: Kmat[i][j] = exp(-D[i][j]^2 / (4 epsilon)) for the k smallest D[i][.]
+// Row i of the k-nearest-neighbour Gaussian kernel: Kmat[i][j] = exp(-D[i][j]^2 / (4 epsilon)) for the k nearest rows of row i
 // (the point itself, at distance 0, counts as its own first neighbour, as in sklearn's kneighbors_graph on the fitted
-// data), 0 elsewhere.  One workgroup per row: the k-th smallest value by a bitonic sort of the row in LDS.
+// data), 0 elsewhere.  EXACTLY k entries per row, like sklearn's kneighbors: rows tied at the k-th distance are taken in
+// index order (sklearn's own choice among exact ties is whatever its partial sort leaves -- unspecified; the smallest
+// indices are a fixed, reproducible choice of the same size).  One workgroup per row: the k-th smallest value by a bitonic
+// sort of the row in LDS, then the ties counted in index order.
 static __global__ void knn_kernel_kernel(const double *__restrict__ D, int N, int NP2, int k, double epsilon, double *__restrict__ Kmat) {
     extern __shared__ double srt[];           // NP2 (next power of two >= N), padded with +inf
+    __shared__ int tie_room;
     const int i = blockIdx.x;
     for (int t = threadIdx.x; t < NP2; t += blockDim.x) srt[t] = t < N ? D[(size_t)i * N + t] : __builtin_inf();
     __syncthreads();
@@ -113,10 +126,38 @@ static __global__ void knn_kernel_kernel(const double *__restrict__ D, int N, in
             }
             __syncthreads();
         }
-    const double thr = srt[k - 1 < N ? k - 1 : N - 1];
+    const int kk = k - 1 < N ? k - 1 : N - 1;
+    const double thr = srt[kk];
+    if (threadIdx.x == 0) {                    // entries strictly below the k-th value: the first position of thr in the sorted row
+        int lo = 0, hi = kk;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (srt[mid] < thr) lo = mid + 1; else hi = mid; }
+        tie_room = kk + 1 - lo;                // how many entries EQUAL to thr belong to the k nearest
+    }
+    __syncthreads();
+    const int room = tie_room;
+    // ties in index order: a tied entry j is kept when fewer than `room` tied entries precede it.  Wave 0 walks the row in
+    // chunks of 64 with a ballot prefix count (N <= a few thousand: a handful of iterations).
+    if (threadIdx.x < 64) {
+        int seen = 0;
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int j = j0 + (int)threadIdx.x;
+            const double d = j < N ? D[(size_t)i * N + j] : __builtin_inf();
+            const bool tie = j < N && d == thr;
+            const unsigned long long m = __ballot(tie);
+            const int rank = seen + (int)__popcll(m & ((1ull << threadIdx.x) - 1ull));
+            if (j < N) Kmat[(size_t)i * N + j] = (d < thr || (tie && rank < room)) ? exp(-d * d / (4.0 * epsilon)) : 0.0;
+            seen += (int)__popcll(m);
+        }
+    }
+}
+
+// per-cluster sizes from the labels (one workgroup; N <= a few thousand)
+static __global__ void label_sizes_kernel(const int *__restrict__ labels, int N, int C, int *__restrict__ sizes) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sizes[c] = 0;
+    __syncthreads();
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
-        const double d = D[(size_t)i * N + j];
-        Kmat[(size_t)i * N + j] = d <= thr ? exp(-d * d / (4.0 * epsilon)) : 0.0;
+        const int l = labels[j];
+        if (l >= 0 && l < C) atomicAdd(&sizes[l], 1);
     }
 }
 

@@ -474,7 +474,7 @@ __device__ inline void split_panel(const typename C::acc_t (&IN)[RT], SplitPanel
 template <class C, int RT, int TP = C::NP>
 __device__ inline typename C::acc_t split_tile_product(const typename C::T *form, int lane, int t, const SplitPanel<RT, C::NP> &B,
                                                        typename C::acc_t acc) {
-    constexpr int KB = split_kblocks(RT), NP = C::NP;
+    constexpr int KB = split_kblocks(RT);
     const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {

@@ -348,6 +348,12 @@ class DevicePlan:
     def sync(self, stream=None):
         _lib.check(self.L.pilot_ot_stream_sync(ctypes.c_void_p(stream) if stream else None))
 
+    def device_matrix(self):
+        """The N x N result of the last full-grid run as it sits in HBM (sync first), for the device-side consumers."""
+        if self.n_rows_max != self.N:
+            raise ValueError("the plan holds a row shard, not the full matrix")
+        return DeviceMatrix(self.dE, self.N, owner=self)
+
     def fetch(self, n_rows=None):
         n_rows = self.n_rows_max if n_rows is None else n_rows
         n = n_rows * self.N
@@ -446,6 +452,59 @@ def silhouette_precomputed(D, labels, return_samples=False):
     _lib.check(_lib.load().pilot_ot_silhouette(_lib.dptr(D), _lib.iptr(codes), D.shape[0], len(uniq), ctypes.byref(score),
                                                _lib.dptr(samples)))
     return (score.value, samples) if return_samples else score.value
+
+
+def _label_codes(labels, n):
+    uniq, codes = np.unique(np.asarray(labels), return_inverse=True)
+    if codes.shape != (n,):
+        raise ValueError("one label per sample expected")
+    return np.ascontiguousarray(codes, dtype=np.int32), len(uniq)
+
+
+def _matrix_arg(E):
+    """(pointer, is_device, N) of a square matrix given as a numpy array or as a device-resident result (DeviceMatrix)."""
+    if isinstance(E, DeviceMatrix):
+        return ctypes.c_void_p(E.ptr), 1, E.N, None
+    E = _as_f64(E, "E")
+    if E.ndim != 2 or E.shape[0] != E.shape[1]:
+        raise ValueError("E must be square, got %s" % (E.shape,))
+    return ctypes.c_void_p(E.ctypes.data), 0, E.shape[0], E
+
+
+class DeviceMatrix:
+    """An N x N fp64 matrix that lives in HBM (e.g. ``DevicePlan.device_matrix()`` after a full-grid run, or
+    ``multi.MultiPlan.device_matrix()``): the consumers below take it without a trip through host memory."""
+
+    def __init__(self, ptr, N, owner=None):
+        self.ptr = int(ptr.value if isinstance(ptr, ctypes.c_void_p) else ptr)
+        self.N = int(N)
+        self.owner = owner            # keeps the allocation alive
+
+
+def silhouette_of_rows(E, labels, metric="cosine", normalize_by_max=False, return_samples=False):
+    """``sklearn.metrics.silhouette_score(E, labels, metric=metric)`` with the ROWS of E as the points -- what
+    ``Sil_computing`` does (pilotpy/tools/Trajectory.py:592-612): row distances and silhouette chained on the device, only the
+    N per-sample scores come back.  E: numpy array or :class:`DeviceMatrix`."""
+    ptr, on_dev, N, keep = _matrix_arg(E)
+    if metric not in _lib.ROW_METRICS:
+        raise NotImplementedError("row metric %r: the device kernel implements %s" % (metric, sorted(_lib.ROW_METRICS)))
+    codes, n_clusters = _label_codes(labels, N)
+    score = ctypes.c_double(0.0)
+    samples = np.empty(N, dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_silhouette_of_rows(ptr, on_dev, N, int(bool(normalize_by_max)), _lib.ROW_METRICS[metric],
+                                                       _lib.iptr(codes), n_clusters, ctypes.byref(score), _lib.dptr(samples)))
+    return (score.value, samples) if return_samples else score.value
+
+
+def diffusion_kernel_of_rows(E, k=64, epsilon=1.0, return_distances=True):
+    """The dense part of ``pl.trajectory`` (pilotpy/plot/ploting.py:95-110) chained on the device: E / E.max() -> Euclidean row
+    distances -> pydiffmap's k-nearest-neighbour Gaussian kernel.  Returns ``(D, Kmat)`` (``D`` None unless asked for)."""
+    ptr, on_dev, N, keep = _matrix_arg(E)
+    D = np.empty((N, N), dtype=np.float64) if return_distances else None
+    Kmat = np.empty((N, N), dtype=np.float64)
+    _lib.check(_lib.load().pilot_ot_diffusion_kernel_of_rows(ptr, on_dev, N, int(k), float(epsilon),
+                                                             _lib.dptr(D) if D is not None else None, _lib.dptr(Kmat)))
+    return D, Kmat
 
 
 def knn_gaussian_kernel(D, k=64, epsilon=1.0):

@@ -82,6 +82,13 @@ class MultiPlan:
         _lib.check(self.L.pilot_ot_multi_fetch(self.h, _lib.dptr(E), _lib.iptr(iters), _lib.dptr(err), _lib.iptr(flags)))
         return E, dict(iters=iters, err=err, flags=flags)
 
+    def device_matrix(self, shard=0):
+        """The assembled N x N matrix as it sits in the HBM of ``shard``'s device (every shard with the RCCL gather, shard 0
+        with peer copies); sync first.  Input of the device-side consumers (``engine.silhouette_of_rows`` ...)."""
+        p = ctypes.c_void_p()
+        _lib.check(self.L.pilot_ot_multi_device_matrix(self.h, int(shard), ctypes.byref(p)))
+        return engine.DeviceMatrix(p, self.N, owner=self)
+
     def rccl_info(self):
         """(n_ranks, rank) per shard as RCCL reports them (ncclCommCount / ncclCommUserRank); (0, -1) with the peer-copy gather."""
         n = np.zeros(self.G, dtype=np.int32)

@@ -323,17 +323,16 @@ def Clustering(EMD, df, category="status", sample_col=1, res=0.01, metric="cosin
 def Sil_computing(EMD, real_labels, metric="cosine"):
     """Silhouette score of a labelling of the samples, the rows of ``EMD`` being the points (Trajectory.py:592-612:
     ``sklearn.metrics.silhouette_score(EMD, real_labels, metric=metric)``; callers pass ``EMD / EMD.max()``,
-    plot/ploting.py:324).  Row-to-row distances and the score are computed on the device; metric "cosine" or "euclidean"."""
-    D = engine.row_distances(EMD, metric=metric)
-    return engine.silhouette_precomputed(D, real_labels)
+    plot/ploting.py:324).  Row-to-row distances and the score are chained on the device (the matrix goes up once, N per-sample
+    scores come back); metric "cosine" or "euclidean".  ``EMD`` may also be an ``engine.DeviceMatrix`` (a result still in HBM)."""
+    return engine.silhouette_of_rows(EMD, real_labels, metric=metric)
 
 
 def diffusion_kernel(adata, epsilon=1, knn=64):
     """The dense part of ``pl.trajectory`` (plot/ploting.py:95-110): ``EMD / EMD.max()``, Euclidean distances between its
     rows, and pydiffmap's k-nearest-neighbour Gaussian kernel ``exp(-d^2 / (4 epsilon))``, all on the device.  Returns
     ``(EMD_normalised_row_distances, kernel_matrix)``; the eigen-decomposition stays with pydiffmap / scipy."""
-    D = engine.row_distances(adata.uns["EMD"], metric="euclidean", normalize_by_max=True)
-    return D, engine.knn_gaussian_kernel(D, k=knn, epsilon=epsilon)
+    return engine.diffusion_kernel_of_rows(adata.uns["EMD"], k=knn, epsilon=epsilon)
 
 
 def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", sample_col="sampleID",

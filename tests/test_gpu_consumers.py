@@ -98,3 +98,49 @@ def test_precomputed_distance_fills_the_uns_contract(name, tmp_path, monkeypatch
     df["sampleID"] = ad2.uns["proportions"].keys()
     df["status"] = list(ad2.uns["real_labels"])
     assert E.max() == 1.0 and df.shape == (len(ad2.uns["real_labels"]), len(ad2.uns["real_labels"]) + 2)
+
+
+def test_consumers_take_the_matrix_where_the_pair_grid_left_it():
+    """pair grid -> row distances -> silhouette / diffusion kernel without the N x N matrix ever visiting host memory: the
+    plan's (and the multi-device plan's) result in HBM is handed to the fused chains as an engine.DeviceMatrix.  Same bits as
+    the host-array route."""
+    from pilot_amd import multi
+    P, M = make_problem(**CONFIGS["c2"])
+    labels = np.arange(100) % 3
+    plan = engine.DevicePlan(P, M)
+    plan.run(0.1)
+    plan.sync()
+    E = plan.fetch()[0]
+    dm = plan.device_matrix()
+    for metric in ("cosine", "euclidean"):
+        host = engine.silhouette_of_rows(E, labels, metric=metric, normalize_by_max=True, return_samples=True)
+        dev = engine.silhouette_of_rows(dm, labels, metric=metric, normalize_by_max=True, return_samples=True)
+        assert host[0] == dev[0]
+        np.testing.assert_array_equal(host[1], dev[1])
+        assert abs(host[0] - silhouette_score(E / E.max(), labels, metric=metric)) <= 1e-12
+    Dh, Kh = engine.diffusion_kernel_of_rows(E, k=9, epsilon=0.7)
+    Dd, Kd = engine.diffusion_kernel_of_rows(dm, k=9, epsilon=0.7)
+    np.testing.assert_array_equal(Dh, Dd)
+    np.testing.assert_array_equal(Kh, Kd)
+    plan.close()
+    mp = multi.MultiPlan(P, M, devices=[0, 0, 0])
+    mp.sinkhorn(0.1)
+    mp.sync()
+    assert engine.silhouette_of_rows(mp.device_matrix(), labels, metric="cosine", normalize_by_max=True) == \
+        engine.silhouette_of_rows(E, labels, metric="cosine", normalize_by_max=True)
+    mp.close()
+
+
+def test_knn_kernel_keeps_exactly_k_entries_when_distances_tie():
+    """sklearn's kneighbors returns exactly k neighbours; among rows tied at the k-th distance this kernel takes the smallest
+    indices (a fixed choice where sklearn's partial sort leaves the choice open)."""
+    N, k = 12, 5
+    D = np.ones((N, N))
+    np.fill_diagonal(D, 0.0)                  # every other point at distance 1: an 11-way tie for 4 places
+    D[3, 7] = D[7, 3] = 0.5
+    Kmat = engine.knn_gaussian_kernel(D, k=k, epsilon=1.0)
+    assert ((Kmat > 0).sum(1) == k).all()
+    want0 = np.zeros(N); want0[[0, 1, 2, 3, 4]] = np.exp(-D[0, [0, 1, 2, 3, 4]] ** 2 / 4.0)
+    np.testing.assert_allclose(Kmat[0], want0, atol=1e-15)
+    assert set(np.flatnonzero(Kmat[3])) == {3, 7, 0, 1, 2}            # itself, the closer one, then ties in index order
+    assert set(np.flatnonzero(Kmat[11])) == {11, 0, 1, 2, 3}
