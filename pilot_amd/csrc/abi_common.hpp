@@ -12,6 +12,9 @@ namespace pilot {
 int abi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // release every cached multi-GPU context of the host-buffer entry points (called by pilot_ot_shutdown)
 void abi_multi_release();
+// a buffer of the calling thread's pool of device temporaries (grown on demand, released by pilot_ot_shutdown); slots 0 .. 11
+// belong to pilot_ot.hip, 12 .. 19 to pilot_ot_consumers.hip
+hipError_t ws_buffer(int slot, size_t bytes, void **out);
 // cell-level cohort, internal face used by the multi-device form (pilot_ot_multi.hip)
 int cell_enqueue_rows(pilot_ot_cell_cohort *c, double scale, double reg, int num_iter_max, double stop_thr, int check_period,
                       double f32_floor_ulps, int row_begin, int row_end, int row_step, size_t *n_out);

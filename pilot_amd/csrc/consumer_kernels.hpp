@@ -16,57 +16,86 @@
 
 namespace pilot {
 
-// max of a buffer -> out[0] (one workgroup; N*N <= a few million)
+// max of a buffer of non-negative doubles -> out[0] (preset to 0): the bit patterns of non-negative doubles order like
+// unsigned integers, so the per-workgroup maxima meet in one atomicMax on the 64-bit pattern.  (A distance matrix; a
+// negative entry can only lose against the preset 0, like in max(E) of a matrix with a zero diagonal.)
 static __global__ void max_reduce_kernel(const double *__restrict__ X, long n, double *__restrict__ out) {
     __shared__ double part[256];
-    double m = -__builtin_inf();
-    for (long t = threadIdx.x; t < n; t += blockDim.x) m = X[t] > m ? X[t] : m;
+    double m = 0.0;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) m = X[t] > m ? X[t] : m;
     part[threadIdx.x] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) part[threadIdx.x] = part[threadIdx.x] > part[threadIdx.x + s] ? part[threadIdx.x] : part[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = part[0];
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(part[0]));
 }
 
 // D[i][j] = distance between rows i and j of X (N x N) * scale, scale = 1 / *inv_scale_src when given (EMD / EMD.max()).
 // metric 0: Euclidean, accumulated as sum (x_ik - x_jk)^2 (no Gram cancellation, matches scipy cdist);
 // metric 1: cosine, 1 - x.y / (|x| |y|), clipped to [0, 2], exact 0 on the diagonal (sklearn cosine_distances).
-// One 16 x 16 output tile per 256-thread workgroup, k swept through LDS in chunks of 32.
-constexpr int RD_TILE = 16, RD_KC = 32;
-static __global__ void __launch_bounds__(RD_TILE * RD_TILE)
+// An N x N x N contraction in fp64 (8e9 multiply-adds at N = 2000; the f64 matrix pipe has the vector pipe's rate, so this is a
+// vector kernel): one 64 x 64 output tile per 256-thread workgroup, 4 x 4 outputs per thread (rows ti + 16 a, columns
+// tj + 16 b: conflict-free LDS reads, 8 operands for 16 multiply-adds), k swept through LDS in chunks of 16.  Every output is
+// accumulated over k in index order, whatever the tiling.
+constexpr int RD_TILE = 64, RD_KC = 16, RD_T = 16, RD_R = 4;
+static __global__ void __launch_bounds__(RD_T * RD_T)
 row_distance_kernel(const double *__restrict__ X, int N, int metric, const double *__restrict__ max_src, double *__restrict__ D) {
-    __shared__ double A[RD_TILE][RD_KC + 1], B[RD_TILE][RD_KC + 1];
-    const int ti = threadIdx.x / RD_TILE, tj = threadIdx.x % RD_TILE;
+    __shared__ double A[RD_KC][RD_TILE + 1], B[RD_KC][RD_TILE + 1];          // [k][row]: a thread's 4 rows are 16 apart
+    const int ti = threadIdx.x / RD_T, tj = threadIdx.x % RD_T;
     const int i0 = blockIdx.y * RD_TILE, j0 = blockIdx.x * RD_TILE;
     const double scale = max_src ? 1.0 / max_src[0] : 1.0;
-    double acc = 0.0, na = 0.0, nb = 0.0;
+    double acc[RD_R][RD_R], na[RD_R], nb[RD_R];
+#pragma unroll
+    for (int a = 0; a < RD_R; ++a) {
+        na[a] = 0.0; nb[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b < RD_R; ++b) acc[a][b] = 0.0;
+    }
     for (int k0 = 0; k0 < N; k0 += RD_KC) {
-        for (int t = threadIdx.x; t < RD_TILE * RD_KC; t += RD_TILE * RD_TILE) {
-            const int r = t / RD_KC, k = t % RD_KC;
-            A[r][k] = (i0 + r < N && k0 + k < N) ? X[(size_t)(i0 + r) * N + k0 + k] * scale : 0.0;
-            B[r][k] = (j0 + r < N && k0 + k < N) ? X[(size_t)(j0 + r) * N + k0 + k] * scale : 0.0;
+        for (int t = threadIdx.x; t < RD_TILE * RD_KC; t += RD_T * RD_T) {
+            const int r = t / RD_KC, k = t % RD_KC;                          // (consecutive threads: consecutive k of one row)
+            A[k][r] = (i0 + r < N && k0 + k < N) ? X[(size_t)(i0 + r) * N + k0 + k] * scale : 0.0;
+            B[k][r] = (j0 + r < N && k0 + k < N) ? X[(size_t)(j0 + r) * N + k0 + k] * scale : 0.0;
         }
         __syncthreads();
-#pragma unroll 8
+#pragma unroll 4
         for (int k = 0; k < RD_KC; ++k) {
-            const double a = A[ti][k], b = B[tj][k];
-            if (metric == 0) { const double d = a - b; acc += d * d; }
-            else { acc += a * b; na += a * a; nb += b * b; }
+            double av[RD_R], bv[RD_R];
+#pragma unroll
+            for (int a = 0; a < RD_R; ++a) { av[a] = A[k][ti + RD_T * a]; bv[a] = B[k][tj + RD_T * a]; }
+            if (metric == 0) {
+#pragma unroll
+                for (int a = 0; a < RD_R; ++a)
+#pragma unroll
+                    for (int b = 0; b < RD_R; ++b) { const double d = av[a] - bv[b]; acc[a][b] += d * d; }
+            } else {
+#pragma unroll
+                for (int a = 0; a < RD_R; ++a) {
+                    na[a] += av[a] * av[a]; nb[a] += bv[a] * bv[a];
+#pragma unroll
+                    for (int b = 0; b < RD_R; ++b) acc[a][b] += av[a] * bv[b];
+                }
+            }
         }
         __syncthreads();
     }
-    const int i = i0 + ti, j = j0 + tj;
-    if (i < N && j < N) {
-        double out;
-        if (metric == 0) out = sqrt(acc);
-        else {
-            out = 1.0 - acc / (sqrt(na) * sqrt(nb));
-            out = out < 0.0 ? 0.0 : (out > 2.0 ? 2.0 : out);
+#pragma unroll
+    for (int a = 0; a < RD_R; ++a)
+#pragma unroll
+        for (int b = 0; b < RD_R; ++b) {
+            const int i = i0 + ti + RD_T * a, j = j0 + tj + RD_T * b;
+            if (i < N && j < N) {
+                double out;
+                if (metric == 0) out = sqrt(acc[a][b]);
+                else {
+                    out = 1.0 - acc[a][b] / (sqrt(na[a]) * sqrt(nb[b]));
+                    out = out < 0.0 ? 0.0 : (out > 2.0 ? 2.0 : out);
+                }
+                D[(size_t)i * N + j] = i == j ? 0.0 : out;
+            }
         }
-        D[(size_t)i * N + j] = i == j ? 0.0 : out;
-    }
 }
 
 // sklearn.metrics.silhouette_samples on a precomputed distance matrix: for sample i, a = mean distance to the other members

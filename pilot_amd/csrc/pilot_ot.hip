@@ -860,7 +860,7 @@ namespace {
 // millisecond a pair and hipFree synchronises the device: nine of them were most of a 22 ms medians call); released by
 // pilot_ot_shutdown().  Slot i of the pool backs the i-th DevBuf a call declares.
 struct WsPool {
-    static constexpr int SLOTS = 12;
+    static constexpr int SLOTS = 20;
     void *p[SLOTS] = {};
     size_t cap[SLOTS] = {};
     int device = -1;
@@ -947,6 +947,11 @@ ThreadCtx &tctx() {
 #define g_host (tctx().host)
 #define g_ws (tctx().ws)
 hipError_t ws_get(int slot, size_t bytes, void **out) { return g_ws.get(slot, bytes, out); }
+}  // namespace
+namespace pilot {
+hipError_t ws_buffer(int slot, size_t bytes, void **out) { return ws_get(slot, bytes, out); }
+}  // namespace pilot
+namespace {
 
 int host_ctx_prepare(int N, int K, size_t n_out) {
     int dev = 0;

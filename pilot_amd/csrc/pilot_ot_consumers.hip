@@ -13,10 +13,12 @@
 #define fail(...) pilot::abi_fail(__VA_ARGS__)
 
 namespace {
+// temporaries of the host entry points: slots 12 .. 19 of the calling thread's pool (no hipMalloc / hipFree per call)
 struct DevMem {
     void *p = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    ~DevMem() { if (p) (void)hipFree(p); }
+    int slot;
+    explicit DevMem(int slot_) : slot(slot_) {}
+    hipError_t alloc(size_t bytes) { return pilot::ws_buffer(slot, bytes ? bytes : 1, &p); }
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
 int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -29,9 +31,14 @@ PILOT_API int pilot_ot_row_distances_dev(const double *d_E, int N, int normalize
     if (metric != PILOT_OT_ROWMETRIC_EUCLIDEAN && metric != PILOT_OT_ROWMETRIC_COSINE) return fail(PILOT_OT_EINVAL, "unknown row metric %d", metric);
     if (normalize_by_max && !d_max_scratch) return fail(PILOT_OT_EINVAL, "normalize_by_max needs an 8-byte device scratch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (normalize_by_max) hipLaunchKernelGGL(pilot::max_reduce_kernel, dim3(1), dim3(256), 0, s, d_E, (long)N * N, d_max_scratch);
+    if (normalize_by_max) {
+        HIP_TRY(hipMemsetAsync(d_max_scratch, 0, sizeof(double), s));
+        long blocks = ((long)N * N + 256 * 8 - 1) / (256 * 8);
+        blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+        hipLaunchKernelGGL(pilot::max_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_E, (long)N * N, d_max_scratch);
+    }
     const unsigned g = (unsigned)((N + pilot::RD_TILE - 1) / pilot::RD_TILE);
-    hipLaunchKernelGGL(pilot::row_distance_kernel, dim3(g, g), dim3(pilot::RD_TILE * pilot::RD_TILE), 0, s, d_E, N, metric,
+    hipLaunchKernelGGL(pilot::row_distance_kernel, dim3(g, g), dim3(pilot::RD_T * pilot::RD_T), 0, s, d_E, N, metric,
                        normalize_by_max ? d_max_scratch : nullptr, d_D);
     HIP_TRY(hipGetLastError());
     return PILOT_OT_OK;
@@ -84,7 +91,7 @@ int check_labels(const int *labels, int N, int n_clusters) {
 int silhouette_of_device_matrix(const double *d_D, const int *labels, int N, int n_clusters, double *score, double *samples, hipStream_t st) {
     int rc = check_labels(labels, N, n_clusters);
     if (rc != PILOT_OT_OK) return rc;
-    DevMem dL, dS, dO;
+    DevMem dL(15), dS(16), dO(17);
     hipError_t e = dL.alloc(sizeof(int) * N);
     if (e == hipSuccess) e = dS.alloc(sizeof(int) * n_clusters);
     if (e == hipSuccess) e = dO.alloc(sizeof(double) * N);
@@ -106,7 +113,7 @@ int silhouette_of_device_matrix(const double *d_D, const int *labels, int N, int
 PILOT_API int pilot_ot_row_distances(const double *E, int N, int normalize_by_max, int metric, double *D) {
     if (!E || !D) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (N <= 0) return fail(PILOT_OT_EINVAL, "N=%d must be positive", N);
-    DevMem dE, dD, dM;
+    DevMem dE(12), dD(13), dM(14);
     const size_t bytes = sizeof(double) * (size_t)N * N;
     hipError_t e = dE.alloc(bytes);
     if (e == hipSuccess) e = dD.alloc(bytes);
@@ -124,7 +131,7 @@ PILOT_API int pilot_ot_silhouette(const double *D, const int *labels, int N, int
     if (N <= 0 || n_clusters <= 0 || n_clusters > 4096) return fail(PILOT_OT_EINVAL, "N=%d n_clusters=%d out of range", N, n_clusters);
     int rc = check_labels(labels, N, n_clusters);
     if (rc != PILOT_OT_OK) return rc;
-    DevMem dD;
+    DevMem dD(13);
     const size_t bytes = sizeof(double) * (size_t)N * N;
     hipError_t e = dD.alloc(bytes);
     if (e == hipSuccess) e = hipMemcpy(dD.p, D, bytes, hipMemcpyHostToDevice);
@@ -135,7 +142,7 @@ PILOT_API int pilot_ot_silhouette(const double *D, const int *labels, int N, int
 PILOT_API int pilot_ot_knn_kernel(const double *D, int N, int k, double epsilon, double *Kmat) {
     if (!D || !Kmat) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (N <= 0) return fail(PILOT_OT_EINVAL, "N=%d must be positive", N);
-    DevMem dD, dK;
+    DevMem dD(13), dK(18);
     const size_t bytes = sizeof(double) * (size_t)N * N;
     hipError_t e = dD.alloc(bytes);
     if (e == hipSuccess) e = dK.alloc(bytes);
@@ -154,7 +161,7 @@ PILOT_API int pilot_ot_silhouette_of_rows(const double *E, int E_is_device, int 
                                           int n_clusters, double *score, double *samples) {
     if (!E || !labels || !score) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (N <= 0 || n_clusters <= 0 || n_clusters > 4096) return fail(PILOT_OT_EINVAL, "N=%d n_clusters=%d out of range", N, n_clusters);
-    DevMem dE, dD, dM;
+    DevMem dE(12), dD(13), dM(14);
     const size_t bytes = sizeof(double) * (size_t)N * N;
     hipError_t e = dD.alloc(bytes);
     if (e == hipSuccess) e = dM.alloc(8);
@@ -170,7 +177,7 @@ PILOT_API int pilot_ot_silhouette_of_rows(const double *E, int E_is_device, int 
 PILOT_API int pilot_ot_diffusion_kernel_of_rows(const double *E, int E_is_device, int N, int k, double epsilon, double *D_out, double *Kmat) {
     if (!E || !Kmat) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (N <= 0) return fail(PILOT_OT_EINVAL, "N=%d must be positive", N);
-    DevMem dE, dD, dK, dM;
+    DevMem dE(12), dD(13), dK(18), dM(14);
     const size_t bytes = sizeof(double) * (size_t)N * N;
     hipError_t e = dD.alloc(bytes);
     if (e == hipSuccess) e = dK.alloc(bytes);
