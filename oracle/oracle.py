@@ -77,6 +77,9 @@ def lib() -> ctypes.CDLL:
         L.pilot_oracle_emd_grid.restype = ctypes.c_int
         L.pilot_oracle_emd_grid.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
+        L.pilot_oracle_cell_w2.restype = ctypes.c_double
+        L.pilot_oracle_cell_w2.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ip, dp]
         L.pilot_oracle_emd_grid_fast.restype = ctypes.c_int
         L.pilot_oracle_emd_grid_fast.argtypes = L.pilot_oracle_emd_grid.argtypes
         _lib = L
@@ -273,6 +276,18 @@ def cell_w2(X, Y, scale, reg, numItermax=1000, stopThr=1e-9, check_period=10, re
                 break
     val = float(np.sum(np.exp(Mr + u[:, None] + v[None, :]) * M))
     return (val, dict(iters=iters, err=err)) if return_info else val
+
+
+def cell_w2_c(X, Y, scale, reg, numItermax=1000, stopThr=1e-9, check_period=10, n_threads=8, return_info=False):
+    """:func:`cell_w2` in C with OpenMP (pilot_oracle.c::pilot_oracle_cell_w2): the same control flow and max-shifted
+    log-sum-exps; affordable for converged pairs of thousands of cells.  Thread-count independent."""
+    X, Y = _f64(X), _f64(Y)
+    it = ctypes.c_int(0)
+    err = ctypes.c_double(0.0)
+    val = lib().pilot_oracle_cell_w2(_dptr(X), X.shape[0], _dptr(Y), Y.shape[0], X.shape[1], float(scale), float(reg),
+                                     int(numItermax), float(stopThr), int(check_period), int(n_threads), ctypes.byref(it),
+                                     ctypes.byref(err))
+    return (val, dict(iters=it.value, err=err.value)) if return_info else val
 
 
 def cell_w2_grid(X, offsets, scale, reg, row_begin=0, row_end=None, row_step=1, **kw):

@@ -451,3 +451,83 @@ ORACLE_API int pilot_oracle_emd_grid(const double *P, int N, int K, const double
     (void)n_threads;
     return 0;
 }
+
+/*
+ * Cell-level W2 EXTENSION (not in the reference; BASELINE config 5): entropic OT between two point clouds with uniform weights
+ * and cost |x - y|^2 / scale, POT 0.9.x ot.bregman.sinkhorn_log control flow (log-domain updates v then u, marginal error
+ * every check_period updates, stop on err < stopThr), value <Gamma, C>.  The C twin of oracle.py::cell_w2 (numpy), so that
+ * converged pairs of thousands of cells -- hundreds of updates over an n x m matrix -- are affordable in a test.
+ * OpenMP over the rows / columns of a pass; every log-sum-exp is computed by ONE thread in index order (max-shifted like
+ * scipy.special.logsumexp), the error norm is summed in index order: the result does not depend on the thread count.
+ */
+ORACLE_API double pilot_oracle_cell_w2(const double *X, int n, const double *Y, int m, int D, double scale, double reg,
+                                       int numItermax, double stopThr, int check_period, int n_threads, int *iters_out,
+                                       double *err_out)
+{
+    double *Mr = (double *)malloc(sizeof(double) * (size_t)n * m);      /* -C / reg */
+    double *u = (double *)calloc((size_t)n, sizeof(double)), *v = (double *)calloc((size_t)m, sizeof(double));
+    double *col = (double *)malloc(sizeof(double) * (size_t)m);
+    if (n_threads < 1) n_threads = 1;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) { const double t = X[(size_t)i * D + d] - Y[(size_t)j * D + d]; s += t * t; }
+            Mr[(size_t)i * m + j] = -(s / scale) / reg;
+        }
+    const double loga = -log((double)n), logb = -log((double)m), b = 1.0 / m;
+    double err = 1.0;
+    int iters = 0;
+    for (int ii = 0; ii < numItermax; ++ii) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+        for (int j = 0; j < m; ++j) {                 /* v = logb - logsumexp(Mr + u[:, None], axis=0) */
+            double mx = -INFINITY;
+            for (int i = 0; i < n; ++i) { const double t = Mr[(size_t)i * m + j] + u[i]; if (t > mx) mx = t; }
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += exp(Mr[(size_t)i * m + j] + u[i] - mx);
+            v[j] = logb - (log(s) + mx);
+        }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+        for (int i = 0; i < n; ++i) {                 /* u = loga - logsumexp(Mr + v[None, :], axis=1) */
+            const double *row = Mr + (size_t)i * m;
+            double mx = -INFINITY;
+            for (int j = 0; j < m; ++j) { const double t = row[j] + v[j]; if (t > mx) mx = t; }
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += exp(row[j] + v[j] - mx);
+            u[i] = loga - (log(s) + mx);
+        }
+        iters = ii + 1;
+        if (ii % check_period == 0) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+            for (int j = 0; j < m; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < n; ++i) s += exp(Mr[(size_t)i * m + j] + u[i] + v[j]);
+                col[j] = s - b;
+            }
+            double e2 = 0.0;
+            for (int j = 0; j < m; ++j) e2 += col[j] * col[j];
+            err = sqrt(e2);
+            if (err < stopThr) break;
+        }
+    }
+    double val = 0.0;
+    for (int i = 0; i < n; ++i) {                     /* sum(exp(Mr + u + v) * C), C = -reg * Mr */
+        const double *row = Mr + (size_t)i * m;
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) s += exp(row[j] + u[i] + v[j]) * (-reg * row[j]);
+        val += s;
+    }
+    if (iters_out) *iters_out = iters;
+    if (err_out) *err_out = err;
+    free(Mr); free(u); free(v); free(col);
+    return val;
+}

@@ -131,6 +131,26 @@ def test_c5_patients_of_5000_cells_against_the_oracle():
     assert np.abs(Wg - Wo).max() <= C5_TOL, np.abs(Wg - Wo).max()
 
 
+def test_c5_converged_pairs_of_thousands_of_cells_against_the_c_oracle():
+    """Converged pairs at full iteration count: patients of 2000 and of 5000 cells, the C / OpenMP twin of
+    the numpy oracle (oracle.cell_w2_c: same control flow, identical to it to 2e-16) run to POT's stopping rule -- up to
+    hundreds of log-domain updates over the n x m plan.  The f32 kernel may stop at an earlier check (its stop threshold is
+    floored at the f32 resolution of the marginal; at reg 0.1 the fp64 oracle needs several times as many updates to get from
+    1e-8 to 1e-9), never later, and must agree within the f32 tolerance either way."""
+    n_conv = 0
+    for cells, reg, pairs in ((2000, 0.2, ((0, 1), (1, 1), (2, 0))), (5000, 0.2, ((1, 0), (2, 2))), (2000, 0.1, ((0, 2),))):
+        X, offs, scale = make_cell_clouds(3, cells, 30, seed=cells + int(100 * reg))
+        Wg, ig = engine.cell_w2_grid(X, offs, scale, reg, return_info=True)
+        for i, j in pairs:
+            wo, info = O.cell_w2_c(X[offs[i]:offs[i + 1]], X[offs[j]:offs[j + 1]], scale, reg, n_threads=32, return_info=True)
+            n_conv += info["iters"] < 1000
+            assert ig["iters"][i, j] <= info["iters"] and ig["iters"][i, j] % 10 == 1 and ig["iters"][i, j] > 11
+            assert abs(Wg[i, j] - wo) <= C5_TOL, (cells, reg, i, j, Wg[i, j], wo, ig["iters"][i, j], info["iters"])
+            print("cell-level W2, %d cells, reg %g, pair (%d, %d): oracle %d updates (err %.1e), gpu %d, |d| = %.2e"
+                  % (cells, reg, i, j, info["iters"], info["err"], ig["iters"][i, j], abs(Wg[i, j] - wo)))
+    assert n_conv >= 4          # the reg 0.2 pairs converge under POT's own rule in fp64
+
+
 def test_c5_full_size_cohort_properties():
     """200 patients x 5000 cells x 30 dims resident on the device; a band of rows is solved (the full 40 000-pair grid
     is bench territory): shards reproduce each other bit for bit, converged pairs are symmetric, self-pairs are the
