@@ -16,6 +16,14 @@
 // 16 x 16 x 32 tile is six v_mfma_f32_16x16x32_bf16 (x1y1 + x1y2 + x2y1 + x2y2 + x1y3 + x3y1, f32 accumulation: terms of
 // order 2^-24 dropped) = 96 matrix-pipe cycles instead of the 8 x 32 = 256 of the f32-input MFMA it replaces -- and the
 // bf16 pipe leaves the vector unit free for the exponentials.
+//
+// HALF (default when the scaled coordinates fit fp16's range): TWO fp16 pieces per coordinate (11 + 11 significant bits) and
+// three v_mfma_f32_16x16x32_f16 per tile (x1y1 + x1y2 + x2y1) -- half the matrix work; the dropped x2y2 and the 2^-22
+// relative representation error of the static operands perturb the exponent by <= 3 * 2^-22 |x||y| 2 alpha log2 e, i.e. the
+// COST by <= ~7e-7 |x||y| / scale (a fixed perturbation of the ground cost: the OT value moves by at most that).  The
+// column potential h_col cannot be rounded to 22 bits and is added on the vector unit; the row shift m_row still rides a
+// spare k-slot, rounded to what its two fp16 pieces represent -- the SAME rounded value is added back after the log, so
+// the rounding cancels exactly.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,8 +37,9 @@ constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 struct CellXb {
     const uint4 *p;
     long long C;
+    int np;                 // pieces per coordinate: 3 (bf16) or 2 (fp16)
     __device__ inline const uint4 &at(long point, int kb, int piece, int g) const {
-        return p[((((long)kb * 3 + piece) * 2 + (g >> 1)) * C + point) * 2 + (g & 1)];
+        return p[((((long)kb * np + piece) * 2 + (g >> 1)) * C + point) * 2 + (g & 1)];
     }
 };
 
@@ -58,18 +67,26 @@ struct CellParams {
 };
 
 // one pre-pass over the cells: the three bf16 pieces of every (scaled) coordinate in MFMA operand order + squared norms
-__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, float op_scale,
+// (half: two fp16 pieces instead of three bf16 ones)
+__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, float op_scale, int half,
                                   unsigned short *__restrict__ Xb, float *__restrict__ nrm) {
+    const int np = half ? 2 : 3;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * KB * 32; idx += (long)gridDim.x * blockDim.x) {
         const long c = idx / (KB * 32);
         const int o = (int)(idx % (KB * 32)), kb = o / 32, d = o;      // coordinate d sits in k-block d / 32, slot d % 32
         float x = d < D ? X[c * D + d] * op_scale : 0.f;
-#pragma unroll
-        for (int piece = 0; piece < 3; ++piece) {
-            const unsigned short hb = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
+        for (int piece = 0; piece < np; ++piece) {
+            unsigned short hb;
+            if (half) {
+                const _Float16 h = static_cast<_Float16>(x);
+                hb = __builtin_bit_cast(unsigned short, h);
+                x -= static_cast<float>(h);
+            } else {
+                hb = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
+                x -= __uint_as_float((unsigned int)hb << 16);
+            }
             const int g = (o % 32) / 8;
-            Xb[((((long)kb * 3 + piece) * 2 + (g >> 1)) * C + c) * 16 + (g & 1) * 8 + (o % 8)] = hb;
-            x -= __uint_as_float((unsigned int)hb << 16);
+            Xb[((((long)kb * np + piece) * 2 + (g >> 1)) * C + c) * 16 + (g & 1) * 8 + (o % 8)] = hb;
         }
     }
     for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
@@ -80,14 +97,26 @@ __global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, in
 }
 
 using cell_bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using cell_f16x8 = _Float16 __attribute__((ext_vector_type(8)));
 using cell_f4 = float __attribute__((ext_vector_type(4)));
-// the lane's operand pieces of one point: p[kb][piece] = 8 bf16 (k-slots 8 g .. 8 g + 7 of k-block kb)
-template <int KB> struct CellOperand { uint4 p[KB][3]; };
-template <int KB> __device__ inline void cell_load(const CellXb &Xb, long point, int g, CellOperand<KB> &o) {
+// the lane's operand pieces of one point: p[kb][piece] = 8 x 16 bit (k-slots 8 g .. 8 g + 7 of k-block kb); NP = 3 bf16 / 2 fp16
+template <int KB, int NP = 3> struct CellOperand { uint4 p[KB][NP]; };
+template <int KB, int NP> __device__ inline void cell_load(const CellXb &Xb, long point, int g, CellOperand<KB, NP> &o) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int piece = 0; piece < 3; ++piece) o.p[kb][piece] = Xb.at(point, kb, piece, g);
+        for (int piece = 0; piece < NP; ++piece) o.p[kb][piece] = Xb.at(point, kb, piece, g);
+}
+// fp16 pieces of a value (hi + lo) and what they add up to
+__device__ inline void cell_split2h(float x, unsigned int &hi, unsigned int &lo) {
+    const _Float16 h = static_cast<_Float16>(x);
+    const _Float16 l = static_cast<_Float16>(x - static_cast<float>(h));
+    hi = __builtin_bit_cast(unsigned short, h); lo = __builtin_bit_cast(unsigned short, l);
+}
+__device__ inline float cell_round2h(float x) {
+    const _Float16 h = static_cast<_Float16>(x);
+    const _Float16 l = static_cast<_Float16>(x - static_cast<float>(h));
+    return static_cast<float>(h) + static_cast<float>(l);
 }
 // exact 3-way split of an f32 into bf16 pieces by truncation (8 + 8 + 8 mantissa bits): x = hi + mid + lo
 __device__ inline void cell_split3(float x, unsigned int &hi, unsigned int &mid, unsigned int &lo) {
@@ -101,7 +130,7 @@ __device__ inline void cell_split3(float x, unsigned int &hi, unsigned int &mid,
 // slot 32 KB - 2 holds (1 on the A side, h_col on the B side), slot 32 KB - 1 holds (-m_row, 1), each value as its three
 // bf16 pieces -- with the 1 only in the leading piece, the six piece products of cell_dot_tile add exactly h_col - m_row,
 // and the tile comes out of the matrix pipe as the finished exponent.  Both slots sit in the .w word of the g = 3 lanes.
-template <int KB> __device__ inline void cell_patch_a(CellOperand<KB> &a, int g, float minus_m) {
+template <int KB> __device__ inline void cell_patch_a(CellOperand<KB, 3> &a, int g, float minus_m) {
     unsigned int h, m, l;
     cell_split3(minus_m, h, m, l);
     if (g == 3) {
@@ -110,7 +139,7 @@ template <int KB> __device__ inline void cell_patch_a(CellOperand<KB> &a, int g,
         a.p[KB - 1][2].w = l << 16;
     }
 }
-template <int KB> __device__ inline void cell_patch_b(CellOperand<KB> &b, int g, float hcol) {
+template <int KB> __device__ inline void cell_patch_b(CellOperand<KB, 3> &b, int g, float hcol) {
     unsigned int h, m, l;
     cell_split3(hcol, h, m, l);
     if (g == 3) {
@@ -119,8 +148,37 @@ template <int KB> __device__ inline void cell_patch_b(CellOperand<KB> &b, int g,
         b.p[KB - 1][2].w = l;
     }
 }
+// fp16 pieces: only the row shift rides the last spare slot (A side: the two pieces of -m_row, B side: 1); the result tile is
+// <a, b> - cell_round2h(m_row).  The other spare slot stays zero on both sides.
+template <int KB> __device__ inline void cell_patch_a(CellOperand<KB, 2> &a, int g, float minus_m) {
+    unsigned int h, l;
+    cell_split2h(minus_m, h, l);
+    if (g == 3) {
+        a.p[KB - 1][0].w = (a.p[KB - 1][0].w & 0xffffu) | (h << 16);
+        a.p[KB - 1][1].w = (a.p[KB - 1][1].w & 0xffffu) | (l << 16);
+    }
+}
+template <int KB> __device__ inline void cell_patch_b(CellOperand<KB, 2> &b, int g, float) {
+    if (g == 3) {
+        b.p[KB - 1][0].w = (b.p[KB - 1][0].w & 0xffffu) | (0x3c00u << 16);       // fp16 1.0
+        b.p[KB - 1][1].w = b.p[KB - 1][1].w & 0xffffu;
+    }
+}
 // 16 x 16 tile of <A_row, B_col>: six bf16 MFMAs per k-block, smallest terms first
-template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB> &a, const CellOperand<KB> &b) {
+template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB, 2> &a, const CellOperand<KB, 2> &b) {
+    cell_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto mm = [](const uint4 &x, const uint4 &y, cell_f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cell_f16x8, x), __builtin_bit_cast(cell_f16x8, y), c, 0, 0, 0);
+    };
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        acc = mm(a.p[kb][1], b.p[kb][0], acc);
+        acc = mm(a.p[kb][0], b.p[kb][1], acc);
+        acc = mm(a.p[kb][0], b.p[kb][0], acc);
+    }
+    return acc;
+}
+template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB, 3> &a, const CellOperand<KB, 3> &b) {
     cell_f4 acc = {0.f, 0.f, 0.f, 0.f};
 
     auto mm = [](const uint4 &x, const uint4 &y, cell_f4 c) {
@@ -170,7 +228,7 @@ __device__ inline float row16_sum(float x) {
 // fma, sub, v_exp, add instead of fma, max, sub, v_exp, add plus one v_exp per row and step (the pass is bound by the
 // vector unit, not by the six MFMAs per tile).  use_ref = false (first update of a pair: no previous value), or a block
 // whose shifted sums leave [2^-64, 2^64] for any row (never seen in practice), takes the online-maximum form.
-template <int KB, bool AUG, class FN>
+template <int KB, bool AUG, int NP, class FN>
 __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int nb,
                                 const float *h2 /* LDS, nb */, const float *hprev /* LDS, na */, float logw2,
                                 bool use_ref, int wave, int n_waves, int lane, FN &&fn) {
@@ -185,13 +243,13 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
     constexpr int RB = KB >= 2 ? 2 : CELL_RB, TB = KB >= 2 ? 1 : (CELL_RB >= 4 ? 1 : 2);
     constexpr int TBS = KB >= 2 ? 2 : 4;                  // column tiles per step of the online-maximum form
     for (int unit = wave; unit * 16 * RB < na; unit += n_waves) {
-        CellOperand<KB> a[RB];
+        CellOperand<KB, NP> a[RB];
         float m[RB][4], l[RB][4];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             int arow = (unit * RB + rb) * 16 + col;       // A operand: lane holds row (lane & 15), k-slots of group g
             if (arow >= na) arow = na - 1;
-            cell_load<KB>(Xb, a0 + arow, g, a[rb]);
+            cell_load<KB, NP>(Xb, a0 + arow, g, a[rb]);
         }
         bool done = false;
         if (use_ref) {                                    // (wave-uniform)
@@ -201,6 +259,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                 for (int r = 0; r < 4; ++r) {
                     const int row = (unit * RB + rb) * 16 + 4 * g + r;
                     m[rb][r] = logw2 - hprev[row < na ? row : na - 1];
+                    if constexpr (AUG && NP == 2) m[rb][r] = -cell_round2h(-m[rb][r]);      // what the fp16 slot subtracts
                     l[rb][r] = 0.f;
                 }
             if constexpr (AUG) {                          // the row shift goes into the spare slot of the A operands
@@ -212,14 +271,14 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                 }
             }
             for (int tb = 0; tb * 16 < nb; tb += TB) {
-                CellOperand<KB> b[TB];
+                CellOperand<KB, NP> b[TB];
                 float h[TB];
 #pragma unroll
                 for (int u = 0; u < TB; ++u) {
                     int bcol = (tb + u) * 16 + col;
                     const bool okc = bcol < nb;
                     if (!okc) bcol = nb - 1;
-                    cell_load<KB>(Xb, b0 + bcol, g, b[u]);
+                    cell_load<KB, NP>(Xb, b0 + bcol, g, b[u]);
                     h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
                     if constexpr (AUG) cell_patch_b<KB>(b[u], g, h[u]);
                 }
@@ -227,7 +286,11 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int u = 0; u < TB; ++u) {
-                        if constexpr (AUG) {
+                        if constexpr (AUG && NP == 2) {
+                            const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = 2 alpha log2e <A, B> - m_row (rounded m)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r] + h[u]);
+                        } else if constexpr (AUG) {
                             const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = the exponent of (row 4g+r, column u)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r]);
@@ -255,7 +318,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                 if (AUG && use_ref) {                                 // the plain operand again
                     int arow = (unit * RB + rb) * 16 + col;
                     if (arow >= na) arow = na - 1;
-                    cell_load<KB>(Xb, a0 + arow, g, a[rb]);
+                    cell_load<KB, NP>(Xb, a0 + arow, g, a[rb]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { m[rb][r] = CELL_NEG_BIG; l[rb][r] = 0.f; }
@@ -268,8 +331,8 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                         int bcol = (tb + u) * 16 + col;
                         const bool okc = bcol < nb;
                         if (!okc) bcol = nb - 1;
-                        CellOperand<KB> b;
-                        cell_load<KB>(Xb, b0 + bcol, g, b);
+                        CellOperand<KB, NP> b;
+                        cell_load<KB, NP>(Xb, b0 + bcol, g, b);
                         h[u] = okc ? h2[bcol] : CELL_NEG_BIG;
                         acc[u] = cell_dot_tile<KB>(a[rb], b);
                     }
@@ -300,7 +363,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
 }
 
 // sum_ij 2^(two_alpha2 <x_i, y_j> + hu2_i + hv2_j) * C_ij  for the rows handled by this wave (lane-local partial)
-template <int KB>
+template <int KB, int NP>
 __device__ inline float value_pass(const CellXb &Xb, long a0, const float *__restrict__ na2, int na,
                                    long b0, const float *__restrict__ nb2, int nb,
                                    const float *hA2, const float *hB2, float dot_unscale, float inv_scale, int wave,
@@ -311,8 +374,8 @@ __device__ inline float value_pass(const CellXb &Xb, long a0, const float *__res
     for (int blk = wave; blk * 16 < na; blk += n_waves) {
         int arow = blk * 16 + col;
         if (arow >= na) arow = na - 1;
-        CellOperand<KB> a;
-        cell_load<KB>(Xb, a0 + arow, g, a);
+        CellOperand<KB, NP> a;
+        cell_load<KB, NP>(Xb, a0 + arow, g, a);
         float hr[4], nr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -325,8 +388,8 @@ __device__ inline float value_pass(const CellXb &Xb, long a0, const float *__res
             int bcol = tb * 16 + col;
             const bool okc = bcol < nb;
             if (!okc) bcol = nb - 1;
-            CellOperand<KB> b;
-            cell_load<KB>(Xb, b0 + bcol, g, b);
+            CellOperand<KB, NP> b;
+            cell_load<KB, NP>(Xb, b0 + bcol, g, b);
             const float h = okc ? hB2[bcol] : CELL_NEG_BIG;
             const float nc = nb2[bcol];
             const f4 acc = cell_dot_tile<KB>(a, b);
@@ -342,8 +405,10 @@ __device__ inline float value_pass(const CellXb &Xb, long a0, const float *__res
 }
 
 // AUG: the embedding leaves two spare k-slots (D <= 32 KB - 2), see cell_patch_a / cell_patch_b
-template <int KB, bool AUG>
+// HALF: two fp16 operand pieces (three piece products per tile) instead of three bf16 ones (six)
+template <int KB, bool AUG, bool HALF = false>
 __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
+    constexpr int NP = HALF ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *hu = reinterpret_cast<float *>(smem_raw);        // [max_n] shifted potentials of the row patient (base 2)
     float *hv = hu + p.max_n;                                // [max_n] ... of the column patient
@@ -352,7 +417,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
     int *qslot = reinterpret_cast<int *>(red + 32);
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, n_waves = blockDim.x / 64;
     const long total = (long)p.n_rows * p.N;
-    const CellXb Xb = {p.Xb, p.C};
+    const CellXb Xb = {p.Xb, p.C, NP};
 
     for (;;) {
         if (threadIdx.x == 0) qslot[0] = atomicAdd(p.queue, 1);
@@ -396,7 +461,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             //      after update ii-1 comes for free; if it stops the pair, (hu, hv_old) is exactly the plan POT returns.
             const bool check = ii > 0 && ((ii - 1) % p.period == 0);
             float e2 = 0.f;
-            lse_pass<KB, AUG>(Xb, o_q, nq, o_p, np, hu, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
+            lse_pass<KB, AUG, NP>(Xb, o_q, nq, o_p, np, hu, hv_cur, logb2, ii > 0, wave, n_waves, lane, [&](int row, float lse2) {
                 if (check) {
                     const float d = __builtin_amdgcn_exp2f(hv_cur[row] + lse2) - bval;
                     e2 = fmaf(d, d, e2);
@@ -419,13 +484,13 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             }
             { float *t = hv_cur; hv_cur = hv_new; hv_new = t; }
             // ---- u-update:  hu_i = log a - LSE_j(2 alpha <x_i, y_j> + hv_j) -------------------------------------------
-            lse_pass<KB, AUG>(Xb, o_p, np, o_q, nq, hv_cur, hu, loga2, ii > 0, wave, n_waves, lane,
+            lse_pass<KB, AUG, NP>(Xb, o_p, np, o_q, nq, hv_cur, hu, loga2, ii > 0, wave, n_waves, lane,
                          [&](int row, float lse2) { hu[row] = loga2 - lse2; });
             __syncthreads();
             iters = ii + 1;
         }
         // ---- value <Gamma, C> ---------------------------------------------------------------------------------------
-        float part = value_pass<KB>(Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
+        float part = value_pass<KB, NP>(Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) red[16 + wave] = part;

@@ -1365,6 +1365,8 @@ struct pilot_ot_cell_cohort {
     long long C = 0, max_n = 0;
     float *dX = nullptr;           // the cells as given (resident: the operand pieces are rebuilt when scale * reg changes)
     float xb_scale = 0.f;          // operand scale the pieces were built with (0: not built)
+    int xb_half = -1;              // ... and their format: 1 two fp16 pieces, 0 three bf16 pieces
+    float max_abs = 0.f;           // largest |coordinate| of the centred cohort (decides whether fp16 pieces are safe)
     uint4 *dXb = nullptr;          // bf16 operand pieces of every cell (resident)
     float *dnrm = nullptr;
     long long *doffs = nullptr;
@@ -1420,8 +1422,14 @@ PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offse
             for (int d = 0; d < D; ++d) mean[(size_t)d] += (double)X[(size_t)i * D + d];
         for (int d = 0; d < D; ++d) mean[(size_t)d] /= (double)c->C;
         std::vector<float> Xc((size_t)c->C * D);
+        float mx = 0.f;
         for (long long i = 0; i < c->C; ++i)
-            for (int d = 0; d < D; ++d) Xc[(size_t)i * D + d] = (float)((double)X[(size_t)i * D + d] - mean[(size_t)d]);
+            for (int d = 0; d < D; ++d) {
+                const float v = (float)((double)X[(size_t)i * D + d] - mean[(size_t)d]);
+                Xc[(size_t)i * D + d] = v;
+                mx = fabsf(v) > mx ? fabsf(v) : mx;
+            }
+        c->max_abs = mx;
         e = hipMemcpy(c->dX, Xc.data(), sizeof(float) * (size_t)c->C * D, hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMemcpy(c->doffs, offsets, sizeof(long long) * (size_t)(N + 1), hipMemcpyHostToDevice);
@@ -1457,6 +1465,7 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
     pilot::CellParams p;
     p.Xb = c->dXb; p.C = c->C; p.nrm = c->dnrm; p.offs = c->doffs; p.N = c->N;
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
+    int half = 0;
     const double alpha = 1.0 / (scale * reg);
     p.alpha = (float)alpha;
     p.two_alpha2 = (float)(2.0 * alpha * 1.4426950408889634);
@@ -1465,11 +1474,16 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
         const float op_scale = sqrtf(p.two_alpha2);
         p.two_alpha2 = op_scale * op_scale;
         p.dot_unscale = 1.f / p.two_alpha2;
-        if (c->xb_scale != op_scale) {
+        // two fp16 pieces (half the matrix work) while the scaled coordinates stay far inside fp16's range and above the
+        // level where its subnormal spacing (2^-24) would cost accuracy; three bf16 pieces otherwise (PILOT_OT_CELL_BF16=1: always)
+        const char *force = getenv("PILOT_OT_CELL_BF16");
+        half = c->max_abs * op_scale < 3.0e4f && !(force && *force && *force != '0') ? 1 : 0;
+        if (c->xb_scale != op_scale || c->xb_half != half) {
             hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, c->dX,
-                               (long)c->C, c->D, c->KB, op_scale, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
+                               (long)c->C, c->D, c->KB, op_scale, half, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
             HIP_TRY(hipGetLastError());
             c->xb_scale = op_scale;
+            c->xb_half = half;
         }
     }
     p.inv_scale = (float)(1.0 / scale);
@@ -1489,8 +1503,13 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
         le = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (le == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);
     };
-    if (c->KB == 1) { if (aug) launch(pilot::cell_w2_kernel<1, true>); else launch(pilot::cell_w2_kernel<1, false>); }
-    else            { if (aug) launch(pilot::cell_w2_kernel<2, true>); else launch(pilot::cell_w2_kernel<2, false>); }
+    if (half) {
+        if (c->KB == 1) { if (aug) launch(pilot::cell_w2_kernel<1, true, true>); else launch(pilot::cell_w2_kernel<1, false, true>); }
+        else            { if (aug) launch(pilot::cell_w2_kernel<2, true, true>); else launch(pilot::cell_w2_kernel<2, false, true>); }
+    } else {
+        if (c->KB == 1) { if (aug) launch(pilot::cell_w2_kernel<1, true>); else launch(pilot::cell_w2_kernel<1, false>); }
+        else            { if (aug) launch(pilot::cell_w2_kernel<2, true>); else launch(pilot::cell_w2_kernel<2, false>); }
+    }
     HIP_TRY(le);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
