@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything the round commits under profiles/: usage tools/gpu_round_report.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/report_$TAG
 mkdir -p $O
@@ -13,26 +13,43 @@ python bench.py --mode emd --config c4 --steps 2 --warmup 1 --no-cpu-baseline > 
 python bench.py --config c4 --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_c4_reg0.1_n1.json 2>> $O/bench.err
 python bench.py --config c2 --no-extras --no-cpu-baseline > $O/bench_c2_reg0.1_n1.json 2>> $O/bench.err
 python bench.py --precision fp32 --no-extras --no-cpu-baseline > $O/bench_c3_reg0.1_fp32_mfma.json 2>> $O/bench.err
+python bench.py --precision bf16x3 --no-extras --no-cpu-baseline > $O/bench_c3_reg0.1_bf16x3.json 2>> $O/bench.err
 python bench.py --precision fp64 --no-extras --no-cpu-baseline > $O/bench_c3_reg0.1_fp64_mfma.json 2>> $O/bench.err
 python bench.py --mode cellw2 > $O/bench_cellw2_c5.json 2>> $O/bench.err
 python bench.py --gpus 2 --logical-shards --no-cpu-baseline > $O/bench_two_logical_shards_one_process.json 2>> $O/bench.err
+python bench.py --gpus 8 --logical-shards --no-cpu-baseline > $O/bench_eight_logical_shards_one_gpu.json 2>> $O/bench.err
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29544 python bench.py --gpus 1 --force-comm --no-cpu-baseline > $O/bench_one_rank_rccl_comm.json 2>> $O/bench.err
-python tools/e2e_timing.py c3 > $O/e2e_tl_wasserstein_distance_c3.txt 2>&1
+python tools/e2e_profile.py c3 > $O/e2e_tl_wasserstein_distance_c3.txt 2>&1
+python tools/shard_floor.py $O/shard_floor.json > $O/shard_floor_one_gpu.txt 2>&1
+python tools/host_enqueue_time.py > $O/host_enqueue_time.txt 2>&1
+python tools/k_sweep.py > $O/k_sweep.txt 2>&1
+python tools/consumer_rate.py > $O/consumer_rate.txt 2>&1
+python tools/small_reg_probe.py > $O/small_reg_c3_reg0.01.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_emd -- python3 $R/bench.py --mode emd --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_emd_c4 -- python3 $R/bench.py --mode emd --config c4 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cellw2 -- python3 $R/bench.py --mode cellw2 --cell-patients 48 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cons -- python3 $R/tools/consumer_rate.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_k80 -- python3 $R/tools/k_point.py 80 > $O/k_point_80.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_k96 -- python3 $R/tools/k_point.py 96 > $O/k_point_96.txt 2>/dev/null
 cd $R
 cp $O/stats/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_bench_c3.csv 2>/dev/null
 cp $O/stats_emd/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_emd_c3.csv 2>/dev/null
 cp $O/stats_emd_c4/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_emd_c4.csv 2>/dev/null
 cp $O/stats_cellw2/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_cellw2_48x5000.csv 2>/dev/null
+cp $O/stats_cons/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_consumers.csv 2>/dev/null
+cp $O/stats_k80/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_k80.csv 2>/dev/null
+cp $O/stats_k96/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_k96.csv 2>/dev/null
 bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc --no-extras > /dev/null 2>&1
 cp $O/pmc/summary.txt $O/rocprofv3_pmc_summary_bench_c3.txt
 bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_emd --mode emd > /dev/null 2>&1
 cp $O/pmc_emd/summary.txt $O/rocprofv3_pmc_summary_emd_c3.txt
+BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k80 80 > /dev/null 2>&1
+cp $O/pmc_k80/summary.txt $O/rocprofv3_pmc_summary_k80.txt
+BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k96 96 > /dev/null 2>&1
+cp $O/pmc_k96/summary.txt $O/rocprofv3_pmc_summary_k96.txt
 python tools/make_traffic_json.py $O > $O/traffic.json
-rm -rf $O/stats $O/stats_emd $O/stats_emd_c4 $O/stats_cellw2 $O/pmc $O/pmc_emd
+rm -rf $O/stats $O/stats_emd $O/stats_emd_c4 $O/stats_cellw2 $O/stats_cons $O/stats_k80 $O/stats_k96 $O/pmc $O/pmc_emd $O/pmc_k80 $O/pmc_k96
 cat $O/pytest_gpu.txt $O/smoke.txt; cut -c1-700 $O/bench_c3_reg0.1_n1.json; head -6 $O/rocprofv3_kernel_stats_bench_c3.csv; cat $O/traffic.json

@@ -6,7 +6,7 @@ import csv, json, os, re, subprocess, sys
 d = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 bench = json.load(open(os.path.join(d, "bench_under_rocprof.json")))
-prec = {"f64": "fp64"}.get(bench["dtype"], "bf16x3" if "bf16" in bench["dtype"] else "fp32")
+prec = {"f64": "fp64"}.get(bench["dtype"], "f16x2" if "fp16" in bench["dtype"] else ("bf16x3" if "bf16" in bench["dtype"] else "fp32"))
 kern, fetch, write = None, None, None
 for line in open(os.path.join(d, "rocprofv3_pmc_summary_bench_c3.txt")):
     m = re.match(r"== (sinkhorn_stream_kernel<[^>]*>)", line)
