@@ -552,6 +552,8 @@ def bench_cellw2(args, reg=0.1, D=30):
     W, info = co.w2_grid(scale, reg, return_info=True)
     dt = time.perf_counter() - t
     kern_s = co.last_kernel_ms * 1e-3
+    pieces = co.last_pieces
+    terms = 3 if pieces == 2 else 6
     co.close()
     upd = info["iters"].astype(np.float64)
     flop = float((upd * 2 * 2.0 * nc * nc * D).sum() + 2.0 * nc * nc * D * upd.size)     # two dot-product passes per update + the value pass
@@ -562,15 +564,19 @@ def bench_cellw2(args, reg=0.1, D=30):
         "metric": "cell-level W2 patient-pairs/sec (full NxN matrix; extension, BASELINE config 5)", "value": round(Np * Np / dt, 2),
         "unit": "pairs/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * dt, 1), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 potentials; dot products as exact 3-way bf16 splits of the coordinates on the bf16 MFMA", "data": "synthetic",
+        "dtype": ("f32 potentials; dot products from 2 fp16 pieces per coordinate (22 significant bits) on the f16 MFMA" if pieces == 2 else
+                  "f32 potentials; dot products as exact 3-way bf16 splits of the coordinates on the bf16 MFMA"), "data": "synthetic",
         "config": {"workload": "c5: %d patients x %d cells x %d dims, entropic W2 reg=%g (POT sinkhorn_log control flow), all N^2 "
                                "ordered pairs" % (Np, nc, D, reg), "n_patients": Np, "cells_per_patient": nc, "n_dims": D, "reg": reg},
-        "roofline": {"bound": "mfma", "kernel": "pilot::cell_w2_kernel<1, true>", "achieved": round(flop * 6 * Dp / D / kern_s / 1e12, 1),
-                     "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flop * 6 * Dp / D / kern_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+        "roofline": {"bound": "mfma", "kernel": "pilot::cell_w2_kernel<1, true, %s>" % ("true" if pieces == 2 else "false"),
+                     "achieved": round(flop * terms * Dp / D / kern_s / 1e12, 1),
+                     "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flop * terms * Dp / D / kern_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                      "traffic": None, "kernel_ms": round(co.last_kernel_ms, 1),
-                     "note": "achieved = bf16 MFMA flop executed: 6 piece products per term (exact 3-way splits of both operands), "
+                     "note": "achieved = 16-bit MFMA flop executed: %d piece products per term (%s), "
                              "D padded to %d; the algorithmic (f32-equivalent) dot-product rate is 2 n_p n_q D per pass = %.1f TFLOP/s "
-                             "(the f32-input MFMA peak is %.1f)" % (Dp, flop / kern_s / 1e12, PEAK_F32_MFMA_TFLOPS),
+                             "(the f32-input MFMA peak is %.1f)" % (terms, "2 fp16 pieces of both operands" if pieces == 2 else
+                                                                    "exact 3-way bf16 splits of both operands", Dp, flop / kern_s / 1e12,
+                                                                    PEAK_F32_MFMA_TFLOPS),
                      "dot_tflops_f32_equivalent": round(flop / kern_s / 1e12, 2),
                      "mean_updates_per_pair": round(float(upd.mean()), 2)},
         "checks": {"pairs_converged": int(conv.sum()), "pairs": int(conv.size), "max_asymmetry_of_converged_pairs": sym},

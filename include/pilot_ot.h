@@ -322,6 +322,7 @@ int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D
 typedef struct pilot_ot_cell_cohort pilot_ot_cell_cohort;
 int pilot_ot_cell_cohort_create(const float *X, const long long *offsets, int N, int D, pilot_ot_cell_cohort **cohort);
 int pilot_ot_cell_cohort_destroy(pilot_ot_cell_cohort *cohort);
+int pilot_ot_cell_cohort_pieces(pilot_ot_cell_cohort *cohort, int *pieces);   /* operand pieces per coordinate of the last call: 2 (fp16) | 3 (bf16) | 0 */
 int pilot_ot_cell_w2_grid_cohort(pilot_ot_cell_cohort *cohort, double scale, double reg, int num_iter_max, double stop_thr,
                                  int check_period, double f32_floor_ulps, int row_begin, int row_end, int row_step,
                                  double *w2, int *iters, double *err, float *kernel_ms);

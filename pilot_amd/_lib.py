@@ -34,7 +34,7 @@ SYMBOLS = [
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_plan_enable_graph", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_proportions_ex", "pilot_ot_centroid_medians", "pilot_ot_embedding_upload",
     "pilot_ot_embedding_destroy", "pilot_ot_centroid_medians_dev", "pilot_ot_cell_w2_grid",
-    "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
+    "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_cohort_pieces", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
     "pilot_ot_mirror_upper_dev",
     "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
     "pilot_ot_silhouette_dev", "pilot_ot_knn_kernel_dev", "pilot_ot_silhouette_of_rows", "pilot_ot_diffusion_kernel_of_rows",
@@ -106,6 +106,7 @@ def load() -> ctypes.CDLL:
                                         dp, ip, dp]
     L.pilot_ot_cell_cohort_create.argtypes = [c_vp, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]
     L.pilot_ot_cell_cohort_destroy.argtypes = [c_vp]
+    L.pilot_ot_cell_cohort_pieces.argtypes = [c_vp, ip]
     L.pilot_ot_cell_w2_grid_cohort.argtypes = [c_vp, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, c_int, c_int, c_int, dp, ip, dp,
                                                ctypes.POINTER(ctypes.c_float)]
     L.pilot_ot_cell_w2_grid_multi.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, ip, c_int, dp, ip, dp]

@@ -1540,6 +1540,12 @@ PILOT_API int pilot_ot_cell_w2_grid_cohort(pilot_ot_cell_cohort *c, double scale
     return rc;
 }
 
+PILOT_API int pilot_ot_cell_cohort_pieces(pilot_ot_cell_cohort *c, int *pieces) {
+    if (!c || !pieces) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    *pieces = c->xb_half < 0 ? 0 : (c->xb_half ? 2 : 3);      // operand pieces of the last call: 2 fp16, 3 bf16, 0 none yet
+    return PILOT_OT_OK;
+}
+
 PILOT_API int pilot_ot_cell_w2_grid(const float *X, const long long *offsets, int N, int D, double scale, double reg,
                                     int num_iter_max, double stop_thr, int check_period, double f32_floor_ulps,
                                     int row_begin, int row_end, int row_step, double *w2, int *iters, double *err) {

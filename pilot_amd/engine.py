@@ -211,7 +211,7 @@ def _cell_inputs(X, offsets):
 
 class CellCohort:
     """Device-resident cell clouds for the cell-level W2 extension (``pilot_ot_cell_cohort_*``): the cells stay in HBM as
-    bf16 operand pieces across calls, a call moves only result rows."""
+    fp16 / bf16 operand pieces across calls, a call moves only result rows."""
 
     def __init__(self, X, offsets):
         X, offsets = _cell_inputs(X, offsets)
@@ -236,6 +236,9 @@ class CellCohort:
                                                        int(row_step), _lib.dptr(w2), _lib.iptr(iters), _lib.dptr(err),
                                                        ctypes.byref(ms)))
         self.last_kernel_ms = float(ms.value)
+        pieces = ctypes.c_int(0)
+        _lib.check(self.L.pilot_ot_cell_cohort_pieces(self.h, ctypes.byref(pieces)))
+        self.last_pieces = pieces.value           # 2: fp16 operand pieces (3 piece products per tile), 3: bf16 (6)
         if return_info:
             return w2, dict(iters=iters, err=err)
         return w2
