@@ -158,7 +158,7 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
             double su = 0.0, sv = 0.0;
             bool neg = false;
             for (int d = 0; d < D; ++d) { neg = neg || u[d] < 0.0 || v[d] < 0.0; su += u[d]; sv += v[d]; }
-            if (neg) { out = HUGE_VAL; break; }
+            if (neg || su == 0.0 || sv == 0.0) { out = HUGE_VAL; break; }     // (scipy: inf for a negative entry or an all-zero row)
             double js = 0.0;
             for (int d = 0; d < D; ++d) {
                 const double p = u[d] / su, q = v[d] / sv, m = (p + q) / 2.0;
