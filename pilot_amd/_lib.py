@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpilot_ot.so")
+LIB_PATH = os.environ.get("PILOT_AMD_LIB") or os.path.join(_HERE, "libpilot_ot.so")      # (PILOT_AMD_LIB: an alternative build, A/B experiments)
 
 OK, EINVAL, EHIP, ENOTSUP, ERCCL = 0, -1, -2, -3, -4
 PREC = {"auto": 0, "fp32": 1, "f32": 1, "float32": 1, "fp64": 2, "f64": 2, "float64": 2, "bf16x3": 3, "generic": 5, "f16x2": 6}

@@ -542,7 +542,7 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
 int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split) {
-    if (split) return RT <= 6 ? 2 : 1;
+    if (split) return RT <= (track ? pilot::SPLIT_OCC2_MAX_RT_TRACK : pilot::SPLIT_OCC2_MAX_RT) ? 2 : 1;
     const int na = RT * 4 * RT * w;
     const bool greg = !split && sym && na <= pilot::GREG_MAX;
     const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) + (split ? 3 * ((RT + 1) / 2) * 4 + 24 : 0) +

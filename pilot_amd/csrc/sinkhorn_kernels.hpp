@@ -866,6 +866,13 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
 template <class C, int RT, bool TRACK> constexpr bool parked_flush() { return C::SPLIT && !TRACK && RT <= 4; }
 
 constexpr int GREG_MAX = 64;
+#ifndef PILOT_SPLIT_OCC2_MAX_RT
+#define PILOT_SPLIT_OCC2_MAX_RT 6
+#endif
+#ifndef PILOT_SPLIT_OCC2_MAX_RT_TRACK
+#define PILOT_SPLIT_OCC2_MAX_RT_TRACK 4      // (K = 80 / 96 at reg 0.01: 160 -> 134 ms, 189 -> 146 ms with one wave and no spills; RT = 4: 32.5 -> 47.5 ms)
+#endif
+constexpr int SPLIT_OCC2_MAX_RT = PILOT_SPLIT_OCC2_MAX_RT, SPLIT_OCC2_MAX_RT_TRACK = PILOT_SPLIT_OCC2_MAX_RT_TRACK;
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
 template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
@@ -878,7 +885,9 @@ template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel
            (operands_in_regs<C, RT, SYM>() ? (RT * C::NREG * RT + 2 * TV * tail_steps<RT>()) * int(sizeof(typename C::T) / 4) : 0);
 }
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
-    if (C::SPLIT) return RT <= 6 ? 2 : 1;     // measured register needs of the split variants (3 waves per SIMD at RT <= 4: slower)
+    // split variants: two waves per SIMD up to SPLIT_OCC2_MAX_RT row tiles (tracking variants: SPLIT_OCC2_MAX_RT_TRACK), one wave
+    // with the whole register file beyond (3 waves per SIMD at RT <= 4: slower)
+    if (C::SPLIT) return RT <= (TRACK ? SPLIT_OCC2_MAX_RT_TRACK : SPLIT_OCC2_MAX_RT) ? 2 : 1;
     return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
 }
 
