@@ -1,0 +1,77 @@
+"""Per-thread caches and helper threads (round 3): the library keeps its host-entry workspaces per calling thread in a
+registry (released by pilot_ot_shutdown, reclaimed when a thread has exited), tl.wasserstein_distance runs its device chain
+on one persistent helper thread and moves bytes on others.  Concurrent callers and short-lived threads must get the same
+bits as a lone caller, and nothing may be left behind on the device.  (tools/stress_threads.py is the long form.)"""
+import copy
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from pilot_amd import _lib, engine, multi, tl
+from pilot_amd.synthetic import make_cells, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wasserstein_distance_from_concurrent_threads_and_short_lived_callers():
+    cohorts = [make_cells(n, k, d, seed=s, cells_per_patient=c) for (n, k, d, s, c) in ((20, 10, 10, 0, 200), (37, 7, 5, 1, 90))]
+    refs = []
+    for ad in cohorts:
+        out = {}
+        for mode in ("reg", "unreg"):
+            ad.uns = {}
+            tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized=mode)
+            out[mode] = ad.uns["EMD"].copy()
+            assert ad.uns["data"].to_numpy().base is not ad.obsm["X_pca"]          # a private copy, like the reference's frame
+            ad.uns["data"].iloc[0, 0] += 1.0
+            assert ad.uns["data"].iloc[0, 0] != ad.obsm["X_pca"][0, 0]
+        refs.append(out)
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(6):
+                i = (tid + it) % len(cohorts)
+                ad = copy.copy(cohorts[i])
+                ad.uns = {}
+                mode = "reg" if (it + tid) % 2 else "unreg"
+                tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized=mode)
+                if not np.array_equal(ad.uns["EMD"], refs[i][mode]):
+                    errors.append((tid, it, "EMD differs"))
+        except Exception as e:                              # noqa: BLE001 -- reported below
+            errors.append((tid, repr(e)))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:3]
+
+    P, M = make_problem(40, 12, 6, seed=3, cells_per_patient=300)
+    Es = engine.sinkhorn_grid(P, M, 0.1)
+
+    def short(tid):
+        try:
+            if not np.array_equal(engine.sinkhorn_grid(P, M, 0.1), Es):
+                errors.append((tid, "sinkhorn"))
+            if not np.array_equal(multi.sinkhorn_grid_multi(P, M, 0.1, devices=[0, 0]), Es):
+                errors.append((tid, "multi"))
+        except Exception as e:                              # noqa: BLE001
+            errors.append((tid, repr(e)))
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_mem():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t))
+        return f.value
+    for k in range(8):                                      # warm: code objects, runtime pools
+        t = threading.Thread(target=short, args=(k,)); t.start(); t.join()
+    _lib.check(_lib.load().pilot_ot_shutdown())
+    m1 = free_mem()
+    for k in range(24):
+        t = threading.Thread(target=short, args=(k,)); t.start(); t.join()
+    _lib.check(_lib.load().pilot_ot_shutdown())
+    m2 = free_mem()
+    assert not errors, errors[:3]
+    assert m1 - m2 < 32 * 2 ** 20, "device memory grew by %.1f MB over 24 short-lived callers" % ((m1 - m2) / 2 ** 20)
+    assert np.array_equal(engine.sinkhorn_grid(P, M, 0.1), Es)         # and the library works after a shutdown
