@@ -550,10 +550,10 @@ int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int 
     return regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
 }
 // mirrors pilot::solo_in_stream: does the fast launch of this configuration carry the one-wave-per-pair path?
-bool stream_has_solo(int w, int RT, bool sym, int tv, bool split) {
+bool stream_has_solo(int w, int RT, bool sym, int tv, bool split, bool half) {
     const int mw = stream_min_waves(w, RT, sym, false, tv, split);
     const int budget = mw >= 4 ? 128 : (mw == 3 ? 168 : 256);
-    return sym && RT <= 4 && (64 + 45) * w <= budget;
+    return sym && RT <= 4 && !(half && RT <= 2) && (64 + 45) * w <= budget;
 }
 
 // LDS of one stream-kernel workgroup: operand image(s) + first-product table + tail weights + one ring of finished pairs
@@ -662,7 +662,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.debug = debug;
     const int tiles = (n_pairs + TILE - 1) / TILE;
     // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
-    const bool solo = stream_has_solo(w, RT, sym, tv, split) && !(p.debug & 512) && !mixed;
+    const bool solo = stream_has_solo(w, RT, sym, tv, split, half) && !(p.debug & 512) && !mixed;
     int solo_blocks = 0;
     {
         // longest-first work order (see order_bucket_kernel)

@@ -895,7 +895,10 @@ template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_w
 // K <= 64, and the launch's register budget holds it without spilling
 template <class C, int RT, bool SYM, bool TRACK, int TV> constexpr bool solo_in_stream() {
     constexpr int budget = min_waves_per_simd<C, RT, SYM, TRACK, TV>() >= 4 ? 128 : (min_waves_per_simd<C, RT, SYM, TRACK, TV>() == 3 ? 168 : 256);
-    return !TRACK && SYM && RT <= 4 && (64 + 45) * int(sizeof(typename C::T) / 4) <= budget;
+    // fp16-split configuration up to 2 row tiles (K <= 32): a 16-pair tile's update (0.4 us with the wave alone on its SIMD) is
+    // shorter than the one-wave-per-pair update (0.48 us: always 64 multiply-adds per row), so the duplicates stay in tiles --
+    // c2 (100 x 30): kernel 0.202 -> 0.169 ms.  A rule by SHAPE, not by load: the same pair takes the same path in every shard.
+    return !TRACK && SYM && RT <= 4 && !(C::HALF && RT <= 2) && (64 + 45) * int(sizeof(typename C::T) / 4) <= budget;
 }
 
 // TRACK = false: plain scaling iterations; a pair whose POT residual scaling would exceed tau (i.e. POT
