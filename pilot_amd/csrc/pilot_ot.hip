@@ -558,7 +558,6 @@ bool stream_has_solo(int w, int RT, bool sym, int tv, bool split, bool half) {
 
 // LDS of one stream-kernel workgroup: operand image(s) + first-product table + tail weights + one ring of finished pairs
 // per wave.  The ring gets as many slots (<= 16) as fit while `want` workgroups stay resident per CU; at least 4.
-// min_ring: the parked-flush variants (pilot::parked_flush) need a full tile's worth of slots.
 struct StreamLds { size_t bytes; int ring, wgs_per_cu; };
 StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want, int min_ring = 4) {
     StreamLds r;
@@ -694,12 +693,16 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         int want = stream_min_waves(w, RT, sym, false, tv, split);
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
         // split configurations up to 4 row-tiles flush their ring inline and park U in LDS meanwhile (pilot::parked_flush):
-        // one 16-byte line per lane and row-tile, and a ring of at least TILE slots
+        // one 16-byte line per lane and row-tile
         const bool park = split && RT <= 4;
-        const size_t park_bytes = park ? (size_t)pilot::WAVES_PER_WG * RT * 4 * 64 * ts : 0;
-        if (park && fixed + park_bytes + pilot::WAVES_PER_WG * slot_bytes * TILE > LDS_BYTES)
+        // (fp16-split configuration: ring slots and the park area hold packed pieces -- whole k-blocks, so an odd row-tile
+        // count rounds up)
+        const size_t slot_fast = half ? (size_t)pilot::ring_slot_stride<pilot::CfgH32x16>(RT) * ts : slot_bytes;
+        const size_t park_lane = half ? (size_t)pilot::park_lane_elems<pilot::CfgH32x16>(RT) : (size_t)RT * 4;
+        const size_t park_bytes = park ? (size_t)pilot::WAVES_PER_WG * park_lane * 64 * ts : 0;
+        if (fixed + park_bytes + pilot::WAVES_PER_WG * slot_fast > LDS_BYTES)
             return fail(PILOT_OT_ENOTSUP, "K=%d: operand images + ring + park area exceed LDS", K);
-        const StreamLds L = stream_lds(fixed + park_bytes, slot_bytes, want, park ? TILE : 4);
+        const StreamLds L = stream_lds(fixed + park_bytes, slot_fast, want);
         int wgs = pl->n_cu * L.wgs_per_cu;
         const int need = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
         if (wgs > need) wgs = need;

@@ -143,7 +143,12 @@ __host__ __device__ constexpr int img_index(int RT, int tp, int r, int t, int la
 // finished pairs wait in a wave-private LDS ring for their cost product: per slot the u panel and the v panel (KP values
 // each, [tile][group][reg] order) + 4 elements of padding (a lane's 16-byte reads of consecutive slots then fall on
 // different banks); ring_meta: per slot the output index, the flags and POT's plan scale (1, or 1/K^2)
-template <class C> __host__ __device__ constexpr int ring_slot_stride(int RT) { return 2 * RT * C::TILE + 4; }
+// (fp16-split configuration: the panels are parked as packed pieces, [part][k-block][lane group] x 16 bytes per column --
+// an odd row-tile count rounds up to whole k-blocks)
+template <class C> __host__ __device__ constexpr int ring_panel_elems(int RT) { return C::HALF ? 2 * ((RT + 1) / 2) * C::NGRP * 4 : RT * C::TILE; }
+template <class C> __host__ __device__ constexpr int ring_slot_stride(int RT) { return 2 * ring_panel_elems<C>(RT) + 4; }
+// (parked flush) 4-byte words a lane parks: its U registers, or its packed U pieces
+template <class C> __host__ __device__ constexpr int park_lane_elems(int RT) { return C::HALF ? 2 * ((RT + 1) / 2) * 4 : RT * C::NREG; }
 constexpr int RING_MAX = 16;
 
 // Cross-lane exchanges between the lane groups of a column (lanes l, l^16, l^32, l^48) with gfx950's
@@ -413,6 +418,32 @@ __device__ inline float resid_f16_hi(float x, unsigned int h) {
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
     return r;
 }
+// fp16-split configuration, round 3: the scalings LIVE as packed fp16 pieces (the B operands of the products as they are), the
+// f32 quotient x = r b (r = 1 / acc) is a temporary: hi = fp16(x), lo = fp16(x - hi) -- 2 multiplies, v_cvt_pk_f16_f32, two
+// v_fma_mix_f32 (residual in one instruction), v_cvt_pk_f16_f32 per element pair.  (One fused multiply-add per half,
+// v_fma_mixlo_f16 / v_fma_mixhi_f16, would be 4 instructions instead of 6, but those two issue at 7.4 cycles against 4.3 for
+// the others -- tools/ubench/valu_rates.hip -- and measured slower: 0.745 vs 0.702 ms at c3.)
+__device__ inline void quot_pieces(float x0, float x1, unsigned int &hi, unsigned int &lo) {
+    hi = cvt_pk_f16(x0, x1);
+    lo = cvt_pk_f16(resid_f16_lo(x0, hi), resid_f16_hi(x1, hi));
+}
+// hi + lo of the low / high halves of two packed registers as f32 (one v_fma_mix_f32 with two fp16 sources)
+__device__ inline float pieces_sum_lo(unsigned int h, unsigned int l) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    return r;
+}
+__device__ inline float pieces_sum_hi(unsigned int h, unsigned int l) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    return r;
+}
+// packed three-way maximum of fp16 pairs (gfx950: v_pk_maximum3_f16; a NaN operand makes the result NaN)
+__device__ inline unsigned int pk_max3_f16(unsigned int a, unsigned int b, unsigned int c) {
+    unsigned int r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // (x0, x1) -> NP packed pairs of pieces, largest first.  bf16 (NP = 3): hi + mid + lo == x exactly (each residual is exactly
 // representable).  fp16 (NP = 2): hi + lo == x to 2^-22 |x| while the low piece is a normal number (scaled domain of CfgH32x16).
 template <int NP> struct Pieces { unsigned int p[NP]; };
@@ -495,13 +526,11 @@ __device__ inline typename C::acc_t split_tile_product(const typename C::T *form
 // piece of the stationary operand is a fixed relative perturbation <= 2^-16 of those entries -- a cost change of
 // reg * 2^-16 on entries that carry <= 1e-2 of the mass -- and the panel's is rounding noise of the same size on that part
 // (c3 at reg 0.01: 37.8 -> 32.0 ms per matrix, max distance to the fp64 oracle on 12 000 pairs 1.5e-7 -> 4.4e-7).
-template <class C, int RT, bool LIVE1 = false>
-__device__ inline void panel_product_split(const typename C::T *form, const typename C::T *form1, int lane,
-                                           const typename C::acc_t (&IN)[RT], typename C::acc_t (&OUT)[RT],
-                                           const typename C::acc_t &last_init) {
+template <class C, int RT>
+__device__ inline void panel_product_pieces(const typename C::T *form, const typename C::T *form1, int lane,
+                                            const SplitPanel<RT, C::NP> &B, typename C::acc_t (&OUT)[RT],
+                                            const typename C::acc_t &last_init) {
     constexpr int KB = split_kblocks(RT), NP = C::NP;
-    SplitPanel<RT, NP> B;
-    split_panel<C, RT, LIVE1>(IN, B);
     const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form) + lane;
     u32x4_t a[NP];
 #pragma unroll
@@ -541,6 +570,48 @@ __device__ inline void panel_product_split(const typename C::T *form, const type
             for (int r = 0; r < 4; ++r) OUT[t][r] = fmaf(lo[r], BAND1_DOWN, OUT[t][r]);
         }
     }
+}
+// The stationary operand in REGISTERS (fp16-split configuration, symmetric cost, <= 4 row-tiles: 2 parts x k-blocks x tiles x
+// 16 bytes <= 64 VGPRs per lane, and G^T = G serves both products): no LDS read in the update loop.  From LDS every MFMA
+// pair waits for a 1 KB operand read, and with all four SIMDs of a CU inside products those reads alone take two thirds of
+// the LDS bandwidth (one ds_read_b128 = 4 LDS cycles per 16-cycle MFMA and SIMD, MI355X_MICROARCH.md "LDS").
+template <int RT, int NP> struct SplitImage { u32x4_t a[NP][split_kblocks(RT)][RT]; };
+#ifndef PILOT_AREG_ORDER
+#define PILOT_AREG_ORDER 1
+#endif
+template <class C, int RT>
+__device__ inline void panel_product_pieces_regs(const SplitImage<RT, C::NP> &A, const SplitPanel<RT, C::NP> &B,
+                                                 typename C::acc_t (&OUT)[RT], const typename C::acc_t &last_init) {
+    constexpr int KB = split_kblocks(RT), NP = C::NP;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) OUT[t][r] = (t == RT - 1) ? last_init[r] : 0.f;
+#if PILOT_AREG_ORDER == 0
+    // one output tile after the other: the element-wise work on tile t can start while the MFMAs of tile t + 1 run
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][kb][t], B.p[term_b<NP>(i)][kb], OUT[t]);
+#else
+    // the RT accumulator chains interleaved
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < n_terms<NP>(); ++i)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][kb][t], B.p[term_b<NP>(i)][kb], OUT[t]);
+#endif
+}
+template <class C, int RT, bool LIVE1 = false>
+__device__ inline void panel_product_split(const typename C::T *form, const typename C::T *form1, int lane,
+                                           const typename C::acc_t (&IN)[RT], typename C::acc_t (&OUT)[RT],
+                                           const typename C::acc_t &last_init) {
+    SplitPanel<RT, C::NP> B;
+    split_panel<C, RT, LIVE1>(IN, B);
+    panel_product_pieces<C, RT>(form, form1, lane, B, OUT, last_init);
 }
 
 struct GridParams {
@@ -784,10 +855,34 @@ __device__ inline __attribute__((always_inline)) void ring_flush_body(const type
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int s = col < cnt ? col : cnt - 1;        // columns beyond the fill level redo the last slot, unused
     const T *rec = ring + s * RSTRIDE;
-    const T scale = rec[2 * KP];
+    constexpr int PE = ring_panel_elems<C>(RT);
+    const T scale = rec[2 * PE];
     // one output row-tile at a time: only the v panel (or its bf16 pieces) is live
     T val = T(0);
-    if constexpr (C::SPLIT) {
+    if constexpr (C::HALF) {
+        // the ring holds packed pieces: v's are the B operand as they lie, u = hi + lo
+        constexpr int KB = split_kblocks(RT);
+        SplitPanel<RT, 2> Bv;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                Bv.p[part][kb] = *reinterpret_cast<const u32x4_t *>(rec + PE + ((part * KB + kb) * NGRP + grp) * 4);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            acc_t zero;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) zero[r] = T(0);
+            const acc_t w = split_tile_product<C, RT>(img_gm, lane, t, Bv, zero);
+            using u32x2_t = unsigned int __attribute__((ext_vector_type(2)));
+            const u32x2_t uh = *reinterpret_cast<const u32x2_t *>(rec + ((0 * KB + t / 2) * NGRP + grp) * 4 + 2 * (t & 1));
+            const u32x2_t ul = *reinterpret_cast<const u32x2_t *>(rec + ((1 * KB + t / 2) * NGRP + grp) * 4 + 2 * (t & 1));
+            val += pieces_sum_lo(uh[0], ul[0]) * w[0];
+            val += pieces_sum_hi(uh[0], ul[0]) * w[1];
+            val += pieces_sum_lo(uh[1], ul[1]) * w[2];
+            val += pieces_sum_hi(uh[1], ul[1]) * w[3];
+        }
+    } else if constexpr (C::SPLIT) {
         SplitPanel<RT, C::NP> Bv;
         {
             acc_t Vr[RT];
@@ -838,7 +933,7 @@ __device__ inline __attribute__((always_inline)) void ring_flush_body(const type
     if constexpr (C::HALF) val *= T(1) / T(H_IN_SCALE);     // u~^T (2^15 G o M) v~ = 2^25 u^T (G o M) v
     const bool redo = p.fb_list && !(val - val == T(0));       // NaN or inf: out of the f32 range somewhere along the way
     if (grp == 0 && col < cnt) {
-        const int *meta = reinterpret_cast<const int *>(rec + 2 * KP + 1);
+        const int *meta = reinterpret_cast<const int *>(rec + 2 * PE + 1);
         const int qq = meta[0];
         int fl = meta[1];
         if (redo || (p.fb_list && (fl & FLAG_NAN))) {
@@ -866,6 +961,9 @@ __device__ __attribute__((noinline)) void ring_flush(const typename C::T *ring, 
 template <class C, int RT, bool TRACK> constexpr bool parked_flush() { return C::SPLIT && !TRACK && RT <= 4; }
 
 constexpr int GREG_MAX = 64;
+#ifndef PILOT_AREG_MAX_RT
+#define PILOT_AREG_MAX_RT 4
+#endif
 #ifndef PILOT_SPLIT_OCC2_MAX_RT
 #define PILOT_SPLIT_OCC2_MAX_RT 6
 #endif
@@ -960,7 +1058,9 @@ sinkhorn_stream_kernel(GridParams p) {
     T *ring = lds + n_img + KP + n_tail + (threadIdx.x / WAVE) * p.ring * RSTRIDE;
     constexpr bool PARK = parked_flush<C, RT, TRACK>();
     // (PARK) one 16-byte line per lane and row-tile behind the rings: U while the inlined flush runs
-    T *park = lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (threadIdx.x / WAVE) * (RT * NREG * WAVE) + (threadIdx.x % WAVE) * NREG;
+    // (fp16-split configuration: the packed pieces of U, [part][k-block] x 16 bytes per lane)
+    constexpr int PARK_LANE = park_lane_elems<C>(RT);
+    T *park = lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (threadIdx.x / WAVE) * (PARK_LANE * WAVE) + (threadIdx.x % WAVE) * 4;
     // small symmetric problems keep the whole operand image in registers (no LDS access in the loop)
     constexpr int NA = RT * NREG * RT;
     constexpr bool GREG = operands_in_regs<C, RT, SYM>();
@@ -1000,17 +1100,66 @@ sinkhorn_stream_kernel(GridParams p) {
     const int K = p.K, N = p.N;
     const T *Pt = static_cast<const T *>(p.P);
     const T uinit = PANEL_SCALE / T(K);
-    const T tau = T(p.tau) * PANEL_SCALE;
+    // (fp16-split configuration: the test reads the leading fp16 piece, which is within 2^-11 of the scaling -- the
+    // threshold is lowered by 2^-10 so that no scaling beyond tau is missed; the few pairs this sends over early are
+    // iterated by the tracking kernel, which decides in f32)
+    const T tau = T(p.tau) * PANEL_SCALE * (C::HALF ? T(1) - T(0.0009765625) : T(1));
     const T kk = T(K) * T(K);
     const unsigned long long colmask = (1ull << TILE) - 1ull;  // lanes of group 0
 
     acc_t A[RT], B[RT], U[RT], V[RT], ACC[RT];
     acc_t RU[TRACK ? RT : 1], RV[TRACK ? RT : 1];
+    // fp16-split configuration: the scalings live as packed fp16 pieces, the B operands of the products as they are
+    // (quot_pieces); U and V above are unused there
+    constexpr int KB = split_kblocks(RT);
+    constexpr bool LIVE1 = TV > 0;
+    SplitPanel<RT, 2> PU, PV;
+    // the operand image in registers (see panel_product_pieces_regs)
+    constexpr bool AREG = C::HALF && SYM && RT <= PILOT_AREG_MAX_RT;
+    SplitImage<AREG ? RT : 1, 2> AR;
+    if constexpr (AREG) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) AR.a[part][kb][t] = reinterpret_cast<const u32x4_t *>(lds)[((part * KB + kb) * RT + t) * WAVE + lane];
+    }
+    // piece pairs of a new pair's u = 1/K (0 in padded slots)
+    unsigned int pu0_hi = 0u, pu0_lo = 0u;
+    if constexpr (C::HALF) { const Pieces<2> s0 = split_pair<C>(PANEL_SCALE / T(p.K), PANEL_SCALE / T(p.K)); pu0_hi = s0.p[0]; pu0_lo = s0.p[1]; }
+    auto pieces_live = [](int kb, int h) { const int t = 2 * kb + h / 2; return t < RT && !(LIVE1 && t == RT - 1 && (h & 1)); };
+    // mask of the live halves of piece pair (kb, h): padded slots of the last row-tile hold 0
+    auto pad_mask = [&](int kb, int h, const acc_t &padc) -> unsigned int {
+        const int t = 2 * kb + h / 2;
+        if (t != RT - 1) return 0xffffffffu;
+        const int e = 2 * (h & 1);
+        return (padc[e] != T(0) ? 0u : 0x0000ffffu) | ((padc[e + 1] != T(0) || LIVE1) ? 0u : 0xffff0000u);
+    };
+    // P = the pieces of the panel X
+    auto quot_panel = [&](const acc_t (&X)[RT], SplitPanel<RT, 2> &P) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int t = 2 * kb + h / 2, e = 2 * (h & 1);
+                unsigned int hi = 0u, lo = 0u;
+                if (pieces_live(kb, h)) {
+                    const int tt = t < RT ? t : 0;
+                    quot_pieces(float(X[tt][e]), (LIVE1 && t == RT - 1) ? 0.f : float(X[tt][e + 1]), hi, lo);
+                }
+                P.p[0][kb][h] = hi; P.p[1][kb][h] = lo;
+            }
+    };
     // 1 in the padded accumulator slots of the last row-tile, 0 elsewhere: seeds every product so that
     // b/acc and a/acc are 0/1 = 0 there (a, b are 0 in padded slots) without per-element selects
     acc_t PADC;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) PADC[r] = M::lidx(RT - 1, r, grp) >= K ? T(1) : T(0);
+    auto product_h = [&](const T *form, const SplitPanel<RT, 2> &P, acc_t (&OUT)[RT]) {
+        if constexpr (AREG) panel_product_pieces_regs<C, RT>(AR, P, OUT, PADC);
+        else if constexpr (C::HALF) panel_product_pieces<C, RT>(form, nullptr, lane, P, OUT, PADC);
+    };
     // per-column state (replicated in the lane groups of the column)
     bool active = false;
     int q = 0, ii = 0, chk = 1, flags = 0, abs_at = -1;
@@ -1023,6 +1172,12 @@ sinkhorn_stream_kernel(GridParams p) {
             ACC[t][r] = T(1);
             if constexpr (TRACK) { RU[t][r] = RV[t][r] = T(0); }
         }
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { PU.p[part][kb][h] = 0u; PV.p[part][kb][h] = 0u; }
 
     int ring_cnt = 0;
     auto flush = [&](int cnt) { ring_flush<C, RT>(ring, p, cnt); };
@@ -1064,6 +1219,14 @@ sinkhorn_stream_kernel(GridParams p) {
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) { A[t][r] = B[t][r] = U[t][r] = V[t][r] = T(0); ACC[t][r] = T(1); }
+                if constexpr (C::HALF) {
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) { PU.p[part][kb][h] = 0u; PV.p[part][kb][h] = 0u; }
+                }
             }
             if (take) {
                 want = false;
@@ -1083,6 +1246,16 @@ sinkhorn_stream_kernel(GridParams p) {
                         if constexpr (TRACK) { RU[t][r] = T(1); RV[t][r] = T(1); }
                     }
                 }
+                if constexpr (C::HALF) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+                            if (pieces_live(kb, h)) {
+                                const unsigned int m = pad_mask(kb, h, PADC);
+                                PU.p[0][kb][h] = pu0_hi & m; PU.p[1][kb][h] = pu0_lo & m;
+                            }
+                }
                 thr = Pt[(size_t)N * KP + j] * IN_SCALE;      // stop threshold of column patient j (prep: f32 floor folded in)
                 chk = 1;
                 ii = 0; flags = 0; abs_at = -1; errv = T(1);
@@ -1090,6 +1263,37 @@ sinkhorn_stream_kernel(GridParams p) {
         }
         if (__ballot(active || want) == 0ull) break;
 
+        T mx = T(0);
+        if constexpr (C::HALF) {
+            // ---- v = b / (G^T u), u = a / (G v): quotients straight into the pieces the products read ----
+            // (the f32 quotients are temporaries; V is read again only by the marginal error of an update that ends with a
+            // test -- small scaled values keep ABSOLUTE precision as pieces, which is all a product needs, but
+            // d_k = v_k (G^T u)_k - b_k sees the relative one)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) V[t][r] = dead(t, r) ? T(0) : B[t][r] * M::rcp(ACC[t][r]);
+            quot_panel(V, PV);
+            product_h(a_g.img, PV, ACC);
+            {
+                acc_t X[RT];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) X[t][r] = dead(t, r) ? T(0) : A[t][r] * M::rcp(ACC[t][r]);
+                quot_panel(X, PU);
+            }
+            // max(u, v) over the leading pieces, two elements per instruction (a NaN piece makes the maximum NaN and the
+            // comparison below false: the pair is caught by the error test instead, as in POT)
+            unsigned int m2 = 0u;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                    if (pieces_live(kb, h)) m2 = pk_max3_f16(m2, PU.p[0][kb][h], PV.p[0][kb][h]);
+            const f16x2_t mh = __builtin_bit_cast(f16x2_t, m2);
+            mx = fmax(float(mh[0]), float(mh[1]));
+        } else {
         // ---- v = b / (G^T u) --------------------------------------------------------------------------
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -1100,7 +1304,6 @@ sinkhorn_stream_kernel(GridParams p) {
             }
         // ---- u = a / (G v) ----------------------------------------------------------------------------
         product(a_g, w_g, V, ACC, PADC);
-        T mx = T(0);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1113,6 +1316,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 if constexpr (TRACK) mx = fmax(fmax(mx, un * RU[t][r]), V[t][r] * RV[t][r]);
                 else mx = fmax(fmax(mx, un), V[t][r]);
             }
+        }
         // POT: max|u| > tau or max|v| > tau  ->  absorb.  "any lane of the column over tau" == "column max over tau"
         const unsigned long long omask = column_any_mask<C>(active && mx > tau);
         const bool over = (omask >> col) & 1ull;
@@ -1168,7 +1372,8 @@ sinkhorn_stream_kernel(GridParams p) {
         ++ii;   // ii updates of (v, u) are done for this column
 
         // ---- ACC = G^T u: feeds the stopping test of this update and the next v ----------------------
-        product(a_gt, w_gt, U, ACC, PADC);
+        if constexpr (C::HALF) product_h(a_gt.img, PU, ACC);
+        else product(a_gt, w_gt, U, ACC, PADC);
 
         // ---- POT's stopping rule: the error of update ii-1 is evaluated when (ii-1) % period == 0 ---
         const bool pending = active && ii == chk;
@@ -1212,48 +1417,73 @@ sinkhorn_stream_kernel(GridParams p) {
                     if (p.iters) p.iters[q] = ii;
                     if (p.err) p.err[q] = double(errv) * double(T(1) / IN_SCALE);
                 }
-                if constexpr (PARK) {
-                    // make room BEFORE the finished columns are stored (the ring has TILE slots here, so they always fit
-                    // afterwards and V is not needed past the flush)
-                    if (ring_cnt + (int)__popcll(fmask) > p.ring) {      // wave-uniform
+                while (fmask) {     // wave-uniform: usually one pass; a second one when the ring fills up in between
+                    if constexpr (PARK) {
+                        // make room BEFORE finished columns are stored: the flush is inlined, U is parked in LDS meanwhile (with
+                        // fewer ring slots than columns a second flush can follow in the next pass)
+                        if (ring_cnt > 0 && ring_cnt + (int)__popcll(fmask) > p.ring) {      // wave-uniform
+                            if constexpr (C::HALF) {
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) store_regs<C>(park + t * NREG * WAVE, U[t]);
-                        ring_flush_body<C, RT>(ring, p, ring_cnt);
-                        ring_cnt = 0;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
-                        const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
+                                for (int part = 0; part < 2; ++part)
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) {
-                            load_regs<C>(park + t * NREG * WAVE, U[t]);
+                                    for (int kb = 0; kb < KB; ++kb) *reinterpret_cast<u32x4_t *>(park + (part * KB + kb) * 4 * WAVE) = PU.p[part][kb];
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < NREG; ++r) { A[t][r] = T(0); B[t][r] = T(0); }
-                            if (active) {
-                                load_regs<C>(pa + t * NGRP * NREG, A[t]);
-                                load_regs<C>(pb + t * NGRP * NREG, B[t]);
+                            for (int t = 0; t < RT; ++t) store_regs<C>(park + t * NREG * WAVE, U[t]);
+                            }
+                            ring_flush_body<C, RT>(ring, p, ring_cnt);
+                            ring_cnt = 0;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            const int i = p.row_begin + (q / N) * p.row_step, j = q % N;
+                            const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
+                            if constexpr (C::HALF) {
 #pragma unroll
-                                for (int r = 0; r < NREG; ++r) {
-                                    if constexpr (C::HALF) { A[t][r] *= IN_SCALE; B[t][r] *= IN_SCALE; }
+                                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                                    for (int kb = 0; kb < KB; ++kb) PU.p[part][kb] = *reinterpret_cast<const u32x4_t *>(park + (part * KB + kb) * 4 * WAVE);
+                            }
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) {
+                                if constexpr (!C::HALF) load_regs<C>(park + t * NREG * WAVE, U[t]);
+#pragma unroll
+                                for (int r = 0; r < NREG; ++r) { A[t][r] = T(0); B[t][r] = T(0); }
+                                if (active) {
+                                    load_regs<C>(pa + t * NGRP * NREG, A[t]);
+                                    load_regs<C>(pb + t * NGRP * NREG, B[t]);
+#pragma unroll
+                                    for (int r = 0; r < NREG; ++r) {
+                                        if constexpr (C::HALF) { A[t][r] *= IN_SCALE; B[t][r] *= IN_SCALE; }
+                                    }
                                 }
                             }
+                            if constexpr (C::HALF) product_h(a_gt.img, PU, ACC);
+                            else product(a_gt, w_gt, U, ACC, PADC);
                         }
-                        product(a_gt, w_gt, U, ACC, PADC);
                     }
-                }
-                while (fmask) {     // wave-uniform: usually one pass; a second one when the ring fills up in between
                     const int space = p.ring - ring_cnt;
                     const int rank = (int)__popcll(fmask & ((1ull << col) - 1ull));
                     const bool put = fin && ((fmask >> col) & 1ull) && rank < space;
                     if (put) {
                         T *rec = ring + (ring_cnt + rank) * RSTRIDE;
+                        constexpr int PE = ring_panel_elems<C>(RT);
+                        if constexpr (C::HALF) {
+#pragma unroll
+                            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                                for (int kb = 0; kb < KB; ++kb) {
+                                    *reinterpret_cast<u32x4_t *>(rec + ((part * KB + kb) * NGRP + grp) * 4) = PU.p[part][kb];
+                                    *reinterpret_cast<u32x4_t *>(rec + PE + ((part * KB + kb) * NGRP + grp) * 4) = PV.p[part][kb];
+                                }
+                        } else {
 #pragma unroll
                         for (int t = 0; t < RT; ++t) {
                             store_regs<C>(rec + (t * NGRP + grp) * NREG, U[t]);
                             store_regs<C>(rec + KP + (t * NGRP + grp) * NREG, V[t]);
                         }
+                        }
                         if (grp == 0) {
-                            rec[2 * KP] = scale;
-                            int *meta = reinterpret_cast<int *>(rec + 2 * KP + 1);
+                            rec[2 * PE] = scale;
+                            int *meta = reinterpret_cast<int *>(rec + 2 * PE + 1);
                             meta[0] = q;
                             meta[1] = flags;
                         }
