@@ -541,8 +541,8 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
 }
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
-int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split) {
-    if (split) return RT <= (track ? pilot::SPLIT_OCC2_MAX_RT_TRACK : pilot::SPLIT_OCC2_MAX_RT) ? 2 : 1;
+int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split, bool half = false) {
+    if (split) return RT <= (track ? pilot::SPLIT_OCC2_MAX_RT_TRACK : (half ? pilot::HALF_OCC2_MAX_RT : pilot::SPLIT_OCC2_MAX_RT)) ? 2 : 1;
     const int na = RT * 4 * RT * w;
     const bool greg = !split && sym && na <= pilot::GREG_MAX;
     const int regs = (track ? 7 : 5) * RT * 4 * w + 4 * w + 56 + (tv ? 24 * w : 0) + (split ? 3 * ((RT + 1) / 2) * 4 + 24 : 0) +
@@ -551,7 +551,7 @@ int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int 
 }
 // mirrors pilot::solo_in_stream: does the fast launch of this configuration carry the one-wave-per-pair path?
 bool stream_has_solo(int w, int RT, bool sym, int tv, bool split, bool half) {
-    const int mw = stream_min_waves(w, RT, sym, false, tv, split);
+    const int mw = stream_min_waves(w, RT, sym, false, tv, split, half);
     const int budget = mw >= 4 ? 128 : (mw == 3 ? 168 : 256);
     return sym && RT <= 4 && !(half && RT <= 2) && (64 + 45) * w <= budget;
 }
@@ -690,7 +690,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     };
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
     if (!mixed) {
-        int want = stream_min_waves(w, RT, sym, false, tv, split);
+        int want = stream_min_waves(w, RT, sym, false, tv, split, half);
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
         // split configurations up to 4 row-tiles flush their ring inline and park U in LDS meanwhile (pilot::parked_flush):
         // one 16-byte line per lane and row-tile

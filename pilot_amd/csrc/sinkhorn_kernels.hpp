@@ -970,7 +970,10 @@ constexpr int GREG_MAX = 64;
 #ifndef PILOT_SPLIT_OCC2_MAX_RT_TRACK
 #define PILOT_SPLIT_OCC2_MAX_RT_TRACK 4      // (K = 80 / 96 at reg 0.01: 160 -> 134 ms, 189 -> 146 ms with one wave and no spills; RT = 4: 32.5 -> 47.5 ms)
 #endif
-constexpr int SPLIT_OCC2_MAX_RT = PILOT_SPLIT_OCC2_MAX_RT, SPLIT_OCC2_MAX_RT_TRACK = PILOT_SPLIT_OCC2_MAX_RT_TRACK;
+#ifndef PILOT_HALF_OCC2_MAX_RT
+#define PILOT_HALF_OCC2_MAX_RT 7             // (fp16-split, piece state: c4 at K = 100 26.85 -> 26.07 ms with two waves and 144 B of spills)
+#endif
+constexpr int SPLIT_OCC2_MAX_RT = PILOT_SPLIT_OCC2_MAX_RT, SPLIT_OCC2_MAX_RT_TRACK = PILOT_SPLIT_OCC2_MAX_RT_TRACK, HALF_OCC2_MAX_RT = PILOT_HALF_OCC2_MAX_RT;
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
 template <class C, int RT, bool SYM> constexpr bool operands_in_regs() {
@@ -985,7 +988,7 @@ template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
     // split variants: two waves per SIMD up to SPLIT_OCC2_MAX_RT row tiles (tracking variants: SPLIT_OCC2_MAX_RT_TRACK), one wave
     // with the whole register file beyond (3 waves per SIMD at RT <= 4: slower)
-    if (C::SPLIT) return RT <= (TRACK ? SPLIT_OCC2_MAX_RT_TRACK : SPLIT_OCC2_MAX_RT) ? 2 : 1;
+    if (C::SPLIT) return RT <= (TRACK ? SPLIT_OCC2_MAX_RT_TRACK : (C::HALF ? HALF_OCC2_MAX_RT : SPLIT_OCC2_MAX_RT)) ? 2 : 1;
     return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
 }
 

@@ -62,24 +62,31 @@ KERNEL(pk_max_f16, REP8(I_PKMAX), REP8(D_PKMAX))
 KERNEL(cndmask, REP8(I_CNDMASK), REP8(D_CNDMASK))
 KERNEL(permlane32_swap, REP8(I_PERM32), REP8(D_PERM32))
 
-// pk_mul / pk_fma on register pairs
-__global__ void k_pk(float *out, const float *in, int iters, int which, long long *cyc) {
-    using f2 = float __attribute__((ext_vector_type(2)));
-    f2 a[8], b = {in[64 + threadIdx.x], in[65 + threadIdx.x]}, c = {in[128 + threadIdx.x], in[129]};
-    for (int i = 0; i < 8; ++i) a[i] = f2{in[threadIdx.x] + i, in[threadIdx.x] - i};
-    const long long t0 = wall_clock64();
-    for (int i = 0; i < iters; ++i)
-        for (int rep = 0; rep < 4; ++rep)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (which == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[j]) : "v"(b));
-                else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "v"(c));
-            }
-    const long long t1 = wall_clock64();
-    float s = 0; for (int i = 0; i < 8; ++i) s += a[i][0] + a[i][1];
-    out[threadIdx.x] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
-}
+// packed f32 on register pairs, and mixes of a transcendental with plain instructions (does v_rcp_f32 leave issue slots?)
+#define KERNEL2(NAME, BODY)                                                                             \
+    __global__ void k2_##NAME(float *out, const float *in, int iters, int dep, long long *cyc) {        \
+        using f2 = float __attribute__((ext_vector_type(2)));                                           \
+        f2 p0 = {in[threadIdx.x], in[threadIdx.x + 1]}, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f;    \
+        const f2 pb = {in[64 + threadIdx.x], in[65 + threadIdx.x]};                                     \
+        float a0 = in[threadIdx.x], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
+        float b = in[64 + threadIdx.x];                                                                 \
+        const long long t0 = wall_clock64();                                                            \
+        for (int i = 0; i < iters; ++i) { BODY BODY BODY BODY }                                         \
+        const long long t1 = wall_clock64();                                                            \
+        out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0[0] + p1[1] + p2[0] + p3[1];      \
+        if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;                                      \
+    }
+#define PKMUL(x) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(pb));
+#define PKFMA(x) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(pb));
+#define RCPX(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x));
+#define MULX(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MIXX(x) asm volatile("v_fma_mix_f32 %0, %0, -1.0, %1 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(b));
+KERNEL2(pk_mul, PKMUL(p0) PKMUL(p1) PKMUL(p2) PKMUL(p3) PKMUL(p0) PKMUL(p1) PKMUL(p2) PKMUL(p3))                       // 8 per body
+KERNEL2(pk_fma, PKFMA(p0) PKFMA(p1) PKFMA(p2) PKFMA(p3) PKFMA(p0) PKFMA(p1) PKFMA(p2) PKFMA(p3))
+KERNEL2(rcp1_mul1, RCPX(a0) MULX(a4) RCPX(a1) MULX(a5) RCPX(a2) MULX(a6) RCPX(a3) MULX(a7))                          // 4 + 4
+KERNEL2(rcp1_mul3, RCPX(a0) MULX(a4) MULX(a5) MULX(a6) RCPX(a1) MULX(a7) MULX(a4) MULX(a5))                          // 2 + 6
+KERNEL2(rcp4_then_mul4, RCPX(a0) RCPX(a1) RCPX(a2) RCPX(a3) MULX(a4) MULX(a5) MULX(a6) MULX(a7))                      // 4 + 4, blocked
+KERNEL2(rcp1_mix1, RCPX(a0) MIXX(a4) RCPX(a1) MIXX(a5) RCPX(a2) MIXX(a6) RCPX(a3) MIXX(a7))
 
 int main() {
     float *d_in, *d_out; long long *d_c;
@@ -110,15 +117,19 @@ int main() {
         if (!strcmp(k.name, "v_mul_f32")) unit = r[0] / 4.0;
         printf("%-22s %10.2f %10.2f %10.2f   = %.1f / %.1f / %.1f cycles (v_mul_f32 independent := 4)\n", k.name, r[0], r[1], r[2], r[0] / unit, r[1] / unit, r[2] / unit);
     }
-    for (int which = 0; which < 2; ++which) {
+    struct { const char *name; void (*fn)(float *, const float *, int, int, long long *); const char *what; } k2s[] = {
+        {"v_pk_mul_f32", k2_pk_mul, "8 packed"}, {"v_pk_fma_f32", k2_pk_fma, "8 packed"}, {"rcp,mul alternating", k2_rcp1_mul1, "4 rcp + 4 mul"},
+        {"rcp,mul,mul,mul", k2_rcp1_mul3, "2 rcp + 6 mul"}, {"4 rcp then 4 mul", k2_rcp4_then_mul4, "4 rcp + 4 mul"}, {"rcp,fma_mix alternating", k2_rcp1_mix1, "4 rcp + 4 fma_mix"}};
+    printf("\nbodies of 8 instructions: cycles per BODY of one wave, 1 and 2 waves per SIMD (v_mul_f32 := 4 cycles)\n");
+    for (auto &k : k2s) {
         double r[2];
         for (int m = 0; m < 2; ++m) {
             long long c;
-            for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k_pk, dim3(1), dim3(m ? 512 : 256), 0, 0, d_out, d_in, iters, which, d_c); hipDeviceSynchronize(); }
+            for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k.fn, dim3(1), dim3(m ? 512 : 256), 0, 0, d_out, d_in, iters, 0, d_c); hipDeviceSynchronize(); }
             hipMemcpy(&c, d_c, 8, hipMemcpyDeviceToHost);
-            r[m] = c * 10.0 / (double(iters) * 32);
+            r[m] = c * 10.0 / (double(iters) * 4);        // ns per body
         }
-        printf("%-22s %10.2f %10s %10.2f   = %.1f / - / %.1f cycles\n", which ? "v_pk_fma_f32" : "v_pk_mul_f32", r[0], "-", r[1], r[0] / unit, r[1] / unit);
+        printf("%-26s (%-18s) %8.1f %8.1f cycles per body\n", k.name, k.what, r[0] / unit, r[1] / unit);
     }
     return 0;
 }
