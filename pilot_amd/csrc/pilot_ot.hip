@@ -553,7 +553,7 @@ int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int 
 bool stream_has_solo(int w, int RT, bool sym, int tv, bool split, bool half) {
     const int mw = stream_min_waves(w, RT, sym, false, tv, split, half);
     const int budget = mw >= 4 ? 128 : (mw == 3 ? 168 : 256);
-    return sym && RT <= 4 && !(half && RT <= 2) && (64 + 45) * w <= budget;
+    return sym && RT <= 4 && !(half && RT < pilot::HALF_SOLO_MIN_RT) && (64 + 45) * w <= budget;
 }
 
 // LDS of one stream-kernel workgroup: operand image(s) + first-product table + tail weights + one ring of finished pairs

@@ -697,39 +697,51 @@ template <typename T> __device__ inline T wave_sum(T x) {
 // TRACK: POT's tau-absorptions are kept books of exactly as in the tracking stream kernel (reference scalings ru, rv per
 // element, the 1/K resets folded into the error test and the final cost) instead of handing the pair over; used for the
 // short f64 hand-over list of the small-reg path, where a 16-pair f64 MFMA tile would run 1000 updates nearly empty.
-template <class C, bool SYM, bool TRACK = false>
-__device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned char *solo_smem, const int *n_items_ptr, int *head_ptr) {
+// NCH = ceil(K / 16) (== the row-tile count) is a template parameter: the matrix-vector product is straight-line code with
+// ALL its broadcast reads issued up front (a chunk loop with a wave-uniform `k0 < K` test puts one LDS round trip in front of
+// every 16 multiply-adds).
+template <class C, bool SYM, int NCH, bool TRACK = false>
+__device__ inline void solo_pairs(const GridParams &p, unsigned char *solo_smem, const int *n_items_ptr, int *head_ptr) {
+    constexpr int RT = NCH, KP = NCH * C::TILE;
     using T = typename C::T;
     const int lane = threadIdx.x % WAVE;
     const int K = p.K, N = p.N;
     const T *img = static_cast<const T *>(p.img);
     const T *plain = img + plain_offset<C>(RT);
     const T *Pt = static_cast<const T *>(p.P);
-    T g1[64], g2[SYM ? 1 : 64];
+    constexpr int KC = NCH * 16;          // contraction length, padded (the tables hold 0 beyond K)
+    // (rows as explicit pairs: every multiply-add below is one v_pk_fma_f32 on adjacent registers)
+    using P2 = pair_of<T>;
+    P2 g1[KC / 2], g2[SYM ? 1 : KC / 2];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        g1[k] = plain[k * WAVE + lane];
-        if constexpr (!SYM) g2[k] = plain[64 * WAVE + k * WAVE + lane];
+    for (int k = 0; k < KC / 2; ++k) {
+        g1[k] = P2{plain[(2 * k) * WAVE + lane], plain[(2 * k + 1) * WAVE + lane]};
+        if constexpr (!SYM) g2[k] = P2{plain[64 * WAVE + (2 * k) * WAVE + lane], plain[64 * WAVE + (2 * k + 1) * WAVE + lane]};
     }
     // y_lane = sum_k g[k] * x_k: x goes through a wave-private LDS line and comes back as broadcast 16-byte reads (half the
     // instructions of a v_readlane per element; the wave is issue-bound)
     T *xline = reinterpret_cast<T *>(solo_smem) + (threadIdx.x / WAVE) * WAVE;
     using V4 = T __attribute__((ext_vector_type(16 / sizeof(T))));
     constexpr int VE = 16 / sizeof(T);
-    auto matvec = [&](const T (&g)[64], T x) {
+    auto matvec = [&](const P2 (&g)[KC / 2], T x) {
         xline[lane] = x;
-        T acc[4] = {T(0), T(0), T(0), T(0)};
+        constexpr int NV = NCH * 16 / VE;
+        V4 xv[NV];
 #pragma unroll
-        for (int k0 = 0; k0 < 64; k0 += 16)
-            if (k0 < K) {        // wave-uniform
+        for (int c = 0; c < NV; ++c) xv[c] = *reinterpret_cast<const V4 *>(xline + c * VE);
+        P2 acc[4];
 #pragma unroll
-                for (int c = 0; c < 16 / VE; ++c) {
-                    const V4 xv = *reinterpret_cast<const V4 *>(xline + k0 + c * VE);
+        for (int j = 0; j < 4; ++j) acc[j] = P2{T(0), T(0)};
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) acc[e & 3] = fma(g[k0 + c * VE + e], xv[e], acc[e & 3]);
-                }
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int h = 0; h < VE / 2; ++h) {
+                const int k2 = c * (VE / 2) + h;
+                const P2 xx = {xv[c][2 * h], xv[c][2 * h + 1]};
+                acc[k2 & 3] = __builtin_elementwise_fma(g[k2], xx, acc[k2 & 3]);
             }
-        return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const P2 s2 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        return s2[0] + s2[1];
     };
     const bool live = lane < K;
     const int pos = ((lane / 16) * 4 + (lane % 4)) * 4 + (lane % 16) / 4;     // accumulator slot of cell type `lane`
@@ -828,8 +840,12 @@ __device__ inline void solo_pairs(const GridParams &p, int KP, int RT, unsigned 
 template <class C>
 __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_solo_track_kernel(GridParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char solo_track_smem[];
-    const int RT = (p.K + C::TILE - 1) / C::TILE;
-    solo_pairs<C, true, true>(p, RT * C::TILE, RT, solo_track_smem, p.list_len, p.queue_head);
+    switch ((p.K + C::TILE - 1) / C::TILE) {       // wave-uniform
+    case 1: solo_pairs<C, true, 1, true>(p, solo_track_smem, p.list_len, p.queue_head); break;
+    case 2: solo_pairs<C, true, 2, true>(p, solo_track_smem, p.list_len, p.queue_head); break;
+    case 3: solo_pairs<C, true, 3, true>(p, solo_track_smem, p.list_len, p.queue_head); break;
+    default: solo_pairs<C, true, 4, true>(p, solo_track_smem, p.list_len, p.queue_head); break;
+    }
 }
 
 // Finished pairs in a wave's ring -> costs <Gamma, M> = u^T (G o M) v: ONE panel product for up to TILE pairs, one output
@@ -973,6 +989,10 @@ constexpr int GREG_MAX = 64;
 #ifndef PILOT_HALF_OCC2_MAX_RT
 #define PILOT_HALF_OCC2_MAX_RT 7             // (fp16-split, piece state: c4 at K = 100 26.85 -> 26.07 ms with two waves and 144 B of spills)
 #endif
+#ifndef PILOT_HALF_SOLO_MIN_RT
+#define PILOT_HALF_SOLO_MIN_RT 1         // (3: duplicates of the fp16-split configuration stay in tiles up to K = 32)
+#endif
+constexpr int HALF_SOLO_MIN_RT = PILOT_HALF_SOLO_MIN_RT;
 constexpr int SPLIT_OCC2_MAX_RT = PILOT_SPLIT_OCC2_MAX_RT, SPLIT_OCC2_MAX_RT_TRACK = PILOT_SPLIT_OCC2_MAX_RT_TRACK, HALF_OCC2_MAX_RT = PILOT_HALF_OCC2_MAX_RT;
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
@@ -996,10 +1016,11 @@ template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_w
 // K <= 64, and the launch's register budget holds it without spilling
 template <class C, int RT, bool SYM, bool TRACK, int TV> constexpr bool solo_in_stream() {
     constexpr int budget = min_waves_per_simd<C, RT, SYM, TRACK, TV>() >= 4 ? 128 : (min_waves_per_simd<C, RT, SYM, TRACK, TV>() == 3 ? 168 : 256);
-    // fp16-split configuration up to 2 row tiles (K <= 32): a 16-pair tile's update (0.4 us with the wave alone on its SIMD) is
-    // shorter than the one-wave-per-pair update (0.48 us: always 64 multiply-adds per row), so the duplicates stay in tiles --
-    // c2 (100 x 30): kernel 0.202 -> 0.169 ms.  A rule by SHAPE, not by load: the same pair takes the same path in every shard.
-    return !TRACK && SYM && RT <= 4 && !(C::HALF && RT <= 2) && (64 + 45) * int(sizeof(typename C::T) / 4) <= budget;
+    // (round 3 had the fp16-split configuration keep its duplicates in tiles up to K = 32, when a tile's update was shorter
+    // than the one-wave-per-pair update; with the straight-line matrix-vector product it is the other way round again:
+    // c2 kernel 0.154 -> 0.136 ms, the 1/8 shard of c3 0.253 -> 0.186 ms.  A rule by SHAPE, never by load: the same pair takes
+    // the same path in every shard.)
+    return !TRACK && SYM && RT <= 4 && !(C::HALF && RT < HALF_SOLO_MIN_RT) && (64 + 45) * int(sizeof(typename C::T) / 4) <= budget;
 }
 
 // TRACK = false: plain scaling iterations; a pair whose POT residual scaling would exceed tau (i.e. POT
@@ -1026,7 +1047,7 @@ sinkhorn_stream_kernel(GridParams p) {
     int block = blockIdx.x;
     if constexpr (solo_in_stream<C, RT, SYM, TRACK, TV>()) {
         // the leading workgroups of the fast launch run the exact-duplicate pairs, one per wave (they start first)
-        if (block < p.solo_blocks) { solo_pairs<C, SYM>(p, KP, RT, smem_raw, p.solo_len, p.solo_head); return; }
+        if (block < p.solo_blocks) { solo_pairs<C, SYM, RT>(p, smem_raw, p.solo_len, p.solo_head); return; }
         block -= p.solo_blocks;
     }
     const int n_items = p.list_len ? *p.list_len : p.n_pairs;
