@@ -68,13 +68,16 @@ struct CellParams {
 
 // one pre-pass over the cells: the three bf16 pieces of every (scaled) coordinate in MFMA operand order + squared norms
 // (half: two fp16 pieces instead of three bf16 ones)
-__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, float op_scale, int half,
+// one_slot (fp16 pieces with spare k-slots): the last k-slot of every cell holds 1 -- the B side of the row-shift slot of
+// cell_patch_a, so the column sweep patches nothing (the A side overwrites or clears it: cell_clear_slot)
+__global__ void cell_setup_kernel(const float *__restrict__ X, long C, int D, int KB, float op_scale, int half, int one_slot,
                                   unsigned short *__restrict__ Xb, float *__restrict__ nrm) {
     const int np = half ? 2 : 3;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < C * KB * 32; idx += (long)gridDim.x * blockDim.x) {
         const long c = idx / (KB * 32);
         const int o = (int)(idx % (KB * 32)), kb = o / 32, d = o;      // coordinate d sits in k-block d / 32, slot d % 32
         float x = d < D ? X[c * D + d] * op_scale : 0.f;
+        if (one_slot && o == KB * 32 - 1) x = 1.f;
         for (int piece = 0; piece < np; ++piece) {
             unsigned short hb;
             if (half) {
@@ -158,12 +161,12 @@ template <int KB> __device__ inline void cell_patch_a(CellOperand<KB, 2> &a, int
         a.p[KB - 1][1].w = (a.p[KB - 1][1].w & 0xffffu) | (l << 16);
     }
 }
-template <int KB> __device__ inline void cell_patch_b(CellOperand<KB, 2> &b, int g, float) {
-    if (g == 3) {
-        b.p[KB - 1][0].w = (b.p[KB - 1][0].w & 0xffffu) | (0x3c00u << 16);       // fp16 1.0
-        b.p[KB - 1][1].w = b.p[KB - 1][1].w & 0xffffu;
-    }
+// (B side: the 1 of that slot is part of the stored operand, cell_setup_kernel's one_slot)
+// a plain A operand: the stored 1 of the last slot is taken out again (products with unpatched operands on both sides)
+template <int KB> __device__ inline void cell_clear_slot(CellOperand<KB, 2> &a, int g) {
+    if (g == 3) a.p[KB - 1][0].w &= 0xffffu;
 }
+template <int KB> __device__ inline void cell_clear_slot(CellOperand<KB, 3> &, int) {}
 // 16 x 16 tile of <A_row, B_col>: six bf16 MFMAs per k-block, smallest terms first
 template <int KB> __device__ inline cell_f4 cell_dot_tile(const CellOperand<KB, 2> &a, const CellOperand<KB, 2> &b) {
     cell_f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -250,6 +253,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
             int arow = (unit * RB + rb) * 16 + col;       // A operand: lane holds row (lane & 15), k-slots of group g
             if (arow >= na) arow = na - 1;
             cell_load<KB, NP>(Xb, a0 + arow, g, a[rb]);
+            if constexpr (AUG && NP == 2) { if (!use_ref) cell_clear_slot<KB>(a[rb], g); }
         }
         bool done = false;
         if (use_ref) {                                    // (wave-uniform)
@@ -270,6 +274,35 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                     cell_patch_a<KB>(a[rb], g, hprev[arow] - logw2);
                 }
             }
+            if constexpr (AUG && NP == 2) {
+                // fp16 pieces: the B side needs no patch (its slot value is stored) and no clamp -- columns beyond the patient
+                // weigh 2^(finite + CELL_NEG_BIG) = 0 whatever the operand (the next patient's cells, or the zeroed pad behind
+                // the last plane), so the address is the lane's base plus 512 bytes per tile.  The tile of step tb + 1 is
+                // requested before the MFMAs of step tb; all MFMAs of a step come first, each output tile into registers of
+                // its own (one shared accumulator made every tile's vector work wait for its MFMAs: `s_nop 7` four times per
+                // step), then the vector work with the adds two at a time (v_pk_add_f32 is full rate; exponentials are not).
+                using f2 = float __attribute__((ext_vector_type(2)));
+                CellOperand<KB, NP> bn;
+                cell_load<KB, NP>(Xb, b0 + col, g, bn);
+                for (int tb = 0; tb * 16 < nb; ++tb) {
+                    const CellOperand<KB, NP> bc = bn;
+                    cell_load<KB, NP>(Xb, b0 + (tb + 1) * 16 + col, g, bn);
+                    const int bcol = tb * 16 + col;
+                    const float hv = bcol < nb ? h2[bcol] : CELL_NEG_BIG;
+                    f4 acc[RB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc[rb] = cell_dot_tile<KB>(a[rb], bc);     // 2 alpha log2e <A, B> - m_row (rounded m)
+                    const f2 hh = {hv, hv};
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const f2 x01 = f2{acc[rb][0], acc[rb][1]} + hh, x23 = f2{acc[rb][2], acc[rb][3]} + hh;
+                        const f2 e01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
+                        const f2 e23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+                        const f2 l01 = f2{l[rb][0], l[rb][1]} + e01, l23 = f2{l[rb][2], l[rb][3]} + e23;
+                        l[rb][0] = l01[0]; l[rb][1] = l01[1]; l[rb][2] = l23[0]; l[rb][3] = l23[1];
+                    }
+                }
+            } else {
             for (int tb = 0; tb * 16 < nb; tb += TB) {
                 CellOperand<KB, NP> b[TB];
                 float h[TB];
@@ -286,11 +319,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int u = 0; u < TB; ++u) {
-                        if constexpr (AUG && NP == 2) {
-                            const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = 2 alpha log2e <A, B> - m_row (rounded m)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r] + h[u]);
-                        } else if constexpr (AUG) {
+                        if constexpr (AUG) {
                             const f4 acc = cell_dot_tile<KB>(a[rb], b[u]);     // acc[r] = the exponent of (row 4g+r, column u)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r]);
@@ -300,6 +329,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                             for (int r = 0; r < 4; ++r) l[rb][r] += __builtin_amdgcn_exp2f(acc[r] + h[u] - m[rb][r]);
                         }
                     }
+            }
             }
             bool bad = false;
 #pragma unroll
@@ -319,6 +349,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
                     int arow = (unit * RB + rb) * 16 + col;
                     if (arow >= na) arow = na - 1;
                     cell_load<KB, NP>(Xb, a0 + arow, g, a[rb]);
+                    if constexpr (AUG && NP == 2) cell_clear_slot<KB>(a[rb], g);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { m[rb][r] = CELL_NEG_BIG; l[rb][r] = 0.f; }
@@ -363,7 +394,7 @@ __device__ inline void lse_pass(const CellXb &Xb, long a0, int na, long b0, int 
 }
 
 // sum_ij 2^(two_alpha2 <x_i, y_j> + hu2_i + hv2_j) * C_ij  for the rows handled by this wave (lane-local partial)
-template <int KB, int NP>
+template <int KB, int NP, bool ONE_SLOT = false>
 __device__ inline float value_pass(const CellXb &Xb, long a0, const float *__restrict__ na2, int na,
                                    long b0, const float *__restrict__ nb2, int nb,
                                    const float *hA2, const float *hB2, float dot_unscale, float inv_scale, int wave,
@@ -376,6 +407,7 @@ __device__ inline float value_pass(const CellXb &Xb, long a0, const float *__res
         if (arow >= na) arow = na - 1;
         CellOperand<KB, NP> a;
         cell_load<KB, NP>(Xb, a0 + arow, g, a);
+        if constexpr (ONE_SLOT) cell_clear_slot<KB>(a, g);
         float hr[4], nr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -490,7 +522,7 @@ __global__ void __launch_bounds__(CELL_WG) cell_w2_kernel(CellParams p) {
             iters = ii + 1;
         }
         // ---- value <Gamma, C> ---------------------------------------------------------------------------------------
-        float part = value_pass<KB, NP>(Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
+        float part = value_pass<KB, NP, (AUG && NP == 2)>(Xb, o_p, nxp, np, o_q, nyq, nq, hu, hv_cur, p.dot_unscale, p.inv_scale, wave, n_waves, lane);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) red[16 + wave] = part;

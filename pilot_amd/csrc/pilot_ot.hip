@@ -1369,6 +1369,7 @@ struct pilot_ot_cell_cohort {
     float *dX = nullptr;           // the cells as given (resident: the operand pieces are rebuilt when scale * reg changes)
     float xb_scale = 0.f;          // operand scale the pieces were built with (0: not built)
     int xb_half = -1;              // ... and their format: 1 two fp16 pieces, 0 three bf16 pieces
+    int xb_one_slot = -1;          // ... and whether the last k-slot of every cell holds 1 (cell_setup_kernel)
     float max_abs = 0.f;           // largest |coordinate| of the centred cohort (decides whether fp16 pieces are safe)
     uint4 *dXb = nullptr;          // bf16 operand pieces of every cell (resident)
     float *dnrm = nullptr;
@@ -1410,7 +1411,9 @@ PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offse
     c->n_cu = current_cu_count();
     hipError_t e = hipGetDevice(&c->device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dX), sizeof(float) * (size_t)c->C * D);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dXb), (size_t)c->C * c->KB * 3 * 64);
+    // (+ a zeroed pad: the column sweep of the fp16-piece kernel reads up to 15 cells past a patient's last one)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dXb), (size_t)c->C * c->KB * 3 * 64 + 1024);
+    if (e == hipSuccess) e = hipMemset(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + 1024);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dnrm), sizeof(float) * (size_t)c->C);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->doffs), sizeof(long long) * (size_t)(N + 1));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dQ), sizeof(int));
@@ -1481,12 +1484,15 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
         // level where its subnormal spacing (2^-24) would cost accuracy; three bf16 pieces otherwise (PILOT_OT_CELL_BF16=1: always)
         const char *force = getenv("PILOT_OT_CELL_BF16");
         half = c->max_abs * op_scale < 3.0e4f && !(force && *force && *force != '0') ? 1 : 0;
-        if (c->xb_scale != op_scale || c->xb_half != half) {
+        const int one_slot = half && c->D <= 32 * c->KB - 2 && !getenv("PILOT_OT_CELL_NO_AUG") ? 1 : 0;
+        if (c->xb_scale != op_scale || c->xb_half != half || c->xb_one_slot != one_slot) {
+            if (c->xb_half != half) HIP_TRY(hipMemsetAsync(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + 1024, c->stream));   // (the piece count changes the planes)
             hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, c->dX,
-                               (long)c->C, c->D, c->KB, op_scale, half, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
+                               (long)c->C, c->D, c->KB, op_scale, half, one_slot, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
             HIP_TRY(hipGetLastError());
             c->xb_scale = op_scale;
             c->xb_half = half;
+            c->xb_one_slot = one_slot;
         }
     }
     p.inv_scale = (float)(1.0 / scale);

@@ -10,14 +10,17 @@
     __global__ void k_##NAME(float *out, const float *in, int iters, int dep, long long *cyc) {         \
         float a0 = in[threadIdx.x], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
         float b = in[64 + threadIdx.x], c = in[128 + threadIdx.x];                                      \
+        const unsigned long long smask = __ballot(b > 1.03f);                                           \
+        unsigned long long p64[8] = {1, 2, 3, 4, 5, 6, 7, 8}, pb64 = threadIdx.x;                      \
         const long long t0 = wall_clock64();                                                            \
         if (!dep) { for (int i = 0; i < iters; ++i) { INDEP INDEP INDEP INDEP } }                       \
         else { for (int i = 0; i < iters; ++i) { DEP DEP DEP DEP } }                                    \
         const long long t1 = wall_clock64();                                                            \
-        out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                       \
+        out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(p64[0] + p64[1] + p64[2] + p64[3] + p64[4] + p64[5] + p64[6] + p64[7]); \
         if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;                                      \
     }
 #define A(i) a##i
+#define P(i) p64[i]
 #define I_MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(A(i)) : "v"(b));
 #define D_MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(b));
 #define I_FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(A(i)) : "v"(b), "v"(c));
@@ -44,6 +47,12 @@
 #define D_PKMAX(i) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a0) : "v"(b));
 #define I_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(A(i)) : "v"(b));
 #define D_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a0) : "v"(b));
+#define I_CNDS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(A(i)) : "v"(b), "s"(smask));
+#define D_CNDS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a0) : "v"(b), "s"(smask));
+#define I_ANDOR(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(A(i)) : "v"(b), "v"(c));
+#define D_ANDOR(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a0) : "v"(b), "v"(c));
+#define I_ADD64(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(P(i)) : "v"(pb64));
+#define D_ADD64(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(P(0)) : "v"(pb64));
 #define I_PERM32(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(A(i)), "+v"(b));
 #define D_PERM32(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b));
 
@@ -61,6 +70,9 @@ KERNEL(pk_maximum3_f16, REP8(I_PKMAX3), REP8(D_PKMAX3))
 KERNEL(pk_max_f16, REP8(I_PKMAX), REP8(D_PKMAX))
 KERNEL(cndmask, REP8(I_CNDMASK), REP8(D_CNDMASK))
 KERNEL(permlane32_swap, REP8(I_PERM32), REP8(D_PERM32))
+KERNEL(cndmask_sgpr, REP8(I_CNDS), REP8(D_CNDS))
+KERNEL(and_or, REP8(I_ANDOR), REP8(D_ANDOR))
+KERNEL(lshl_add_u64, REP8(I_ADD64), REP8(D_ADD64))
 
 // packed f32 on register pairs, and mixes of a transcendental with plain instructions (does v_rcp_f32 leave issue slots?)
 #define KERNEL2(NAME, BODY)                                                                             \
@@ -99,7 +111,8 @@ int main() {
         {"v_mul_f32", k_mul}, {"v_fma_f32", k_fma}, {"v_rcp_f32", k_rcp}, {"v_exp_f32", k_exp}, {"v_cvt_pk_f16_f32", k_cvt_pk_f16},
         {"v_cvt_f32_f16", k_cvt_f32_f16}, {"v_fma_mix_f32", k_fma_mix_f32}, {"v_fma_mixlo_f16", k_fma_mixlo_f16},
         {"v_fma_mixhi_f16", k_fma_mixhi_f16}, {"v_max3_f32", k_max3_f32}, {"v_pk_maximum3_f16", k_pk_maximum3_f16},
-        {"v_pk_max_f16", k_pk_max_f16}, {"v_cndmask_b32", k_cndmask}, {"v_permlane32_swap", k_permlane32_swap}};
+        {"v_pk_max_f16", k_pk_max_f16}, {"v_cndmask_b32 (vcc)", k_cndmask}, {"v_cndmask_b32 (sgpr pair)", k_cndmask_sgpr}, {"v_and_or_b32", k_and_or},
+        {"v_lshl_add_u64", k_lshl_add_u64}, {"v_permlane32_swap", k_permlane32_swap}};
     double unit = 0;
     printf("%-22s %10s %10s %10s   (ns per instruction of one wave; independent x8 / dependent chain; 1 and 2 waves per SIMD)\n", "instruction", "indep w1", "dep w1", "indep w2");
     for (auto &k : ks) {
