@@ -192,6 +192,29 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
         rowmin[i] = m;
     }
     __syncthreads();
+    // ORD (K <= 64): the initial label of column j is min over the SOURCE rows i of c_ij = M_ij - pu_i, and a source's pu_i never
+    // moves (its distance is 0 in every search; rows only ever stop being sources), so c is the same matrix for every pair
+    // and every search: M - rowmin.  Each column's rows are ranked by c_ij once per workgroup (ties: lower row first, the
+    // order the rebuild loop finds them in): a column's label source is its source row of smallest RANK -- one byte read and
+    // an integer minimum per source row instead of a readlane pair, a row read, an fp64 subtract, an fp64 compare and three
+    // selects (315 source visits per c3 pair).
+    constexpr bool ORD = NK == 1 && !MG;
+    unsigned char *ord = reinterpret_cast<unsigned char *>(rowmin + K);      // [column][rank] -> row
+    unsigned char *rnk = ord + (size_t)K * K;                                // [column][row] -> rank
+    if constexpr (ORD) {
+        for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
+            const int i = t / K, j = t % K;
+            const double c = Msh[(size_t)i * K + j] - rowmin[i];
+            int rank = 0;
+            for (int i2 = 0; i2 < K; ++i2) {
+                const double c2 = Msh[(size_t)i2 * K + j] - rowmin[i2];
+                rank += (c2 < c || (c2 == c && i2 < i)) ? 1 : 0;
+            }
+            ord[j * K + rank] = (unsigned char)i;
+            rnk[j * K + i] = (unsigned char)rank;
+        }
+        __syncthreads();
+    }
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
     const double INF = __builtin_inf(), NEG = -1.0;
     // LAZY: keep a search going after an augmentation dried its root / emptied an arc / left its target open, and restart
@@ -303,7 +326,29 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             bool src_changed = false;
 #pragma unroll
             for (int e = 0; e < NK; ++e) { src_changed = src_changed || srcmask[e] != prev_src[e]; prev_src[e] = srcmask[e]; }
-            if (src_changed) {
+            if constexpr (ORD) {
+                if (src_changed) {
+                    const unsigned long long sm = srcmask[0];
+                    if (__ballot(lane < K && (Apar[0] < 0 || !((sm >> Apar[0]) & 1ull)))) {     // some column lost its source
+                        unsigned int best = 0xffu;
+                        const unsigned char *rl = rnk + (lane < K ? lane : 0) * K;
+                        unsigned long long m = sm;
+                        while (m) {                                        // wave-uniform
+#if defined(EMD_STAT) && EMD_STAT == 4
+                            ++n_stat;
+#endif
+                            const int i = __builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const unsigned int r = rl[i];
+                            best = r < best ? r : best;
+                        }
+                        if (lane < K) {
+                            Apar[0] = ord[lane * K + best];
+                            A[0] = Msh[(size_t)Apar[0] * K + lane] - rowmin[Apar[0]];
+                        }
+                    }
+                }
+            } else if (src_changed) {
 #pragma unroll
                 for (int e = 0; e < NK; ++e) { A[e] = INF; Apar[e] = -1; }
 #pragma unroll
@@ -537,6 +582,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     if (reach) { parR[e] = __builtin_ctzll(hit) + 64 * wsel; fR[e] = bd; }
                 }
                 // those rows: forward arcs to every open column
+                // (tried: rows tied in one step sharing the per-column tail -- min_i (M_ij - pu_i) first, then one subtract of
+                // pv_j, clamp, add and compare per step: 7.27 -> 7.48 ms at c3, the two extra live values cost more than the
+                // fp64 operations they save at 64 registers per lane)
+                {
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = tieR[e];
@@ -559,6 +608,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                             }
                         }
                     }
+                }
                 }
             }
             if (tripped) break;
