@@ -44,8 +44,7 @@ def test_parity_f32_and_f64(cfg, step, reg):
     Eb, ib = engine.sinkhorn_grid(P, M, reg, precision="bf16x3", row_step=step, return_info=True)
     assert np.abs(Eb - Eo).max() <= TOL32 and (ib["iters"] == i32["iters"]).mean() > 0.98
     assert np.all(isp["iters"] <= io["iters"]) and np.all(isp["iters"] % 20 == 1) and np.all((isp["flags"] & _lib.FLAG_F64) == 0)
-    # same stopping decisions as the f32 MFMA path, up to rounding (at K <= 32 the fp16 configuration keeps duplicate pairs
-    # in tiles while f32 solves them one wave each: a handful more knife-edge checks on c1's 20 duplicates)
+    # same stopping decisions as the f32 MFMA path, up to rounding at knife-edge checks
     assert (isp["iters"] == i32["iters"]).mean() >= 0.97
     assert np.abs(E32 - Eo).max() <= TOL32
     assert np.abs(E64 - Eo).max() <= TOL64
@@ -188,6 +187,27 @@ def test_nonsymmetric_cost(prec, tol):
     Eo = O.sinkhorn_grid(P, M, 0.3, n_threads=16)
     Eg = engine.sinkhorn_grid(P, M, 0.3, precision=prec)
     assert np.abs(Eg - Eo).max() <= tol
+
+
+@pytest.mark.parametrize("K", [10, 30, 50, 64])
+def test_register_image_and_lds_image_give_the_same_bits(K):
+    """fp16-split configuration: with a symmetric cost and K <= 64 the operand image lives in registers and the four
+    accumulator chains are interleaved; declared non-symmetric, the same matrix goes through the LDS image (two forms, tile
+    after tile).  Every tile's MFMA sequence is the same, so off the diagonal (duplicates take the one-wave path only in
+    the symmetric launch) the two must agree bit for bit, update counts included."""
+    P, M = make_problem(60, K, 8, seed=7 * K, cells_per_patient=300)
+    N = P.shape[0]
+    L = _lib.load()
+    out = {}
+    for sym in (1, 0):
+        emd = np.empty((N, N)); iters = np.empty((N, N), dtype=np.int32)
+        _lib.check(L.pilot_ot_sinkhorn_grid(_lib.dptr(P), N, K, _lib.dptr(M), 0.1, 1000, 1e-9, 1e3, 20, _lib.PREC["f16x2"], 0.0, sym,
+                                            0, N, 1, _lib.dptr(emd), _lib.iptr(iters), None, None))
+        out[sym] = (emd, iters)
+    off = ~np.eye(N, dtype=bool)
+    np.testing.assert_array_equal(out[1][0][off], out[0][0][off])
+    np.testing.assert_array_equal(out[1][1][off], out[0][1][off])
+    assert np.abs(out[1][0] - out[0][0]).max() <= TOL32
 
 
 @pytest.mark.parametrize("K", [34, 67])
