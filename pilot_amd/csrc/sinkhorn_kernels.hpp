@@ -6,7 +6,8 @@
 //     u, v of its pairs form K x TILE panels and one Sinkhorn update is two panel products  G^T U  and
 //     G V  with the SHARED K x K Gibbs kernel G = exp(-M/reg);
 //   * G is the stationary MFMA "A" operand, pre-arranged once per launch in LDS in exactly the lane
-//     order the instruction wants (conflict-free, one ds_read per MFMA);
+//     order the instruction wants (conflict-free, one ds_read per MFMA) -- and, in the fp16-split configuration with a
+//     symmetric cost and K <= 64, held in 64 VGPRs per lane instead, so that the update loop reads no LDS at all;
 //   * the result tile of v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64 has its column (= pair) on
 //     the lane and its rows (= cell types) in the accumulator registers, so it is fed back as the "B"
 //     operand of the next product with NO lane movement and NO LDS round trip: k-step (t', r) consumes
