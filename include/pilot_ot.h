@@ -44,7 +44,7 @@ extern "C" {
 
 /* precision of the Sinkhorn pair-grid kernel */
 #define PILOT_OT_MAX_COST_OVER_REG 600.0 /* beyond it exp(-M/reg) leaves the f64 range: every entry point runs PREC_GENERIC */
-#define PILOT_OT_PREC_AUTO 0 /* F16X2 while max(M)/reg <= 11.5, BF16X3 (both f32 values) while exp(-max(M)/reg) stays a normal f32
+#define PILOT_OT_PREC_AUTO 0 /* F16X2 while max(M)/reg <= 16, BF16X3 (both f32 values) while exp(-max(M)/reg) stays a normal f32
                               * far from underflow (<= 60), else AUTO_MIXED / f64 */
 #define PILOT_OT_PREC_F32 1    /* f32 values, products on the f32-input MFMA (v_mfma_f32_16x16x4_f32): IEEE f32 FMA chains */
 #define PILOT_OT_PREC_F64 2
@@ -62,7 +62,7 @@ extern "C" {
                                 * to PREC_F32, ~2x its speed */
 #define PILOT_OT_PREC_F16X2 6  /* f32 values, products on v_mfma_f32_16x16x32_f16 through 2-way fp16 operand splits (11 + 11
                                 * significant bits, three piece products per term) in a fixed scaled domain (2^15 G, 32 u, 32 v):
-                                * valid while max(M)/reg <= 11.5 and tau <= 2000 (PILOT's defaults: reg 0.1 on cost/max, tau 1e3);
+                                * valid while max(M)/reg <= 16 and tau <= 2000 (PILOT's defaults: reg 0.1 on cost/max, tau 1e3);
                                 * outside that range the call runs BF16X3.  Pairs in which POT would tau-absorb are redone by
                                 * the BF16X3 tracking kernel.  Same stopping checks as BF16X3 on 99.9 % of the pairs. */
 
@@ -339,7 +339,7 @@ int pilot_ot_auto_precision_for(double max_cost_over_reg, int K, int cost_is_sym
 /* the precision a call with these arguments RUNS (every Sinkhorn entry point goes through it): GENERIC beyond
  * PILOT_OT_MAX_COST_OVER_REG; AUTO by range; an explicit f32-class precision (F32, BF16X3, F16X2) beyond the f32 range
  * (max(M)/reg > 60) runs AUTO_MIXED -- explicit precisions are honoured inside their valid range only; F16X2 outside its
- * scaled domain (max(M)/reg > 11.5 or tau > 2000) runs BF16X3. */
+ * scaled domain (max(M)/reg > 16 or tau > 2000) runs BF16X3. */
 int pilot_ot_resolve_precision(int precision, double max_cost_over_reg, int K, int cost_is_symmetric, double tau);
 
 #ifdef __cplusplus

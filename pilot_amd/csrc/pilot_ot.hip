@@ -358,16 +358,22 @@ PILOT_API int pilot_ot_cost_matrix(const double *centroids, int K, int D, int me
 }
 
 // ------------------------------------------------------------------------------------------------
+// range of the fp16-split configuration (PILOT_OT_H_MAX_COST_OVER_REG: experiment switch of tools/f16x2_range_probe.py)
+static double h_max_cost_over_reg() {
+    const char *e = getenv("PILOT_OT_H_MAX_COST_OVER_REG");
+    return e && *e ? atof(e) : pilot::H_MAX_COST_OVER_REG;
+}
+
 PILOT_API int pilot_ot_auto_precision(double max_cost_over_reg) {
     // f32 keeps every Gibbs-kernel entry exp(-M/reg) a well-scaled normal number only while
     // max(M)/reg stays clear of the f32 exponent range (ln FLT_MIN = -87.3); beyond ~60 the
     // far-transport entries lose bits, so AUTO switches to the f64 kernel.
     // Inside that range the f32 values are iterated with bf16-split products (PILOT_OT_PREC_BF16X3: f32-level rounding on
     // the bf16 matrix pipe, measured 1.3x the f32-input MFMA path).
-    // While max(M)/reg <= 11.5 (PILOT's default reg = 0.1 on the max-normalised cost gives 10) every entry of 2^15 exp(-M/reg)
-    // is a well-scaled fp16 pair and the products run on 2-way fp16 splits (PILOT_OT_PREC_F16X2: half the MFMAs, a third of
+    // While max(M)/reg <= 16 (PILOT's default reg = 0.1 on the max-normalised cost gives 10) every entry of 2^15 exp(-M/reg)
+    // is a fp16 pair good to <= 2^-15.9 relative (22 bits down to 11.8; see H_MAX_COST_OVER_REG) and the products run on 2-way fp16 splits (PILOT_OT_PREC_F16X2: half the MFMAs, a third of
     // the split instructions of BF16X3; same stopping checks, same 1e-7 class distance to the fp64 oracle).
-    if (max_cost_over_reg <= pilot::H_MAX_COST_OVER_REG) return PILOT_OT_PREC_F16X2;
+    if (max_cost_over_reg <= h_max_cost_over_reg()) return PILOT_OT_PREC_F16X2;
     return max_cost_over_reg <= 60.0 ? PILOT_OT_PREC_BF16X3 : PILOT_OT_PREC_F64;
 }
 
@@ -395,7 +401,7 @@ PILOT_API int pilot_ot_resolve_precision(int precision, double max_cost_over_reg
         if (precision == PILOT_OT_PREC_F64) precision = PILOT_OT_PREC_AUTO_MIXED;    // f32 first, f64 for the pairs that need it
     }
     if (precision == PILOT_OT_PREC_F16X2 &&
-        (max_cost_over_reg > pilot::H_MAX_COST_OVER_REG || tau > pilot::H_MAX_TAU || !split_fits_lds(K, cost_is_symmetric != 0, 1)))
+        (max_cost_over_reg > h_max_cost_over_reg() || tau > pilot::H_MAX_TAU || !split_fits_lds(K, cost_is_symmetric != 0, 1)))
         precision = split_fits_lds(K, cost_is_symmetric != 0, 1) ? PILOT_OT_PREC_BF16X3 : PILOT_OT_PREC_F32;
     return precision;
 }

@@ -102,7 +102,13 @@ struct CfgS32x16 {
 // hands a pair over at u, v > tau <= 2000, so 32 u < 65504), and a = 2^25 a, b = 2^25 b make the update  v~ = b~ / (G~^T u~)
 // come out in the same scaled domain with no extra instruction.  Same accumulator layout as the other 16x16 configurations.
 constexpr float H_PANEL_SCALE = 32.f, H_GIBBS_SCALE = 32768.f, H_IN_SCALE = 33554432.f;     // 2^5, 2^15, 2^25 = 2^15 * 2^5 * 2^5
-constexpr double H_MAX_COST_OVER_REG = 11.5;       // exp(-11.78) * 2^15 = 2^-2: below it the low piece of an entry loses bits
+// Range.  Down to exp(-11.78) 2^15 = 2^-2 both pieces of a Gibbs entry are normal fp16 numbers (22 significant bits).  Below,
+// the low piece is a subnormal with ABSOLUTE spacing 2^-24, i.e. the entry x is off by <= 2^-24 / x relative: a FIXED
+// perturbation of the cost of that arc by reg 2^-24 / x.  At max(M)/reg = 16 the smallest entry is x = 2^15 e^-16 = 2^-8.1,
+// so even a plan with ALL its mass on the smallest entries moves by <= reg 2^-15.9 = 1e-6, a tenth of the f32 tolerance;
+// measured on c2 / c3 / c4 samples: <= 3.2e-7 against the fp64 oracle up to 16 (2.7e-7 for the bf16 split), 4.8e-7 at 20,
+// 1.5e-6 at 22 (tools/f16x2_range_probe.py).  Beyond ~15 the tracking pass takes over the run time and the gain is gone.
+constexpr double H_MAX_COST_OVER_REG = 16.0;
 constexpr double H_MAX_TAU = 2000.0;
 struct CfgH32x16 {
     using T = float;

@@ -168,3 +168,25 @@ def test_c5_full_size_cohort_properties():
     both = conv[:, :4] & conv[:, :4].T
     assert np.abs(sq - sq.T)[both].max() <= 1e-5
     assert (np.argmin(A, axis=1) == np.arange(4)).all()
+
+
+@pytest.mark.parametrize("cfg,step,reg", [("c3", 60, 0.07), ("c2", 5, 0.0625), ("c4", 500, 0.065)])
+def test_fp16_split_configuration_down_to_cost_over_reg_16(cfg, step, reg):
+    """AUTO keeps the fp16-split configuration up to max(M)/reg = 16 (sinkhorn_kernels.hpp, H_MAX_COST_OVER_REG: below 11.8 the
+    low piece of the smallest Gibbs entries is an fp16 subnormal -- a fixed cost perturbation of <= reg 2^-15.9): same
+    tolerance as everywhere, and the same result as asking for f16x2 by name."""
+    from pilot_amd.synthetic import CONFIGS, make_problem
+    P, M = make_problem(**CONFIGS[cfg])
+    L = _lib.load()
+    assert L.pilot_ot_resolve_precision(_lib.PREC["auto"], float(M.max() / reg), P.shape[1], 1, 1e3) == _lib.PREC["f16x2"]
+    assert L.pilot_ot_resolve_precision(_lib.PREC["auto"], 16.5, P.shape[1], 1, 1e3) == _lib.PREC["bf16x3"]
+    Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=16, return_info=True)
+    Ea, ia = engine.sinkhorn_grid(P, M, reg, row_step=step, return_info=True)
+    np.testing.assert_array_equal(Ea, engine.sinkhorn_grid(P, M, reg, precision="f16x2", row_step=step))
+    assert np.abs(Ea - Eo).max() <= 1e-5
+    # (a scaling that jumps past the fp16 range within one update ends as NaN in the fast pass and is solved again by the
+    # POT-literal kernel: a handful of pairs at most)
+    f64 = (ia["flags"] & _lib.FLAG_F64) > 0
+    assert f64.mean() < 0.01 and np.all(ia["iters"][~f64] <= io["iters"][~f64])
+    Eb = engine.sinkhorn_grid(P, M, reg, precision="bf16x3", row_step=step)
+    assert np.abs(Ea - Eb).max() <= 2e-6

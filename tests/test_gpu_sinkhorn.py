@@ -36,11 +36,11 @@ def test_parity_f32_and_f64(cfg, step, reg):
     Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=16, return_info=True)
     E32, i32 = engine.sinkhorn_grid(P, M, reg, precision="fp32", row_step=step, return_info=True)
     E64, i64 = engine.sinkhorn_grid(P, M, reg, precision="fp64", row_step=step, return_info=True)
-    # precision "auto" at these regs (max(M)/reg <= 11.5) = f32 values iterated with fp16-split products (PILOT_OT_PREC_F16X2)
+    # precision "auto" at these regs (max(M)/reg <= 16) = f32 values iterated with fp16-split products (PILOT_OT_PREC_F16X2)
     Es, isp = engine.sinkhorn_grid(P, M, reg, precision="auto", row_step=step, return_info=True)
     np.testing.assert_array_equal(Es, engine.sinkhorn_grid(P, M, reg, precision="f16x2", row_step=step))
     assert np.abs(Es - Eo).max() <= TOL32
-    # the bf16-split configuration (AUTO for 11.5 < max(M)/reg <= 60) on the same problem
+    # the bf16-split configuration (AUTO for 16 < max(M)/reg <= 60) on the same problem
     Eb, ib = engine.sinkhorn_grid(P, M, reg, precision="bf16x3", row_step=step, return_info=True)
     assert np.abs(Eb - Eo).max() <= TOL32 and (ib["iters"] == i32["iters"]).mean() > 0.98
     assert np.all(isp["iters"] <= io["iters"]) and np.all(isp["iters"] % 20 == 1) and np.all((isp["flags"] & _lib.FLAG_F64) == 0)
