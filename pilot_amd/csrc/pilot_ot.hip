@@ -446,7 +446,8 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
     // per-pair work lists of the full grid, so that no grid call allocates (the POT-literal kernel's scratch, 2 K^2 doubles per
     // resident workgroup, is the exception: allocated by the first call that needs that kernel)
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->nan_list), sizeof(int) * (size_t)N * N);
+    // (two lists of N^2: pairs that ended in NaN, and pairs the f32 passes hand to the f64 pass)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->nan_list), 2 * sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) pl->nan_list_n = (size_t)N * N;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->flags_ws), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) pl->flags_ws_n = (size_t)N * N;
@@ -660,14 +661,26 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     if ((size_t)n_pairs > pl->nan_list_n) {
         if (pl->nan_list) HIP_TRY(hipFree(pl->nan_list));
         pl->nan_list = nullptr; pl->nan_list_n = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->nan_list), sizeof(int) * (size_t)n_pairs));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->nan_list), 2 * sizeof(int) * (size_t)n_pairs));
         pl->nan_list_n = (size_t)n_pairs;
     }
     p.nan_list = pl->nan_list; p.nan_count = pl->track_count + 10;
+    // Between the fp16-split range and the two-band path (12 < max(M)/reg <= 60) a few pairs per matrix leave the f32 range in
+    // the single-band kernels (a scaling jumps past the fp16 domain within one update; products underflow at reg <= 0.025).
+    // They used to go to the POT-literal kernel with the other NaN pairs -- one workgroup per pair, 12.5 us per update: 3 to 13
+    // pairs cost 12 ms of a 30 ms call at reg 0.025 .. 0.0175.  They are collected like the small-reg path collects its
+    // hand-over and solved again by the f64 tracking kernel (symmetric cost, K <= 64: one wave per pair, 1.1 us per update).
+    const bool redo64 = !mixed && split && 1.0 / reg > 12.0 && !(debug & 4096);
+    // From max(M)/reg = 24 on nearly every pair tau-absorbs (c3: 28 % at 20, 94 % at 25) and the fast pass only hands its pairs
+    // over after a few dozen wasted updates (3.7 of 11.6 ms at reg 0.04): every pair goes to the tracking kernel at once, as
+    // in the two-band path.
+    const bool track_all = mixed || (split && !half && 1.0 / reg > 24.0 && !(debug & 8192));
+    int *const fb_list = pl->nan_list + pl->nan_list_n;
+    if (redo64) { p.fb_list = fb_list; p.fb_count = pl->track_count + 8; }
     p.debug = debug;
     const int tiles = (n_pairs + TILE - 1) / TILE;
     // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
-    const bool solo = stream_has_solo(w, RT, sym, tv, split, half) && !(p.debug & 512) && !mixed;
+    const bool solo = stream_has_solo(w, RT, sym, tv, split, half) && !(p.debug & 512) && !track_all;
     int solo_blocks = 0;
     {
         // longest-first work order (see order_bucket_kernel)
@@ -695,7 +708,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
                    : pilot::launch_stream_f32(RT, sym, track, dim3(wgs), L.bytes, s, p);
     };
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
-    if (!mixed) {
+    if (!track_all) {
         int want = stream_min_waves(w, RT, sym, false, tv, split, half);
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
         // split configurations up to 4 row-tiles flush their ring inline and park U in LDS meanwhile (pilot::parked_flush):
@@ -724,10 +737,10 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         p.img = static_cast<float *>(img) + pilot::track_img_elems(cfg, RT);
         fixed_t = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * ts + (size_t)KP * ts;
     }
+    if (track_all) { p.list = pl->order_list; p.list_len = nullptr; }     // EVERY pair goes through the tracking kernel (longest first)
     if (mixed) {
-        // small reg: EVERY pair goes through the tracking kernel (longest first), with the Gibbs kernel in two exponent
-        // bands; pairs that still leave the f32 range are collected in track_list for the f64 pass
-        p.list = pl->order_list; p.list_len = nullptr;
+        // small reg: the Gibbs kernel in two exponent bands; pairs that still leave the f32 range are collected in track_list
+        // for the f64 pass
         p.bands = 2;
         p.fb_list = pl->track_list; p.fb_count = pl->track_count + 8;
         fixed_t = (size_t)(sym ? 1 : 2) * form * ts * 2 + (size_t)KP * ts;
@@ -741,7 +754,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         if (wgs_t > need) wgs_t = need;
         HIP_TRY(launch(tv_t, true, wgs_t, L));
     }
-    if (mixed) {
+    if (mixed || redo64) {
         // third pass: the collected pairs in f64 (operand images and proportions rebuilt for the f64 configuration in the
         // same buffers -- the f32 passes are complete in stream order; no ordering, the list is short)
         const int RT64 = RT;
@@ -753,7 +766,8 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         HIP_TRY(pilot::launch_prep(pilot::CFG_F64, d_M, K, RT64, reg, img, d_P, Pt, N, 2, stop_thr, floor_ulps, 0, row_begin, row_step,
                                    pl->order_bucket, pl->order_hist, pl->order_list, pl->track_count + 4, pl->track_count + 1, 0, 1, s));
         pilot::GridParams q = p;
-        q.list = pl->track_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9;
+        q.list = mixed ? pl->track_list : fb_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9;
+        q.img = img;                        // (the fp16-split configuration's tracking pass had moved it to its own block)
         q.fb_list = nullptr; q.fb_count = nullptr; q.bands = 1;
         q.nan_list = pl->nan_list; q.nan_count = pl->track_count + 10;
         if (sym && K <= 64 && !(p.debug & 2048)) {

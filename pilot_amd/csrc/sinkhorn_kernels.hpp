@@ -826,7 +826,9 @@ __device__ inline void solo_pairs(const GridParams &p, unsigned char *solo_smem,
                     if (TRACK && abs_at >= 0 && abs_at == ii - 1) { val *= T(1) / kk; flags |= FLAG_ABSORB_LAST; }
                     if (lane == 0) {
                         if (!(val - val == T(0))) flags |= FLAG_NAN;     // NaN or inf
-                        if (p.nan_list && (flags & FLAG_NAN)) {
+                        if (p.fb_list && (flags & FLAG_NAN) && sizeof(T) == 4) {          // out of the f32 range: the f64 pass
+                            p.fb_list[__hip_atomic_fetch_add(p.fb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
+                        } else if (p.nan_list && (flags & FLAG_NAN)) {
                             p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
                         } else {
                             p.emd[q] = double(val);

@@ -190,3 +190,23 @@ def test_fp16_split_configuration_down_to_cost_over_reg_16(cfg, step, reg):
     assert f64.mean() < 0.01 and np.all(ia["iters"][~f64] <= io["iters"][~f64])
     Eb = engine.sinkhorn_grid(P, M, reg, precision="bf16x3", row_step=step)
     assert np.abs(Ea - Eb).max() <= 2e-6
+
+
+@pytest.mark.parametrize("reg", [0.04, 0.02])
+def test_mid_reg_between_the_fp16_range_and_the_two_band_path(reg):
+    """24 < max(M)/reg <= 60: nearly every pair tau-absorbs, so every pair goes straight to the (single-band) tracking kernel,
+    and the few pairs that leave the f32 range there are solved again by the f64 tracking kernel (FLAG_F64; they used to take
+    the POT-literal kernel, 12 ms for a dozen pairs) -- values within the f32 tolerance, the f64 pairs update for update."""
+    P, M = make_problem(**CONFIGS["c3"])
+    rows = dict(row_begin=3, row_end=600, row_step=40)
+    Eo, io = O.sinkhorn_grid(P, M, reg, n_threads=32, return_info=True, **rows)
+    Eg, ig = engine.sinkhorn_grid(P, M, reg, return_info=True, **rows)
+    assert np.abs(Eg - Eo).max() <= TOL32
+    assert ((ig["flags"] & _lib.FLAG_ABSORBED) > 0).mean() > 0.9
+    f64 = (ig["flags"] & _lib.FLAG_F64) > 0
+    assert f64.mean() < 0.01
+    np.testing.assert_array_equal(ig["iters"][f64], io["iters"][f64])
+    assert np.all(ig["iters"][~f64] <= io["iters"][~f64])
+    # the full matrix: how many pairs take the f64 pass, and that they come out finite
+    E, info = engine.sinkhorn_grid(P, M, reg, return_info=True)
+    assert np.isfinite(E).all() and ((info["flags"] & _lib.FLAG_F64) > 0).sum() < 100
