@@ -59,6 +59,11 @@ def test_argument_validation_needs_no_device():
     rc = L.pilot_ot_cost_matrix(dp(P), 4, 3, 99, dp(out))
     assert rc in (_lib.EINVAL, _lib.EHIP)
     assert L.pilot_ot_auto_precision(10.0) == 6 and L.pilot_ot_auto_precision(30.0) == 3 and L.pilot_ot_auto_precision(100.0) == 2     # f16x2 / bf16x3 / f64
+    # the fp16-split configuration reaches max(M)/reg = 16 (sinkhorn_kernels.hpp, H_MAX_COST_OVER_REG), by name too
+    assert L.pilot_ot_auto_precision(16.0) == 6 and L.pilot_ot_auto_precision(16.1) == 3
+    L.pilot_ot_resolve_precision.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    assert L.pilot_ot_resolve_precision(6, 15.0, 50, 1, 1e3) == 6 and L.pilot_ot_resolve_precision(6, 17.0, 50, 1, 1e3) == 3
+    assert L.pilot_ot_resolve_precision(6, 10.0, 50, 1, 5e3) == 3                # tau beyond the scaled fp16 domain
 
 
 def test_python_wrappers_validate_shapes():
