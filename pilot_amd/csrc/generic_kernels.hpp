@@ -6,9 +6,13 @@
 // log-absorption that the fast kernels only keep books of: when max(u, v) > tau the scalings are folded into the potentials
 // (alpha, beta) and the pair's own kernel matrix K' = exp(-(M - alpha - beta) / reg) is rebuilt, so entries that underflow
 // in the fixed Gibbs image come back (what ADVICE r01 asked for).  K' (and its transpose, for coalesced row products) lives
-// in a per-workgroup global scratch that stays in L2; the vectors live in LDS.  Sums run in the oracle's order (row index
-// ascending), so values agree with the CPU restatement to the last few ulps of exp / log.  Throughput is that of a
-// vector-unit fp64 code with K^2 exponentials per absorption: a correct fallback, not a fast path.
+// in a per-workgroup global scratch that stays in L2; the vectors live in LDS.  A matrix-vector product puts the outputs on
+// the lanes (coalesced rows of K' / K'^T, four outputs per lane at a time) and the contraction range split over up to sixteen waves
+// (as many as LDS has rows of partial sums for); the partial sums of an output are added in wave order, so values agree with the CPU restatement (row index
+// ascending) to a few ulps and are the same on every run.  (Round 3: before, one thread per output summed its K terms
+// serially -- a load round trip per term, K of the 256 threads working: 72 us per update at K = 130; lanes along the
+// contraction with a shuffle tree per output was no better: 33 dependent load + reduce rounds per wave.)  Throughput is
+// that of a vector-unit fp64 code with K^2 exponentials per absorption: a correct fallback, not a fast path.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -25,9 +29,14 @@ struct GenericParams {
     int *queue;                // dynamic pair queue (zeroed by the host)
     const int *list;           // nullable: explicit work-item list (pairs another kernel handed over), length *list_len
     const int *list_len;
+    int nsplit;                // waves that share one output block of a matrix-vector product (power of two <= 16; LDS holds
+                               // nsplit rows of K partial sums)
 };
 
-constexpr int GENERIC_WG = 256;
+#ifndef PILOT_GENERIC_WG
+#define PILOT_GENERIC_WG 1024
+#endif
+constexpr int GENERIC_WG = PILOT_GENERIC_WG, GENERIC_WAVES = GENERIC_WG / 64;     // (sixteen waves: a sixteenth of the contraction range each)
 
 __device__ inline double block_reduce_sum(double x, double *red) {
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
@@ -38,6 +47,10 @@ __device__ inline double block_reduce_sum(double x, double *red) {
     double s = 0.0;
     for (int w = 0; w < GENERIC_WG / 64; ++w) s += red[w];       // fixed order
     return s;
+}
+__device__ inline double wave_tree_sum(double x) {      // every lane gets the sum of the 64, always added in the same order
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;
 }
 __device__ inline double block_reduce_max(double x, double *red) {
     for (int off = 32; off >= 1; off >>= 1) { const double y = __shfl_xor(x, off); x = y > x ? y : x; }
@@ -54,8 +67,9 @@ static __global__ void __launch_bounds__(GENERIC_WG) sinkhorn_generic_kernel(Gen
     extern __shared__ double sm[];
     const int K = p.K, N = p.N;
     double *a = sm, *b = a + K, *u = b + K, *v = u + K, *up = v + K, *vp = up + K, *alpha = vp + K, *beta = alpha + K;
-    double *red = beta + K;                          // 8 doubles
-    int *qs = reinterpret_cast<int *>(red + 8);
+    double *red = beta + K;                          // GENERIC_WAVES doubles
+    double *part = red + GENERIC_WAVES;              // GENERIC_WAVES x K partial sums of a matrix-vector product
+    int *qs = reinterpret_cast<int *>(part + p.nsplit * K);
     double *Km = p.kws + (size_t)blockIdx.x * 2 * K * K, *Kt = Km + (size_t)K * K;
     const double reg = p.reg;
     auto build_kernel = [&]() {                      // K' = exp(-(M - alpha_i - beta_j) / reg): POT get_K
@@ -87,20 +101,40 @@ static __global__ void __launch_bounds__(GENERIC_WG) sinkhorn_generic_kernel(Gen
         for (int ii = 0; ii < p.max_iter; ++ii) {
             for (int k = threadIdx.x; k < K; k += GENERIC_WG) { up[k] = u[k]; vp[k] = v[k]; }
             __syncthreads();
-            // v = b / (K'^T u): column j summed over rows in ascending order (coalesced over j)
-            for (int j = threadIdx.x; j < K; j += GENERIC_WG) {
-                double s = 0.0;
-                for (int i = 0; i < K; ++i) s += Km[(size_t)i * K + j] * u[i];
-                v[j] = b[j] / s;
-            }
-            __syncthreads();
-            // u = a / (K' v): row i summed over columns in ascending order (the transpose keeps the reads coalesced)
-            for (int i = threadIdx.x; i < K; i += GENERIC_WG) {
-                double s = 0.0;
-                for (int j = 0; j < K; ++j) s += Kt[(size_t)j * K + i] * v[j];
-                u[i] = a[i] / s;
-            }
-            __syncthreads();
+            const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+            const int ns = p.nsplit, sw = wave % ns, og = wave / ns, n_og = GENERIC_WAVES / ns;
+            const int c0 = (K * sw) / ns, c1 = (K * (sw + 1)) / ns;       // this wave's part of the contraction range
+            // v = b / (K'^T u): outputs j on the lanes (row i of K' is contiguous over j), rows c0 .. c1 on this wave; four
+            // outputs per lane at a time: 32 independent loads in flight
+            auto product = [&](const double *X, const double *x, const double *num, double *out) {
+                for (int j0 = lane + 256 * og; j0 < K; j0 += 256 * n_og) {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    const bool h1 = j0 + 64 < K, h2 = j0 + 128 < K, h3 = j0 + 192 < K;
+#pragma unroll 8
+                    for (int i = c0; i < c1; ++i) {
+                        const double xi = x[i];
+                        const double *row = X + (size_t)i * K + j0;
+                        s0 += row[0] * xi;
+                        if (h1) s1 += row[64] * xi;
+                        if (h2) s2 += row[128] * xi;
+                        if (h3) s3 += row[192] * xi;
+                    }
+                    part[sw * K + j0] = s0;
+                    if (h1) part[sw * K + j0 + 64] = s1;
+                    if (h2) part[sw * K + j0 + 128] = s2;
+                    if (h3) part[sw * K + j0 + 192] = s3;
+                }
+                __syncthreads();
+                for (int j = threadIdx.x; j < K; j += GENERIC_WG) {
+                    double t = part[j];
+                    for (int w = 1; w < ns; ++w) t += part[w * K + j];          // wave order
+                    out[j] = num[j] / t;
+                }
+                __syncthreads();
+            };
+            product(Km, u, b, v);
+            // u = a / (K' v): outputs i on the lanes (row j of K'^T is contiguous over i)
+            product(Kt, v, a, u);
             iters = ii + 1;
             double mu = 0.0, mv = 0.0, nanf = 0.0;
             for (int k = threadIdx.x; k < K; k += GENERIC_WG) {
@@ -121,12 +155,13 @@ static __global__ void __launch_bounds__(GENERIC_WG) sinkhorn_generic_kernel(Gen
                 ++nabs; last_abs = ii;
             }
             if (ii % p.period == 0) {                          // || Gamma^T 1 - b ||_2 with Gamma = get_Gamma(alpha, beta, u, v)
-                double e2 = 0.0;
-                for (int j = threadIdx.x; j < K; j += GENERIC_WG) {
+                double e2 = 0.0;        // (lane 0 of every wave carries the wave's columns)
+                for (int j = wave; j < K; j += GENERIC_WG / 64) {
                     const double lv = log(v[j]);
                     double s = 0.0;
-                    for (int i = 0; i < K; ++i) s += exp(-(p.M[(size_t)i * K + j] - alpha[i] - beta[j]) / reg + log(u[i]) + lv);
-                    e2 += (s - b[j]) * (s - b[j]);
+                    for (int i = lane; i < K; i += 64) s += exp(-(p.M[(size_t)i * K + j] - alpha[i] - beta[j]) / reg + log(u[i]) + lv);
+                    s = wave_tree_sum(s);
+                    if (lane == 0) e2 += (s - b[j]) * (s - b[j]);
                 }
                 err = sqrt(block_reduce_sum(e2, red));
             }

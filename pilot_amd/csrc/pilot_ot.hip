@@ -514,7 +514,11 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
     const int N = pl->N, K = pl->K;
     const int n_pairs = n_rows * N;
     if (n_pairs == 0) return PILOT_OT_OK;
-    const size_t lds = sizeof(double) * (8 * (size_t)K + 8) + 16;
+    // 8 vectors + nsplit rows of partial sums (as many as fit, a power of two <= the waves of a workgroup) + reduction scratch + queue slot
+    int nsplit = pilot::GENERIC_WAVES;
+    auto lds_for = [&](int ns) { return sizeof(double) * ((8 + (size_t)ns) * (size_t)K + pilot::GENERIC_WAVES) + 16; };
+    while (nsplit > 1 && lds_for(nsplit) > LDS_BYTES) nsplit /= 2;
+    const size_t lds = lds_for(nsplit);
     if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the generic kernel's LDS vectors", K);
     if (!pl->kws) {
         // two workgroups per CU, fewer when K' and its transpose would take more than 8 GB in all
@@ -537,10 +541,11 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
     pilot::GenericParams g;
     g.P = d_P; g.M = d_M; g.N = N; g.K = K; g.n_pairs = n_pairs; g.row_begin = row_begin; g.row_step = row_step;
     g.reg = reg; g.tau = tau; g.stop_thr = stop_thr; g.max_iter = num_iter_max; g.period = check_period;
-    g.emd = d_emd; g.iters = d_iters; g.err = d_err; g.flags = d_flags; g.kws = pl->kws; g.queue = queue;
+    g.emd = d_emd; g.iters = d_iters; g.err = d_err; g.flags = d_flags; g.kws = pl->kws; g.queue = queue; g.nsplit = nsplit;
     g.list = list; g.list_len = list_len;
     int wgs = pl->generic_wgs < n_pairs ? pl->generic_wgs : n_pairs;
     if (list && wgs > 64) wgs = 64;          // a hand-over list is short (usually empty)
+    if (const char *e = getenv("PILOT_OT_GENERIC_WGS")) { const int w = atoi(e); if (w > 0 && w < wgs) wgs = w; }      // experiment switch
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::sinkhorn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pilot::sinkhorn_generic_kernel, dim3(wgs), dim3(pilot::GENERIC_WG), lds, s, g);
     HIP_TRY(hipGetLastError());
