@@ -192,7 +192,7 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 constexpr int MAX_K = 128;          // the MFMA pair-grid kernels (8 row-tiles of 16 cell types)
 constexpr int GENERIC_MAX_K = 2048;  // the reference-semantics fallback kernel (vectors in LDS)
 constexpr int EMD_MAX_K = 256;       // exact-OT kernel: 4 rows / columns per lane
-constexpr int CTRL_INTS = 16;      // control block of a call: see pilot_ot_plan::track_count
+constexpr int CTRL_INTS = pilot::CTRL_INTS;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
@@ -670,6 +670,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         pl->nan_list_n = (size_t)n_pairs;
     }
     p.nan_list = pl->nan_list; p.nan_count = pl->track_count + 10;
+    p.unequal = pl->track_count + pilot::CTRL_UNEQUAL;
     // Between the fp16-split range and the two-band path (12 < max(M)/reg <= 60) a few pairs per matrix leave the f32 range in
     // the single-band kernels (a scaling jumps past the fp16 domain within one update; products underflow at reg <= 0.025).
     // They used to go to the POT-literal kernel with the other NaN pairs -- one workgroup per pair, 12.5 us per update: 3 to 13

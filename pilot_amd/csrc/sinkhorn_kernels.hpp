@@ -649,6 +649,7 @@ struct GridParams {
     int *nan_list;        // nullable: pairs that end in NaN are appended here and re-solved by the POT-literal kernel, which
     int *nan_count;       //   reverts to the last good iterate like POT does (generic_kernels.hpp)
     int debug;            // experiment switches (PILOT_OT_DEBUG): bit0 no priority, bit1 no longest-first order
+    const int *unequal;   // fp16-split configuration: control slot CTRL_UNEQUAL (see the refill of the stream kernel)
 };
 
 // Operand block of one call in global memory, in elements of T (4-byte units for the bf16-split configuration):
@@ -1221,6 +1222,7 @@ sinkhorn_stream_kernel(GridParams p) {
     int res_next = 0, res_end = 0, res_base = 0, qbatch = 0;
     bool exhausted = false;
     bool want = true;  // column asks for a (new) pair
+    const bool hand_all_over = C::HALF && p.unequal && *p.unequal != 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
         const unsigned long long wmask = __ballot(want) & colmask;
@@ -1292,6 +1294,22 @@ sinkhorn_stream_kernel(GridParams p) {
                 thr = Pt[(size_t)N * KP + j] * IN_SCALE;      // stop threshold of column patient j (prep: f32 floor folded in)
                 chk = 1;
                 ii = 0; flags = 0; abs_at = -1; errv = T(1);
+            }
+            if constexpr (C::HALF) {
+                // Histograms of unequal mass (never PILOT's proportions; the ABI takes any P): u grows and v shrinks by the
+                // mass ratio at every update, and long before tau is reached the shrinking panel has left the range in which
+                // two fp16 pieces hold 22 bits (fuzz: 1.1e-5 / 2.4e-5 off at 40 capped updates).  The prep kernel flags such
+                // a P, and this pass only forwards its pairs to the tracking kernel, which iterates f32 values.
+                if (hand_all_over) {                                     // (wave-uniform)
+                    const unsigned long long tm = __ballot(take) & colmask;
+                    if (tm) {
+                        int base = 0;
+                        if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(tm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (take && grp == 0) p.track_list[base + __popcll(tm & ((1ull << col) - 1ull))] = q;
+                    }
+                    if (take) { active = false; want = true; }
+                }
             }
         }
         if (__ballot(active || want) == 0ull) break;
@@ -1633,7 +1651,7 @@ template <class C>
 __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT, double reg,
                                   typename C::T *__restrict__ img, const double *__restrict__ Psrc,
                                   typename C::T *__restrict__ Pdst, long n_p, int write_tail, double stop_thr,
-                                  double floor_ulps, int tid, int nthr) {
+                                  double floor_ulps, int tid, int nthr, int *unequal = nullptr) {
     using M = C;
     using T = typename C::T;
     const int KP = RT * M::TILE;
@@ -1698,9 +1716,14 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
     }
     // stop threshold per (column) patient behind the proportions: POT's stopThr, floored in f32 at floor_ulps * eps * ||b||_2
     // (the marginal error cannot get below the rounding of b itself)
+    double mass0 = 0.0;
+    for (int k = 0; k < K; ++k) mass0 += Psrc[k];
     for (long row = tid; row < n_p / KP; row += nthr) {
-        double n2 = 0.0;
-        for (int k = 0; k < K; ++k) n2 += Psrc[row * K + k] * Psrc[row * K + k];
+        double n2 = 0.0, mass = 0.0;
+        for (int k = 0; k < K; ++k) { n2 += Psrc[row * K + k] * Psrc[row * K + k]; mass += Psrc[row * K + k]; }
+        // histograms of unequal mass: the scalings of a pair drift apart by the mass ratio at every update (see the refill of
+        // the stream kernel); 1e-6 relative is a drift of 0.1 % over 1000 updates
+        if (unequal && !(fabs(mass - mass0) <= 1e-6 * fabs(mass0))) atomicOr(unequal, 1);
         double thr = stop_thr;
         if (sizeof(T) == 4) { const double fl = floor_ulps * 1.1920928955078125e-07 * sqrt(n2); thr = thr > fl ? thr : fl; }
         Pdst[n_p + row] = T(thr);
@@ -1722,6 +1745,9 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
 // duplicates in the last one) and the work list is emitted from the highest bucket down.  Three tiny
 // launches: bucket ids + histogram, (prefix is folded into) scatter.
 constexpr int ORDER_NB = 48;
+// control block of a call (ints, zeroed per call by the host): [0 .. CTRL_INTS) counters and queue heads, then the order
+// histograms.  Slot CTRL_UNEQUAL is set by the prep kernel when the rows of P do not all carry the same mass.
+constexpr int CTRL_INTS = 16, CTRL_UNEQUAL = 12;
 
 // wave-aggregated LDS counter: lanes with equal `b` share one atomic; returns the lane's slot (base + rank among equals)
 __device__ inline int lds_count_aggregated(int *counters, int b, bool valid) {
@@ -1817,7 +1843,8 @@ __global__ void __launch_bounds__(256) sinkhorn_prep_kernel(const double *__rest
         bucket_body(blockIdx.x, Psrc, N, K, n_rows, row_begin, row_step, bucket, hist, collapse, order_smem);
     } else {
         setup_body<C>(Msrc, K, RT, reg, img, Psrc, Pdst, (long)N * RT * C::TILE, write_tail, stop_thr, floor_ulps,
-                      ((int)blockIdx.x - n_tiles) * (int)blockDim.x + (int)threadIdx.x, PREP_SETUP_BLOCKS * (int)blockDim.x);
+                      ((int)blockIdx.x - n_tiles) * (int)blockDim.x + (int)threadIdx.x, PREP_SETUP_BLOCKS * (int)blockDim.x,
+                      hist - (CTRL_INTS - CTRL_UNEQUAL));
     }
 }
 

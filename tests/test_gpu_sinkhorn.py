@@ -189,6 +189,25 @@ def test_nonsymmetric_cost(prec, tol):
     assert np.abs(Eg - Eo).max() <= tol
 
 
+@pytest.mark.parametrize("K,cap", [(48, 40), (64, 40), (50, 1000)])
+def test_unequal_masses_do_not_run_in_the_scaled_fp16_domain(K, cap):
+    """Histograms of unequal mass (never PILOT's proportions, but the ABI takes any P): u grows and v shrinks by the mass
+    ratio at every update and the shrinking panel leaves the range in which two fp16 pieces hold 22 bits long before tau is
+    reached (fuzz: 1.1e-5 / 2.4e-5 off at 40 capped updates, reg 1).  The prep kernel flags such a P and the fp16 pass only
+    forwards its pairs to the tracking kernel: f32 tolerance again, and the equal-mass rows of the same call too."""
+    rng = np.random.default_rng(K + cap)
+    P = rng.dirichlet(np.ones(K), size=40)
+    P[:30] *= rng.uniform(0.5, 2.0, size=(30, 1))
+    _, M = make_problem(40, K, 6, seed=K, cells_per_patient=300)
+    for reg in (1.0, 0.3):
+        Eo, io = O.sinkhorn_grid(P, M, reg, n_threads=16, return_info=True, numItermax=cap)
+        Eg, ig = engine.sinkhorn_grid(P, M, reg, return_info=True, num_iter_max=cap)
+        fin = np.isfinite(Eo)
+        edge = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) != ((ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+        assert np.isfinite(Eg[fin]).all() and edge.mean() < 0.05
+        assert np.abs(Eg - Eo)[fin & ~edge].max() <= TOL32 * max(1.0, np.abs(Eo[fin]).max())
+
+
 @pytest.mark.parametrize("K", [10, 30, 50, 64])
 def test_register_image_and_lds_image_give_the_same_bits(K):
     """fp16-split configuration: with a symmetric cost and K <= 64 the operand image lives in registers and the four
