@@ -884,7 +884,7 @@ __device__ inline __attribute__((always_inline)) void ring_flush_body(const type
     constexpr int PE = ring_panel_elems<C>(RT);
     const T scale = rec[2 * PE];
     // one output row-tile at a time: only the v panel (or its bf16 pieces) is live
-    T val = T(0);
+    T val = T(0), val1 = T(0);
     if constexpr (C::HALF) {
         // the ring holds packed pieces: v's are the B operand as they lie, u = hi + lo
         constexpr int KB = split_kblocks(RT);
@@ -923,13 +923,16 @@ __device__ inline __attribute__((always_inline)) void ring_flush_body(const type
 #pragma unroll
             for (int r = 0; r < NREG; ++r) zero[r] = T(0);
             acc_t w = split_tile_product<C, RT>(img_gm, lane, t, Bv, zero);
+            acc_t ur;
+            load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
             if (p.bands == 2) {                       // wave-uniform
                 const acc_t w1 = split_tile_product<C, RT>(img_gm1, lane, t, Bv, zero);
 #pragma unroll
-                for (int r = 0; r < NREG; ++r) w[r] = fmaf(w1[r], BAND1_DOWN, w[r]);
+                for (int r = 0; r < NREG; ++r) {
+                    w[r] = fmaf(w1[r], BAND1_DOWN, w[r]);
+                    val1 += ur[r] * (w1[r] * BAND1_DOWN);     // the part of the cost that sits on band-1 arcs
+                }
             }
-            acc_t ur;
-            load_regs<C>(rec + (t * NGRP + grp) * NREG, ur);
 #pragma unroll
             for (int r = 0; r < NREG; ++r) val += ur[r] * w[r];
         }
@@ -957,7 +960,14 @@ __device__ inline __attribute__((always_inline)) void ring_flush_body(const type
     }
     val = group_sum<C>(val) * scale;
     if constexpr (C::HALF) val *= T(1) / T(H_IN_SCALE);     // u~^T (2^15 G o M) v~ = 2^25 u^T (G o M) v
-    const bool redo = p.fb_list && !(val - val == T(0));       // NaN or inf: out of the f32 range somewhere along the way
+    bool redo = p.fb_list && !(val - val == T(0));             // NaN or inf: out of the f32 range somewhere along the way
+    if constexpr (C::SPLIT && !C::HALF) {
+        // Two exponent bands: the update loop takes the band-1 partial products from two bf16 pieces (16 bits), which is
+        // rounding noise of 2^-16 on THAT part of a product.  Where band-1 arcs carry more than a quarter of a pair's cost
+        // (tiny K: every off-diagonal arc can be a band-1 arc; the 600 x 50 benchmark: 1e-8 .. 1e-2) that is no longer
+        // below the f32 tolerance (fuzz: 1.2e-5 at K = 2, 3) and the pair is solved again by the f64 pass.
+        if (p.bands == 2 && p.fb_list) redo = redo || group_sum<C>(val1) * scale > T(0.25) * val;
+    }
     if (grp == 0 && col < cnt) {
         const int *meta = reinterpret_cast<const int *>(rec + 2 * PE + 1);
         const int qq = meta[0];
