@@ -164,7 +164,8 @@ int pilot_ot_cost_matrix_dev_ex(const double *d_centroids, int K, int D, int met
  * cost_is_symmetric: 1 if M == M^T exactly (always true for pdist output), 0 otherwise.
  * Range: K <= 128 and max(M)/reg <= 600 run on the MFMA kernels (they keep total scalings against the fixed exp(-M/reg), so
  * the ratio must fit the f64 exponent range); larger K (<= 2048) or smaller reg run PILOT_OT_PREC_GENERIC, whatever precision
- * was asked for.  The device-resident form takes M already divided by its max (Trajectory.py:101) and looks at 1/reg.
+ * was asked for.  The device-resident form cannot see max(M): it judges the range by the plan's max_cost / reg, which is
+ * 1/reg (M divided by its max, Trajectory.py:101) until pilot_ot_plan_set_max_cost says otherwise.
  * emd / iters / err / flags: n_rows x N; iters, err, flags may be NULL. */
 int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg,
                            int num_iter_max, double stop_thr, double tau, int check_period,
@@ -178,6 +179,12 @@ int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, doubl
 typedef struct pilot_ot_plan pilot_ot_plan;
 int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan);
 int pilot_ot_plan_destroy(pilot_ot_plan *plan);
+/* max(M) of the cost matrix the caller keeps on the device (default 1: the cost divided by its maximum, what
+ * Trajectory.py:101 hands to the pair loop).  Every range decision of pilot_ot_sinkhorn_grid_dev -- which precision AUTO
+ * means, the fp16-split domain (max(M)/reg <= 16), the hand-over and two-band thresholds, the POT-literal fallback -- is
+ * taken on max_cost / reg.  A caller whose M is not normalised MUST set it: with max(M) = 3 and reg = 0.1 the Gibbs entries
+ * of the fp16-split images would underflow and the call would return finite but wrong distances. */
+int pilot_ot_plan_set_max_cost(pilot_ot_plan *plan, double max_cost);
 int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *plan, const double *d_P, const double *d_M, double reg,
                                int num_iter_max, double stop_thr, double tau, int check_period,
                                int precision, double f32_floor_ulps, int cost_is_symmetric,

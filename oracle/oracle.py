@@ -72,6 +72,11 @@ def lib() -> ctypes.CDLL:
             dp, ctypes.c_int, ctypes.c_int, dp, ctypes.c_double, ctypes.c_int,
             ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp, ip]
+        L.pilot_oracle_sinkhorn_grid_ex.restype = ctypes.c_int
+        L.pilot_oracle_sinkhorn_grid_ex.argtypes = [
+            dp, ctypes.c_int, ctypes.c_int, dp, ctypes.c_double, ctypes.c_int,
+            ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp, ip]
         L.pilot_oracle_emd2.restype = ctypes.c_double
         L.pilot_oracle_emd2.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_int, dp]
         L.pilot_oracle_emd_grid.restype = ctypes.c_int
@@ -121,8 +126,11 @@ def _rows(N, row_begin, row_end, row_step):
 
 def sinkhorn_grid(P, M, reg, numItermax=NUM_ITER_MAX, stopThr=STOP_THR, tau=TAU,
                   print_period=PRINT_PERIOD, legacy_loop=False, row_begin=0, row_end=None,
-                  row_step=1, n_threads=1, return_info=False):
-    """All ordered pairs (selected rows x all columns) -- Trajectory.py:512-515."""
+                  row_step=1, n_threads=1, return_info=False, stop_floor_ulps=0.0):
+    """All ordered pairs (selected rows x all columns) -- Trajectory.py:512-515.
+
+    ``stop_floor_ulps`` > 0 is NOT POT: stopThr floored per pair at that many f32 ulps of ||b||_2, the f32 GPU kernels'
+    stopping rule, so that bench.py can time the CPU on the update counts the GPU ran (``cpu_baseline_equal_updates``)."""
     P, M = _f64(P), _f64(M)
     N, K = P.shape
     row_end, nrows = _rows(N, row_begin, row_end, row_step)
@@ -130,9 +138,9 @@ def sinkhorn_grid(P, M, reg, numItermax=NUM_ITER_MAX, stopThr=STOP_THR, tau=TAU,
     iters = np.zeros((nrows, N), dtype=np.int32)
     err = np.zeros((nrows, N))
     flags = np.zeros((nrows, N), dtype=np.int32)
-    rc = lib().pilot_oracle_sinkhorn_grid(
+    rc = lib().pilot_oracle_sinkhorn_grid_ex(
         _dptr(P), N, K, _dptr(M), float(reg), int(numItermax), float(tau), float(stopThr),
-        int(print_period), int(bool(legacy_loop)), row_begin, row_end, row_step, int(n_threads),
+        int(print_period), int(bool(legacy_loop)), float(stop_floor_ulps), row_begin, row_end, row_step, int(n_threads),
         _dptr(emd), _iptr(iters), _dptr(err), _iptr(flags))
     if rc != 0:
         raise ValueError("pilot_oracle_sinkhorn_grid: bad arguments")

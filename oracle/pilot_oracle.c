@@ -92,12 +92,19 @@ static void get_Gamma(const double *M, const double *alpha, const double *beta,
  * reset to 1/na,1/nb rather than 1, so the plan evaluated in that same
  * iteration is scaled by 1/(na*nb) until the next update restores the scale.
  */
-ORACLE_API double pilot_oracle_sinkhorn2_stabilized(
+/* doubles of scratch one call needs (K, Gamma, alpha, u, uprev, beta, v, vprev) */
+ORACLE_API size_t pilot_oracle_sinkhorn_ws_doubles(int na, int nb)
+{
+    return (size_t)2 * na * nb + 3 * (size_t)na + 3 * (size_t)nb;
+}
+
+/* The call itself on caller-provided scratch `buf` (pilot_oracle_sinkhorn_ws_doubles(na, nb) doubles): the pair loop keeps
+ * one block per thread instead of a malloc/free per pair (the allocator serialised the OpenMP leg). */
+static double sinkhorn2_stabilized_ws(
     const double *a, const double *b, const double *M, int na, int nb,
     double reg, int numItermax, double tau, double stopThr, int print_period,
-    int legacy_loop, int *info, double *err_out)
+    int legacy_loop, int *info, double *err_out, double *buf)
 {
-    double *buf = (double *)malloc(sizeof(double) * ((size_t)2 * na * nb + 3 * (size_t)na + 3 * (size_t)nb));
     double *K = buf, *G = K + (size_t)na * nb;
     double *alpha = G + (size_t)na * nb, *u = alpha + na, *uprev = u + na;
     double *beta = uprev + na, *v = beta + nb, *vprev = v + nb;
@@ -171,6 +178,17 @@ ORACLE_API double pilot_oracle_sinkhorn2_stabilized(
         info[ORACLE_INFO_FLAGS] = flags;
     }
     if (err_out) *err_out = err;
+    return val;
+}
+
+ORACLE_API double pilot_oracle_sinkhorn2_stabilized(
+    const double *a, const double *b, const double *M, int na, int nb,
+    double reg, int numItermax, double tau, double stopThr, int print_period,
+    int legacy_loop, int *info, double *err_out)
+{
+    double *buf = (double *)malloc(sizeof(double) * pilot_oracle_sinkhorn_ws_doubles(na, nb));
+    const double val = sinkhorn2_stabilized_ws(a, b, M, na, nb, reg, numItermax, tau, stopThr, print_period, legacy_loop,
+                                               info, err_out, buf);
     free(buf);
     return val;
 }
@@ -184,33 +202,58 @@ ORACLE_API double pilot_oracle_sinkhorn2_stabilized(
  * row; iters/err (nullable) have the same shape.  n_threads<=1: the
  * reference's single-threaded order; >1: OpenMP over pairs (bench baseline).
  */
-ORACLE_API int pilot_oracle_sinkhorn_grid(
+/* stop_floor_ulps > 0 (NOT POT: the bench's equal-work leg only): stopThr is floored per pair at
+ * stop_floor_ulps * FLT_EPSILON * ||b||_2, the f32 kernels' rule (sinkhorn_kernels.hpp, setup_body), so that the CPU runs
+ * the update counts the f32 GPU kernels run.  0 = POT's rule. */
+ORACLE_API int pilot_oracle_sinkhorn_grid_ex(
     const double *P, int N, int K, const double *M, double reg,
-    int numItermax, double tau, double stopThr, int print_period, int legacy_loop,
+    int numItermax, double tau, double stopThr, int print_period, int legacy_loop, double stop_floor_ulps,
     int row_begin, int row_end, int row_step, int n_threads,
     double *emd, int *iters, double *err, int *flags)
 {
     if (N <= 0 || K <= 0 || row_step <= 0 || row_begin < 0 || row_end > N) return -1;
     const int nrows = row_end > row_begin ? (row_end - row_begin + row_step - 1) / row_step : 0;
     const long total = (long)nrows * N;
-#ifdef _OPENMP
     if (n_threads < 1) n_threads = 1;
-#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
 #endif
-    for (long t = 0; t < total; ++t) {
-        const int r = (int)(t / N), j = (int)(t % N);
-        const int i = row_begin + r * row_step;
-        int info[ORACLE_INFO_N];
-        double e;
-        emd[t] = pilot_oracle_sinkhorn2_stabilized(P + (size_t)i * K, P + (size_t)j * K, M, K, K,
-                                                   reg, numItermax, tau, stopThr, print_period,
-                                                   legacy_loop, info, &e);
-        if (iters) iters[t] = info[ORACLE_INFO_ITERS];
-        if (err) err[t] = e;
-        if (flags) flags[t] = info[ORACLE_INFO_FLAGS];
+    {
+        double *buf = (double *)malloc(sizeof(double) * pilot_oracle_sinkhorn_ws_doubles(K, K));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (long t = 0; t < total; ++t) {
+            const int r = (int)(t / N), j = (int)(t % N);
+            const int i = row_begin + r * row_step;
+            int info[ORACLE_INFO_N];
+            double e, thr = stopThr;
+            if (stop_floor_ulps > 0.0) {
+                double n2 = 0.0;
+                for (int k = 0; k < K; ++k) n2 += P[(size_t)j * K + k] * P[(size_t)j * K + k];
+                const double fl = stop_floor_ulps * 1.1920928955078125e-07 * sqrt(n2);
+                if (fl > thr) thr = fl;
+            }
+            emd[t] = sinkhorn2_stabilized_ws(P + (size_t)i * K, P + (size_t)j * K, M, K, K,
+                                             reg, numItermax, tau, thr, print_period,
+                                             legacy_loop, info, &e, buf);
+            if (iters) iters[t] = info[ORACLE_INFO_ITERS];
+            if (err) err[t] = e;
+            if (flags) flags[t] = info[ORACLE_INFO_FLAGS];
+        }
+        free(buf);
     }
-    (void)n_threads;
     return 0;
+}
+
+ORACLE_API int pilot_oracle_sinkhorn_grid(
+    const double *P, int N, int K, const double *M, double reg,
+    int numItermax, double tau, double stopThr, int print_period, int legacy_loop,
+    int row_begin, int row_end, int row_step, int n_threads,
+    double *emd, int *iters, double *err, int *flags)
+{
+    return pilot_oracle_sinkhorn_grid_ex(P, N, K, M, reg, numItermax, tau, stopThr, print_period, legacy_loop, 0.0,
+                                         row_begin, row_end, row_step, n_threads, emd, iters, err, flags);
 }
 
 /*

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pilot_ot_device_name", "pilot_ot_dev_alloc", "pilot_ot_dev_free", "pilot_ot_memcpy_h2d",
     "pilot_ot_memcpy_d2h", "pilot_ot_stream_sync", "pilot_ot_cost_matrix", "pilot_ot_cost_matrix_dev",
     "pilot_ot_cost_matrix_ex", "pilot_ot_cost_matrix_dev_ex",
-    "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy",
+    "pilot_ot_sinkhorn_grid", "pilot_ot_plan_create", "pilot_ot_plan_destroy", "pilot_ot_plan_set_max_cost",
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_resolve_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_plan_enable_graph", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_proportions_ex", "pilot_ot_centroid_medians", "pilot_ot_embedding_upload",
@@ -85,6 +85,7 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_sinkhorn_grid.argtypes = [dp, c_int, c_int, dp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int,
                                          c_dbl, c_int, c_int, c_int, c_int, dp, ip, dp, ip]
     L.pilot_ot_plan_create.argtypes = [c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pilot_ot_plan_set_max_cost.argtypes = [c_vp, c_dbl]
     L.pilot_ot_plan_destroy.argtypes = [c_vp]
     L.pilot_ot_sinkhorn_grid_dev.argtypes = [c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl,
                                              c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]

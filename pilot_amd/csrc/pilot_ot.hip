@@ -211,6 +211,8 @@ static int emd_wgs_per_cu(int K) {
 
 struct pilot_ot_plan {
     int N, K, device;
+    double max_cost;   // max(M) of the cost the caller keeps on the device (pilot_ot_plan_set_max_cost; 1 = Trajectory.py:101's
+                       // normalised cost): every range decision of a device-resident call is taken on max_cost / reg
     void *img;         // 3 operand images, sized for f64 at this K
     void *p_slot;      // N x KP proportions in accumulator-slot order (f32 or f64; sized for f64)
     int *track_list;   // N x N
@@ -243,11 +245,11 @@ struct pilot_ot_plan {
     int gkey_seen;                    // the key below was used by an ordinary (uncaptured) call: buffers are grown
     struct GraphKey {
         const void *P, *M, *emd, *iters, *err, *flags;
-        double reg, stop_thr, tau, floor_ulps;
+        double reg, stop_thr, tau, floor_ulps, max_cost;
         int num_iter_max, check_period, cfg, mixed, sym, row_begin, n_rows, row_step, debug;
         bool operator==(const GraphKey &o) const {
             return P == o.P && M == o.M && emd == o.emd && iters == o.iters && err == o.err && flags == o.flags && reg == o.reg &&
-                   stop_thr == o.stop_thr && tau == o.tau && floor_ulps == o.floor_ulps && num_iter_max == o.num_iter_max &&
+                   stop_thr == o.stop_thr && tau == o.tau && floor_ulps == o.floor_ulps && max_cost == o.max_cost && num_iter_max == o.num_iter_max &&
                    check_period == o.check_period && cfg == o.cfg && mixed == o.mixed && sym == o.sym && row_begin == o.row_begin &&
                    n_rows == o.n_rows && row_step == o.row_step && debug == o.debug;
         }
@@ -413,7 +415,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if ((long long)N * N > 0x7fffffffLL) return fail(PILOT_OT_ENOTSUP, "N=%d: N*N overflows the pair index", N);
     pilot_ot_plan *pl = new (std::nothrow) pilot_ot_plan();
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
-    pl->N = N; pl->K = K;
+    pl->N = N; pl->K = K; pl->max_cost = 1.0;
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->emdg_slab = nullptr; pl->emdg_wgs = 0; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
@@ -459,6 +461,13 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
     }
     *plan = pl;
+    return PILOT_OT_OK;
+}
+
+PILOT_API int pilot_ot_plan_set_max_cost(pilot_ot_plan *pl, double max_cost) {
+    if (!pl) return fail(PILOT_OT_EINVAL, "plan is NULL");
+    if (!(max_cost > 0.0) || !std::isfinite(max_cost)) return fail(PILOT_OT_EINVAL, "max_cost=%g must be positive and finite", max_cost);
+    pl->max_cost = max_cost;
     return PILOT_OT_OK;
 }
 
@@ -676,11 +685,11 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     // They used to go to the POT-literal kernel with the other NaN pairs -- one workgroup per pair, 12.5 us per update: 3 to 13
     // pairs cost 12 ms of a 30 ms call at reg 0.025 .. 0.0175.  They are collected like the small-reg path collects its
     // hand-over and solved again by the f64 tracking kernel (symmetric cost, K <= 64: one wave per pair, 1.1 us per update).
-    const bool redo64 = !mixed && split && 1.0 / reg > 12.0 && !(debug & 4096);
+    const bool redo64 = !mixed && split && pl->max_cost / reg > 12.0 && !(debug & 4096);
     // From max(M)/reg = 24 on nearly every pair tau-absorbs (c3: 28 % at 20, 94 % at 25) and the fast pass only hands its pairs
     // over after a few dozen wasted updates (3.7 of 11.6 ms at reg 0.04): every pair goes to the tracking kernel at once, as
     // in the two-band path.
-    const bool track_all = mixed || (split && !half && 1.0 / reg > 24.0 && !(debug & 8192));
+    const bool track_all = mixed || (split && !half && pl->max_cost / reg > 24.0 && !(debug & 8192));
     int *const fb_list = pl->nan_list + pl->nan_list_n;
     if (redo64) { p.fb_list = fb_list; p.fb_count = pl->track_count + 8; }
     p.debug = debug;
@@ -810,21 +819,21 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     if (rc != PILOT_OT_OK) return rc;
     {
         const int n_rows_g = (row_end - row_begin + row_step - 1) / row_step;
-        // K beyond the MFMA kernels, a reg beyond the f64 range of exp(-M/reg) (M is /max, Trajectory.py:101: device-resident
-        // callers keep that convention), or on request: POT's loop literally, absorbed kernel rebuilt per pair
-        if (precision == PILOT_OT_PREC_GENERIC || pl->K > MAX_K || 1.0 / reg > MAX_COST_OVER_REG)
+        // K beyond the MFMA kernels, a reg beyond the f64 range of exp(-M/reg) (judged by the plan's max_cost), or on request: POT's loop literally, absorbed kernel rebuilt per pair
+        if (precision == PILOT_OT_PREC_GENERIC || pl->K > MAX_K || pl->max_cost / reg > MAX_COST_OVER_REG)
             return run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows_g, row_step, d_emd,
                                d_iters, d_err, d_flags, static_cast<hipStream_t>(stream));
     }
-    // (M is /max, Trajectory.py:101: the range is judged by 1/reg here; host callers have resolved with the true max(M) already)
-    precision = pilot_ot_resolve_precision(precision, 1.0 / reg, pl->K, cost_is_symmetric, tau);
+    // (the range is judged by the plan's max_cost / reg: 1 / reg for Trajectory.py:101's normalised cost unless the caller said
+    // otherwise with pilot_ot_plan_set_max_cost; the host and multi-device entry points set it from the M they copy in)
+    precision = pilot_ot_resolve_precision(precision, pl->max_cost / reg, pl->K, cost_is_symmetric, tau);
     bool mixed = false;
     if (precision == PILOT_OT_PREC_AUTO_MIXED) {
         precision = PILOT_OT_PREC_F64;
         mixed = true;
     }
     // beyond the f32 range AUTO still tries f32 first, pair by pair, where the split images fit and POT's defaults hold
-    mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && 1.0 / reg <= 140.0 && !getenv("PILOT_OT_NO_MIXED");
+    mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && pl->max_cost / reg <= 140.0 && !getenv("PILOT_OT_NO_MIXED");
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -845,7 +854,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     // graph replay: the first call with a new argument set runs as usual (and grows the work buffers), the second one is
     // captured, later ones replay the instantiated graph
     const char *dbg = getenv("PILOT_OT_DEBUG");
-    const pilot_ot_plan::GraphKey key = {d_P, d_M, d_emd, d_iters, d_err, d_flags, reg, stop_thr, tau, f32_floor_ulps, num_iter_max,
+    const pilot_ot_plan::GraphKey key = {d_P, d_M, d_emd, d_iters, d_err, d_flags, reg, stop_thr, tau, f32_floor_ulps, pl->max_cost, num_iter_max,
                                          check_period, cfg, mixed ? 1 : 0, cost_is_symmetric != 0 ? 1 : 0, row_begin, n_rows, row_step,
                                          dbg ? atoi(dbg) : 0};
     if (pl->gexec && key == pl->gkey) {
@@ -1079,6 +1088,7 @@ PILOT_API int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double
     hipError_t e = hipMemcpy(h.dP, P, sizeof(double) * (size_t)N * K, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h.dM, M, sizeof(double) * (size_t)K * K, hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
+    h.plan->max_cost = mx > 0.0 ? mx : 1.0;
     rc = pilot_ot_sinkhorn_grid_dev(h.plan, h.dP, h.dM, reg, num_iter_max, stop_thr, tau, check_period, precision,
                                     f32_floor_ulps, cost_is_symmetric, row_begin, row_end, row_step, h.dE,
                                     iters ? h.dIt : nullptr, err ? h.dErr : nullptr, h.dFl, nullptr);

@@ -414,6 +414,7 @@ PILOT_API int pilot_ot_multi_set_inputs(pilot_ot_multi *m, const double *P, cons
     m->max_cost = mx;
     DeviceGuard guard;
     for (Shard &h : m->sh) {
+        if (mx > 0.0) { const int r = pilot_ot_plan_set_max_cost(h.plan, mx); if (r != PILOT_OT_OK) return r; }
         HIP_TRY(hipSetDevice(h.device));
         HIP_TRY(hipMemcpyAsync(h.dP, P, sizeof(double) * (size_t)m->N * m->K, hipMemcpyHostToDevice, h.stream));
         HIP_TRY(hipMemcpyAsync(h.dM, M, sizeof(double) * (size_t)m->K * m->K, hipMemcpyHostToDevice, h.stream));

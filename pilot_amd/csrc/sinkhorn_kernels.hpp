@@ -1353,7 +1353,8 @@ sinkhorn_stream_kernel(GridParams p) {
                 for (int h = 0; h < 4; ++h)
                     if (pieces_live(kb, h)) m2 = pk_max3_f16(m2, PU.p[0][kb][h], PV.p[0][kb][h]);
             const f16x2_t mh = __builtin_bit_cast(f16x2_t, m2);
-            mx = fmax(float(mh[0]), float(mh[1]));
+            const float m0 = float(mh[0]), m1 = float(mh[1]);
+            mx = (m0 <= tau && m1 <= tau) ? fmax(m0, m1) : __builtin_inff();      // a NaN half counts as over (see below)
         } else {
         // ---- v = b / (G^T u) --------------------------------------------------------------------------
 #pragma unroll
@@ -1379,6 +1380,11 @@ sinkhorn_stream_kernel(GridParams p) {
             }
         }
         // POT: max|u| > tau or max|v| > tau  ->  absorb.  "any lane of the column over tau" == "column max over tau"
+        // (fp16-split configuration: a scaling that jumps from below tau past the fp16 range in ONE update -- 531 -> 2071 at
+        // K = 2 -- becomes the pieces (inf, -inf), the next product NaN, and a NaN maximum is not "> tau": such a pair used to
+        // end at its next error test as "numerical errors" and take the POT-literal kernel, one workgroup per pair -- 65 of the
+        // 67 ms of a 600 x 2 call.  There a NaN maximum counts as over (mx = inf, above): the tracking kernel, which iterates
+        // f32 values, restarts the pair.)
         const unsigned long long omask = column_any_mask<C>(active && mx > tau);
         const bool over = (omask >> col) & 1ull;
         if constexpr (TRACK) {
@@ -1830,6 +1836,14 @@ __device__ inline void bucket_body(int tile, const double *__restrict__ Psrc, in
             const float v = 4.f * (1.f - log2f(l1[r]));      // l1 = 2 -> 0, halves add 4
             b = v < 0.f ? 0 : (v > float(ORDER_NB - 2) ? ORDER_NB - 2 : int(v));
             if (collapse) b = 0;       // experiment switch: natural order, only the duplicates are told apart
+        } else if (row_begin + rr * row_step != jb + jl) {
+            // a == b bit for bit but two DIFFERENT patients: stays in the tiles, at the head of their queue.  Only the diagonal
+            // takes the one-wave path -- it is sized for one pair per row, and a cohort with a handful of cell types has
+            // thousands of duplicate patients (K = 2, 200 cells each: 6 700 of 360 000 pairs, a quarter of them running to the
+            // cap), which 16 to a wave in the tiles take a fraction of the time they queue for on solo waves
+            // (profiles/r04/small_k_probe.txt).  A rule by VALUE (the two indices), like the old one: a row shard and the
+            // full grid still send the same pair down the same path.
+            b = ORDER_NB - 2;
         }
         if (valid) bucket[(size_t)rr * N + jb + jl] = (unsigned char)b;
         (void)lds_count_aggregated(lh, b, valid);

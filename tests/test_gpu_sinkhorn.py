@@ -245,9 +245,10 @@ def test_nonsymmetric_cost_with_tail_rows(K, prec, tol):
 
 @pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("f16x2", TOL32), ("fp64", TOL64)])
 def test_duplicate_patients_take_the_solo_path(prec, tol, monkeypatch):
-    """Pairs with a == b bit for bit (the diagonal AND duplicate patients) are solved one per wavefront; more duplicates
-    than rows must queue up, row shards must reproduce the full matrix, and switching the path off must agree within
-    the tolerance (different summation order, same iteration)."""
+    """The diagonal pairs (i, i) are solved one per wavefront; duplicate PATIENTS (a == b bit for bit, i != j) stay in the
+    tiles since round 4 (a cohort with a handful of cell types has thousands of them).  Row shards must reproduce the full
+    matrix, and switching the one-wave path off must agree within the tolerance (different summation order, same
+    iteration) and leave every off-diagonal pair bit for bit alone."""
     P, M = make_problem(30, 50, 6, seed=77, cells_per_patient=300)
     P[[5, 12, 20]] = P[0]
     P[29] = P[3]
@@ -262,12 +263,58 @@ def test_duplicate_patients_take_the_solo_path(prec, tol, monkeypatch):
     monkeypatch.setenv("PILOT_OT_DEBUG", "512")
     Eoff = engine.sinkhorn_grid(P, M, 0.1, precision=prec)
     monkeypatch.delenv("PILOT_OT_DEBUG")
-    dup = np.zeros((30, 30), dtype=bool)
-    for grp in ([0, 5, 12, 20], [3, 29]):
-        dup[np.ix_(grp, grp)] = True
-    dup |= np.eye(30, dtype=bool)
-    np.testing.assert_array_equal(Eoff[~dup], Eg[~dup])        # everything else is the same code path, bit for bit
+    dup = np.eye(30, dtype=bool)
+    np.testing.assert_array_equal(Eoff[~dup], Eg[~dup])        # everything off the diagonal is the same code path, bit for bit
     assert np.abs(Eoff - Eg).max() <= tol
+
+
+@pytest.mark.parametrize("K", [2, 3, 4, 5, 8])
+def test_single_digit_cell_type_counts_stay_on_the_mfma_kernels(K, monkeypatch):
+    """Pathomics cohorts have single-digit K.  Their scalings can jump from below tau past the fp16 range within one update
+    (531 -> 2071 at K = 2): such a pair must be handed to the f32 tracking kernel, not end as "numerical errors" and take the
+    POT-literal kernel (round 3: 20 580 of 360 000 pairs at K = 2, 65 of the call's 67 ms).  With the hand-over launch
+    switched off (PILOT_OT_DEBUG=1024) a pair it would have solved keeps the sentinel written here -- timing-free check of
+    WHICH kernel solves these pairs -- and the values must be the oracle's."""
+    P, M = make_problem(160, K, 8, seed=K, cells_per_patient=200)
+    N = P.shape[0]
+    Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
+    monkeypatch.setenv("PILOT_OT_DEBUG", "1024")
+    plan = engine.DevicePlan(P, M)
+    sent = np.full(N * N, -7, dtype=np.int32)
+    _lib.check(plan.L.pilot_ot_memcpy_h2d(plan.dFl, sent.ctypes.data, sent.nbytes))
+    plan.run(0.1)
+    plan.sync()
+    E, info = plan.fetch()
+    plan.close()
+    assert int((info["flags"] == -7).sum()) == 0, "pairs were left to the POT-literal kernel"
+    assert int((info["flags"] & _lib.FLAG_F64).sum()) == 0
+    absorbed = (io["flags"] & O.FLAG_ABSORBED) > 0
+    assert absorbed.sum() > 0                                   # the case this test is about occurs in the cohort
+    assert (((info["flags"] & _lib.FLAG_ABSORBED) > 0) != absorbed).mean() < 0.01      # (a scaling within rounding of tau may differ)
+    edge = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((info["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+    assert np.abs(E - Eo)[~edge].max() <= TOL32
+    # duplicate patients (a == b, i != j: hundreds at this K) run in the tiles, the diagonal on waves of its own; both within tolerance
+    dup = (np.abs(P[:, None, :] - P[None, :, :]).sum(-1) == 0) & ~np.eye(N, dtype=bool)
+    assert dup.sum() > 0 and np.abs(E - Eo)[dup & ~edge].max() <= TOL32
+
+
+def test_device_resident_call_with_a_cost_that_is_not_normalised():
+    """the device entry point cannot see max(M).  DevicePlan tells the plan (pilot_ot_plan_set_max_cost),
+    and AUTO must then leave the fp16-split domain (valid while max(M)/reg <= 16) instead of returning finite but wrong
+    distances: max(M) = 3 at reg 0.1 is a ratio of 30."""
+    P, M = make_problem(48, 20, 6, seed=11, cells_per_patient=300)
+    M3 = 3.0 * M
+    Eo = O.sinkhorn_grid(P, M3, 0.1, n_threads=16)
+    plan = engine.DevicePlan(P, M3)
+    assert plan.max_cost == pytest.approx(3.0)
+    plan.run(0.1)
+    plan.sync()
+    E, info = plan.fetch()
+    plan.close()
+    assert np.abs(E - Eo).max() <= TOL32 * 3.0
+    np.testing.assert_array_equal(E, engine.sinkhorn_grid(P, M3, 0.1))     # the host entry point takes the same decisions
+    with pytest.raises(_lib.PilotOTError):
+        _lib.check(_lib.load().pilot_ot_plan_set_max_cost(None, 1.0))
 
 
 def test_row_selection_and_single_row_grids():
