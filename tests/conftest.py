@@ -11,6 +11,9 @@ os.environ.setdefault("PILOT_AMD_NO_RESULTS_DIR", "1")
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = ["c1_20x10x10", "c2s_100x30x30", "ragged_categorical_12x7x5", "pathomics_15x6x8"]
+# the reference's OWN test input (test/test_pilot.py:6-15): Tutorial/Datasets/Kidney_IgAN_G.h5ad, 634 patients x 14 clusters x 14
+# morphometric features, run through the reference's wasserstein_distance(data_type='Pathomics'); rows 0::3 of the matrices stored
+GOLDEN_REAL = "kidney_igan_g_634x14x14"
 # reference-executed with NON-default options (metric, regulizer, reg are stored in the fixture)
 GOLDEN_OPTION_CASES = ["opts_euclidean_18x10x6", "opts_cityblock_14x8x4"]
 
@@ -59,11 +62,33 @@ def golden_adata(g, categorical=False):
     cell_col = "Cell_type" if pathomics else "cell_types"
     obs = pd.DataFrame({cell_col: g["obs_cell"].astype(object), "sampleID": g["obs_sample"].astype(object),
                         "status": g["obs_status"].astype(object)})
+    if "obs_cell_dtype" in g:            # the real dataset: the obs dtypes anndata gives (int64 clusters, stored category orders)
+        obs[cell_col] = g["obs_cell"].astype(str(g["obs_cell_dtype"]))
+        obs["sampleID"] = pd.Categorical(g["obs_sample"].astype(object), categories=list(g["sample_categories"]))
+        obs["status"] = pd.Categorical(g["obs_status"].astype(object), categories=list(g["status_categories"]))
     if categorical:
         for c in obs.columns:
             obs[c] = obs[c].astype("category")
     ad = Cohort(g["emb"], obs, emb_key="X_pca")
+    if "var_names" in g:
+        ad.var_names = [str(v) for v in g["var_names"]]
     return ad, cell_col
+
+
+def frame_digests(uns):
+    """SHA-256 of adata.uns['data'] / ['annot'] exactly as tests/golden/gen_golden.py::frame_digests takes them of the
+    reference's frames (values + dtype + column names of `data`; the three label columns of `annot` as strings)."""
+    import hashlib
+    data, annot = uns["data"], uns["annot"]
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(data.to_numpy()).tobytes())
+    h.update(("|" + str(data.to_numpy().dtype) + "|" + "\x1f".join(str(c) for c in data.columns)).encode())
+    g = hashlib.sha256()
+    g.update("\x1e".join(str(c) for c in annot.columns).encode())
+    for c in annot.columns:
+        g.update(("\x1d" + "\x1f".join(str(v) for v in annot[c].tolist())).encode())
+    g.update(("|%d" % len(annot)).encode())
+    return h.hexdigest(), g.hexdigest()
 
 
 def load_golden_pack(name="random_pack"):

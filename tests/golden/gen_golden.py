@@ -103,8 +103,26 @@ def import_reference():
     return T
 
 
+def frame_digests(uns):
+    """SHA-256 of what the reference leaves in adata.uns['data'] / ['annot'] (Trajectory.py:92-93): the values' bytes, dtype and
+    column names of `data`; the three label columns of `annot` as strings.  The tests hold tl.wasserstein_distance to these."""
+    import hashlib
+    data, annot = uns["data"], uns["annot"]
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(data.to_numpy()).tobytes())
+    h.update(("|" + str(data.to_numpy().dtype) + "|" + "\x1f".join(str(c) for c in data.columns)).encode())
+    g = hashlib.sha256()
+    g.update("\x1e".join(str(c) for c in annot.columns).encode())
+    for c in annot.columns:
+        g.update(("\x1d" + "\x1f".join(str(v) for v in annot[c].tolist())).encode())
+    g.update(("|%d" % len(annot)).encode())
+    return h.hexdigest(), g.hexdigest()
+
+
 def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.1, clusters_col="cell_types", metric="cosine",
-             regulizer=0.2):
+             regulizer=0.2, row_step=1, extra=None):
+    """row_step > 1: only rows 0, row_step, ... of the two N x N matrices are stored (a 634-patient cohort would be 13 MB of
+    float64); the frames' labels and everything else are stored whole."""
     obs = adata.obs
     results = {}
     for mode in ("unreg", "reg"):
@@ -115,17 +133,25 @@ def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.
     u = results["unreg"]
     samples = list(u["proportions"].keys())
     cells = list(u["cost"].columns)
+    data_sha, annot_sha = frame_digests(u)
+    assert (data_sha, annot_sha) == frame_digests(results["reg"])
+    for mode in results:       # the frame is from_dict(EMD).T with the sample ids on both axes (Trajectory.py:518-521)
+        df = results[mode]["EMD_df"]
+        assert np.array_equal(df.to_numpy(), results[mode]["EMD"].T) and list(df.columns) == samples and list(df.index) == samples
     np.savez_compressed(
         os.path.join(out_dir, name + ".npz"),
-        emb=np.asarray(adata.obsm[emb_key]),
+        data_sha256=np.asarray(data_sha), annot_sha256=np.asarray(annot_sha), row_step=np.asarray(row_step),
+        **(extra or {}),
+        emb=np.asarray(adata.obsm[emb_key] if emb_key in adata.obsm else adata.X),
         obs_cell=np.asarray(obs[clusters_col].astype(str), dtype=str), obs_sample=np.asarray(obs["sampleID"].astype(str), dtype=str),
         obs_status=np.asarray(obs["status"].astype(str), dtype=str),
         samples=np.asarray(samples, dtype=str), cells=np.asarray(cells, dtype=str),
         proportions=np.stack([u["proportions"][s] for s in samples]),
         cost=u["cost"].to_numpy(), cost_index_name=np.asarray(str(u["cost"].index.name)),
         real_labels=np.asarray(u["real_labels"], dtype=str),
-        emd_unreg=u["EMD"], emd_unreg_df=u["EMD_df"].to_numpy(),
-        emd_reg=results["reg"]["EMD"], emd_reg_df=results["reg"]["EMD_df"].to_numpy(),
+        emd_unreg=u["EMD"][::row_step], emd_reg=results["reg"]["EMD"][::row_step],
+        # (the frames are the transposes, asserted above; stored only with the full matrices)
+        **({"emd_unreg_df": u["EMD_df"].to_numpy(), "emd_reg_df": results["reg"]["EMD_df"].to_numpy()} if row_step == 1 else {}),
         emd_df_index_name=np.asarray(str(u["EMD_df"].index.name)),
         reg=np.asarray(reg), data_type=np.asarray(data_type), metric=np.asarray(metric), regulizer=np.asarray(regulizer),
         uns_keys=np.asarray(sorted(u.keys()), dtype=str),
@@ -133,6 +159,30 @@ def run_case(T, name, adata, out_dir, data_type="scRNA", emb_key="X_pca", reg=0.
     )
     print(name, "N=%d K=%d C=%d" % (len(samples), len(cells), len(obs)), "EMD unreg max", u["EMD"].max(),
           "reg max", results["reg"]["EMD"].max())
+
+
+def real_dataset_case(T, out_dir):
+    """The reference's OWN test input (test/test_pilot.py:6-15): Tutorial/Datasets/Kidney_IgAN_G.h5ad through
+    wasserstein_distance(clusters_col='Cell_type', sample_col='sampleID', status='status', data_type='Pathomics').
+    scanpy / anndata / h5py are absent here, so the file is read by tests/golden/mini_h5.py and wrapped in the same
+    duck-typed AnnData as the synthetic cohorts, with the obs dtypes anndata would give (int64 cell types, categorical
+    sample ids and status with the stored category order).  634 patients x 14 glomerulus clusters x 14 morphometric
+    features, 24 227 glomeruli: real labels, real K, real (heavily duplicated, tiny) cohorts."""
+    import mini_h5
+    from pilot_amd.synthetic import Cohort
+    path = os.path.join(REFERENCE, "Tutorial", "Datasets", "Kidney_IgAN_G.h5ad")
+    d = mini_h5.read_h5ad(path)
+    obs = pd.DataFrame({
+        "Cell_type": d["obs"]["Cell_type"],
+        "sampleID": pd.Categorical(d["obs"]["sampleID"][0], categories=list(d["obs"]["sampleID"][1])),
+        "status": pd.Categorical(d["obs"]["status"][0], categories=list(d["obs"]["status"][1])),
+    }, index=pd.Index(d["obs_names"]))
+    ad = Cohort(d["X"], obs)
+    ad.var_names = [str(v) for v in d["var_names"]]
+    extra = dict(obs_cell_dtype=np.asarray(str(obs["Cell_type"].dtype)), sample_categories=np.asarray(list(d["obs"]["sampleID"][1]), dtype=str),
+                 status_categories=np.asarray(list(d["obs"]["status"][1]), dtype=str), var_names=np.asarray(ad.var_names, dtype=str),
+                 source=np.asarray("Tutorial/Datasets/Kidney_IgAN_G.h5ad (reference test/test_pilot.py:6-15), read by tests/golden/mini_h5.py"))
+    run_case(T, "kidney_igan_g_634x14x14", ad, out_dir, data_type="Pathomics", clusters_col="Cell_type", row_step=3, extra=extra)
 
 
 def main():
@@ -207,6 +257,7 @@ def main():
                         pack["c%d_%s" % (i, k)] = z[k]
             pack["n_cases"] = np.asarray(n_pack)
             np.savez_compressed(os.path.join(out_dir, "random_pack.npz"), **pack)
+            real_dataset_case(T, out_dir)
         finally:
             os.chdir(cwd)
 

@@ -4,7 +4,7 @@ import pandas as pd
 import pytest
 import scipy.spatial.distance as ssd
 
-from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden, load_golden_pack
+from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, GOLDEN_REAL, frame_digests, golden_adata, load_golden, load_golden_pack
 from oracle import oracle as O
 from pilot_amd import _lib, engine, tl
 from pilot_amd.synthetic import CONFIGS, make_cells, make_problem
@@ -297,11 +297,12 @@ def test_cost_matrix_golden(name):
 
 
 # ------------------------------------------------------------------------------- tl surface
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + [GOLDEN_REAL])
 @pytest.mark.parametrize("mode", ["unreg", "reg"])
 def test_wasserstein_distance_end_to_end_vs_reference_fixture(name, mode, tmp_path, monkeypatch):
     """Mirror of the reference's own test (test/test_pilot.py:9-28) plus numbers: same call, same uns keys,
-    same Python types, values within tolerance of what the reference's code produced (golden)."""
+    same Python types, values within tolerance of what the reference's code produced (golden).  The last case IS the
+    reference test's input: Tutorial/Datasets/Kidney_IgAN_G.h5ad with data_type='Pathomics' (634 patients, 14 clusters)."""
     monkeypatch.chdir(tmp_path)
     g = load_golden(name)
     ad, cell_col = golden_adata(g, categorical=(name.startswith("ragged")))
@@ -316,7 +317,8 @@ def test_wasserstein_distance_end_to_end_vs_reference_fixture(name, mode, tmp_pa
     assert isinstance(E, np.ndarray) and E.dtype == np.float64
     assert E.shape[0] == E.shape[1] == len(u["real_labels"]) == len(g["samples"])       # test_pilot.py:26-28
     want = g["emd_unreg"] if mode == "unreg" else g["emd_reg"]
-    assert np.abs(E - want).max() <= 1e-12
+    assert np.abs(E[::int(g["row_step"])] - want).max() <= 1e-12        # (the 634-patient case stores rows 0, 3, 6, ..)
+    assert frame_digests(u) == (str(g["data_sha256"]), str(g["annot_sha256"]))     # uns['data'], uns['annot']: the reference's bytes
     df = u["EMD_df"]
     assert isinstance(df, pd.DataFrame) and df.index.name == "sampleID"
     assert [str(s) for s in df.index] == list(g["samples"]) == [str(s) for s in df.columns]
@@ -341,6 +343,7 @@ def test_wasserstein_distance_with_other_options_vs_reference_fixture(name, mode
                             engine_options={"precision": "fp64"})
     u = ad.uns
     assert sorted(u.keys()) == list(g["uns_keys"])
+    assert frame_digests(u) == (str(g["data_sha256"]), str(g["annot_sha256"]))
     assert [str(k) for k in u["proportions"]] == list(g["samples"])
     np.testing.assert_array_equal(np.stack(list(u["proportions"].values())), g["proportions"])
     assert [str(c) for c in u["cost"].columns] == list(g["cells"]) == [str(c) for c in u["cost"].index]

@@ -4,7 +4,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, golden_adata, load_golden, load_golden_pack
+from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, GOLDEN_REAL, golden_adata, load_golden, load_golden_pack
 from oracle import oracle as O
 from pilot_amd import tl
 
@@ -18,7 +18,7 @@ def _annot(g):
                                                     sample_col="sampleID", status="status")
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + [GOLDEN_REAL])
 def test_extract_frames_have_reference_columns(name):
     g = load_golden(name)
     data, annot = _annot(g)
@@ -29,7 +29,7 @@ def test_extract_frames_have_reference_columns(name):
     assert tl.path_to_results == "Results_PILOT/plots"
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + [GOLDEN_REAL])
 @pytest.mark.parametrize("categorical", [False, True])
 def test_label_codes_follow_first_appearance_order(name, categorical):
     """The host's only job for Cluster_Representations / cost_matrix is factorising the label columns; the
@@ -47,7 +47,7 @@ def test_label_codes_follow_first_appearance_order(name, categorical):
     np.testing.assert_array_equal(np.asarray(cells, dtype=object)[ccodes], annot["cell_type"].astype(object).to_numpy())
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + [GOLDEN_REAL])
 def test_oracle_restatements_match_the_reference_fixture(name):
     """oracle.cluster_representations / oracle.cost_matrix (what the GPU kernels are checked against) reproduce
     the numbers the reference's own code produced, bit for bit."""
@@ -61,6 +61,24 @@ def test_oracle_restatements_match_the_reference_fixture(name):
     assert ora_cent.shape == (len(g["cells"]), data.shape[1])
 
 
+def test_real_dataset_fixture_is_what_the_reference_test_reads():
+    """tests/golden/kidney_igan_g_634x14x14.npz: the reference test's own input (test/test_pilot.py:6-15) run through the
+    reference's wasserstein_distance(data_type='Pathomics').  Shapes as test_pilot.py:26-28 asserts them, and the oracle's OT
+    numbers on a few of the stored rows (the fixture's were produced by the same oracle behind the reference's loop: this
+    guards the fixture against an oracle change, it does not pin POT -- ot_source says which it was)."""
+    g = load_golden(GOLDEN_REAL)
+    N, K = g["proportions"].shape
+    assert (N, K) == (634, 14) and g["emb"].shape == (24227, 14) and len(g["real_labels"]) == N
+    rs = int(g["row_step"])
+    assert g["emd_unreg"].shape == g["emd_reg"].shape == (len(range(0, N, rs)), N)
+    assert sorted(set(g["real_labels"])) == ["30-60", "<30", ">60"]
+    M = g["cost"] / g["cost"].max()                                   # Trajectory.py:101
+    rows = [0, 30, 120]
+    for r in rows:
+        np.testing.assert_allclose(O.emd_grid(g["proportions"], M, row_begin=r, row_end=r + 1)[0], g["emd_unreg"][r // rs], atol=1e-13)
+        np.testing.assert_allclose(O.sinkhorn_grid(g["proportions"], M, 0.1, row_begin=r, row_end=r + 1)[0], g["emd_reg"][r // rs], atol=1e-13)
+
+
 def test_oracle_prior_uses_c_minus_one():
     annot = pd.DataFrame({"cell_type": list("aabbbc"), "sampleID": list("xxyyyz"), "status": list("ppqqqr")})
     rep, _ = O.cluster_representations(annot["cell_type"], annot["sampleID"], regulizer=0.5)
@@ -69,7 +87,7 @@ def test_oracle_prior_uses_c_minus_one():
     np.testing.assert_array_equal(rep["z"], (np.array([0., 0, 1]) + prior) / (1 + sum(prior)))
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + [GOLDEN_REAL])
 def test_return_real_labels(name):
     g = load_golden(name)
     _, annot = _annot(g)
