@@ -166,6 +166,16 @@ __host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? 16 : 8; }
 #ifndef EMD_WPE
 #define EMD_WPE 1
 #endif
+#ifdef EMD_NO_FENCE            // timing experiment only (drops the ordering of the flow slab's stores and loads)
+#define EMD_FENCE() do {} while (0)
+#else
+#define EMD_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#endif
+#ifndef EMD_ZERO_PER_PAIR      // 1: round 3's form, the whole K x K flow slab zeroed per pair (A/B switch)
+#define EMD_ZERO_PER_PAIR 0
+#endif
+// dynamic pair queue: EMD_NQ counters, EMD_Q_STRIDE ints apart (one 128-byte line each)
+constexpr int EMD_NQ = 64, EMD_Q_STRIDE = 32;
 #if EMD_WPE
 #define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK <= 2 ? 8 : 2, 8)))
 #else
@@ -200,7 +210,8 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
     // selects (315 source visits per c3 pair).
     constexpr bool ORD = NK == 1 && !MG;
     unsigned char *ord = reinterpret_cast<unsigned char *>(rowmin + K);      // [column][rank] -> row
-    unsigned char *rnk = ord + (size_t)K * K;                                // [column][row] -> rank
+    unsigned char *rnk = ord + (size_t)K * K;                                // [row][column] -> rank of the row in that column
+                                                                             // (lanes = columns read consecutive bytes: no bank conflict)
     if constexpr (ORD) {
         for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
             const int i = t / K, j = t % K;
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 rank += (c2 < c || (c2 == c && i2 < i)) ? 1 : 0;
             }
             ord[j * K + rank] = (unsigned char)i;
-            rnk[j * K + i] = (unsigned char)rank;
+            rnk[i * K + j] = (unsigned char)rank;
         }
         __syncthreads();
     }
@@ -233,14 +244,34 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
     auto row_offset = [&](long r) { return r * (N - p.row_begin) - (long)p.row_step * r * (r - 1) / 2; };
     // (a wave's first item is its own number -- no burst of atomics on one address at the start of a small grid --, the
     // following ones come from the counter, which starts behind the resident waves)
-    const int n_waves = (int)gridDim.x * EMD_WAVES;
-    for (bool first_item = true;; first_item = false) {
-        int ti = (int)blockIdx.x * EMD_WAVES + wave;
-        if (!first_item) {
-            if (lane == 0) ti = n_waves + __hip_atomic_fetch_add(p.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The flow slab holds zeros outside the support of the pair being solved: zeroed ONCE per wave here, and a finished pair
+    // puts back zeros in the (<= 2K - 1) entries of its final support while it sums its cost.  (Round 3 zeroed the K x K slab
+    // per pair: 20 KB written and later fetched again per c3 pair -- 7.5 GB of HBM traffic per launch for 0.29 GB of inputs
+    // and outputs, profiles/r03/rocprofv3_pmc_summary_emd_c3.txt.)
+    for (int t = lane; t < K * K; t += 64) F[t] = 0.0;
+    EMD_FENCE();
+    __builtin_amdgcn_wave_barrier();
+    // Pairs are drawn from EMD_NQ device-wide counters, each on a cache line of its own: counter c hands out the items
+    // c, c + EMD_NQ, c + 2 EMD_NQ, ..  One counter for all was 11.4 ns of one L2 atomic unit per pair whatever K is -- ALL of the
+    // 2.06 ms of a 600 x 600 grid at K <= 16 (profiles/r04/small_k_probe_before.txt); drawing batches from it instead left
+    // the launch waiting for the waves with the longest batches (K = 50: +5 %, the 634-patient kidney cohort +13 %).  A wave
+    // starts at the counter of its own number and moves on to the next one when a counter runs out, so the items still go
+    // out one by one, in increasing order per counter (the long rows of the upper triangle first).  Every counter has waves
+    // that start on it and drain it, so a wave may give up after a few empty neighbours (all counters run out at about the
+    // same time: a full round of 64 atomics per wave at the end would cost more than the queue itself); a launch with
+    // fewer waves than counters makes the full round.
+    const int q_max_tries = (int)gridDim.x * EMD_WAVES >= EMD_NQ ? 6 : EMD_NQ;
+    int qc = ((int)blockIdx.x * EMD_WAVES + wave) % EMD_NQ, q_tries = 0;
+    for (;;) {
+        int ti = 0;
+        if (lane == 0) ti = __hip_atomic_fetch_add(p.queue + qc * EMD_Q_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long t = (long)qc + (long)EMD_NQ * uni_i32(ti);
+        if (t >= n_items) {
+            if (++q_tries >= q_max_tries) break;
+            qc = qc + 1 == EMD_NQ ? 0 : qc + 1;
+            continue;
         }
-        const long t = uni_i32(ti);
-        if (t >= n_items) break;
+        q_tries = 0;
         int r, j_s;
         if (p.upper_only) {
             const double a = 0.5 * p.row_step, b = (double)(N - p.row_begin) + a;      // offset(r) = b r - a r^2
@@ -272,7 +303,9 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
         sa = uni_f64(wave_sum_f64(sa)); sb = uni_f64(wave_sum_f64(sb));
         const double scale = sa / sb;
         const double tol = 1e-15 * (sa > 0.0 ? sa : 1.0);
+#if EMD_ZERO_PER_PAIR
         for (int t = lane; t < K * K; t += 64) F[t] = 0.0;
+#endif
         // warm start: wherever the diagonal arc (i, i) has zero reduced cost (always, for a metric-like cost with a
         // zero diagonal) ship min(a_i, b_i) along it.  Flow only on zero-reduced-cost arcs keeps complementary
         // slackness, so the augmenting-path phase continues from an optimal partial flow and only has to move the
@@ -290,7 +323,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 if (f > 0.0) { F[(size_t)idx * K + idx] = f; ship[e][e] = 1ull << lane; ra[e] -= f; rb[e] -= f; }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        EMD_FENCE();
         __builtin_amdgcn_wave_barrier();
         int n_aug = 0, n_search = 0;
 #ifdef EMD_STAT     // diagnostic builds: 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows in A rebuilds, 5 searches
@@ -299,7 +332,11 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
         const int aug_guard = 64 * K + 64;   // far above the O(K) augmentations SSP needs; bounds every loop
         bool tripped = false;
         int trip_code = 0;
+#ifdef EMD_NO_CLOCK
+        const unsigned long long t_start = 0;
+#else
         const unsigned long long t_start = wall_clock64();
+#endif
         const unsigned long long watchdog_ticks = 400000000ull;  // 4 s of the 100 MHz constant clock per pair
 
         // One search per round: shortest paths from ANY row that still has supply to the columns that still have demand
@@ -320,7 +357,9 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             }
             if (!any_src) break;
             if (n_aug > aug_guard || n_search > aug_guard) { tripped = true; trip_code = 5; break; }
+#ifndef EMD_NO_CLOCK
             if ((n_search & 15) == 15 && wall_clock64() - t_start > watchdog_ticks) { tripped = true; trip_code = 6; break; }
+#endif
             // initial column labels min over sources i of rc(i, j) = (A_j - pv_j)+ with A_j = min_i (M_ij - pu_i): a source's
             // potential never moves (its distance is 0), so A and its arg-min only change when a source runs dry
             bool src_changed = false;
@@ -331,7 +370,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     const unsigned long long sm = srcmask[0];
                     if (__ballot(lane < K && (Apar[0] < 0 || !((sm >> Apar[0]) & 1ull)))) {     // some column lost its source
                         unsigned int best = 0xffu;
-                        const unsigned char *rl = rnk + (lane < K ? lane : 0) * K;
+                        const unsigned char *rl = rnk + (lane < K ? lane : 0);
                         unsigned long long m = sm;
                         while (m) {                                        // wave-uniform
 #if defined(EMD_STAT) && EMD_STAT == 4
@@ -339,7 +378,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #endif
                             const int i = __builtin_ctzll(m);
                             m &= m - 1ull;
-                            const unsigned int r = rl[i];
+                            const unsigned int r = rl[i * K];
                             best = r < best ? r : best;
                         }
                         if (lane < K) {
@@ -549,7 +588,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                                 }
                             }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        EMD_FENCE();
                         __builtin_amdgcn_wave_barrier();
                         bool dry = false;
 #pragma unroll
@@ -640,10 +679,16 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     const int j = __builtin_ctzll(m) + 64 * w;
                     m &= m - 1ull;
                     cost += F[(size_t)idx * K + j] * Mrd[(size_t)idx * K + j];
+#if !EMD_ZERO_PER_PAIR
+                    F[(size_t)idx * K + j] = 0.0;           // the slab goes back to all zeros for the wave's next pair
+#endif
                 }
             }
         }
         cost = uni_f64(wave_sum_f64(cost));
+        if (tripped) {          // (never seen; a guard that tripped mid-augmentation may leave entries outside the masks)
+            for (int t = lane; t < K * K; t += 64) F[t] = 0.0;
+        }
         if (lane == 0) {
             p.emd[q] = tripped ? __builtin_nan("") : cost;
 #ifdef EMD_STAT
@@ -652,6 +697,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;
 #endif
         }
+        EMD_FENCE();      // (the zeros written back above: other lanes write these entries next)
         __builtin_amdgcn_wave_barrier();
     }
 }

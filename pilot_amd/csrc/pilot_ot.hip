@@ -445,7 +445,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int) * pilot::EMD_NQ * pilot::EMD_Q_STRIDE);
     // per-pair work lists of the full grid, so that no grid call allocates (the POT-literal kernel's scratch, 2 K^2 doubles per
     // resident workgroup, is the exception: allocated by the first call that needs that kernel)
     // (two lists of N^2: pairs that ended in NaN, and pairs the f32 passes hand to the f64 pass)
@@ -1116,7 +1116,7 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
     p.upper_only = mode != PILOT_OT_EMD_ALL;
     p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab; p.queue = pl->emd_counter;
-    HIP_TRY(hipMemsetAsync(pl->emd_counter, 0, sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(pl->emd_counter, 0, sizeof(int) * pilot::EMD_NQ * pilot::EMD_Q_STRIDE, s));
     const long total = (long)n_rows * N;
     if (K > EMD_MAX_K) {
         // beyond the one-wave-per-pair kernel: one workgroup per pair, vectors in LDS, flows in a global slab per resident
