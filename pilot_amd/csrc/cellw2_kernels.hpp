@@ -30,6 +30,14 @@
 namespace pilot {
 
 constexpr float CELL_NEG_BIG = -1.0e30f;
+// The pipelined fp16 column sweep requests tile tb + 1 (16 cells) unclamped while it works on tile tb, so after a partial last
+// tile it reads up to 2 * 16 - 1 = 31 cells past a patient's last one: the operand buffer ends in a zeroed pad of
+// CELL_PREFETCH_CELLS cells of 32 bytes per plane (a weight of 2^(finite - big) = 0 makes whatever is read there harmless,
+// but the read itself must stay inside the allocation).  Host allocation and kernel share this constant.
+constexpr int CELL_TILE_CELLS = 16, CELL_PREFETCH_TILES = 1;
+constexpr int CELL_PREFETCH_CELLS = (CELL_PREFETCH_TILES + 1) * CELL_TILE_CELLS;
+constexpr size_t CELL_PAD_BYTES = (size_t)CELL_PREFETCH_CELLS * 32;
+static_assert(CELL_PAD_BYTES >= (size_t)((CELL_PREFETCH_TILES + 1) * CELL_TILE_CELLS - 1) * 32, "operand pad shorter than the sweep's read-ahead");
 constexpr int CELL_WG = 1024;   // 16 waves share one pair: the self-pairs converge slowly and set the critical path
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 

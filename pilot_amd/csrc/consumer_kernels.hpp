@@ -103,13 +103,21 @@ row_distance_kernel(const double *__restrict__ X, int N, int metric, const doubl
 // One workgroup per sample.  The row and the labels are staged in LDS; thread c then adds up cluster c's distances IN INDEX
 // ORDER -- the order of sklearn's np.bincount(labels, weights=row) -- so the sums are reproducible bit for bit (LDS float
 // atomics would make them depend on the arrival order).  LDS: N doubles + N ints + C doubles.  s_out[i] = s_i.
+// staged == 0 (a row that does not fit LDS, N beyond ~12 700): the row and the labels are read from global memory in the
+// same order instead -- the same sums bit for bit, only C doubles of LDS, no limit on N.
 static __global__ void silhouette_kernel(const double *__restrict__ D, const int *__restrict__ labels, const int *__restrict__ sizes,
-                                         int N, int C, double *__restrict__ s_out) {
+                                         int N, int C, int staged, double *__restrict__ s_out) {
     extern __shared__ double sil_smem[];
-    double *row = sil_smem, *csum = row + N;
-    int *lab = reinterpret_cast<int *>(csum + C);
+    double *csum = sil_smem;
     const int i = blockIdx.x;
-    for (int j = threadIdx.x; j < N; j += blockDim.x) { row[j] = D[(size_t)i * N + j]; lab[j] = labels[j]; }
+    const double *row = D + (size_t)i * N;
+    const int *lab = labels;
+    if (staged) {
+        double *srow = csum + C;
+        int *slab = reinterpret_cast<int *>(srow + N);
+        for (int j = threadIdx.x; j < N; j += blockDim.x) { srow[j] = row[j]; slab[j] = labels[j]; }
+        row = srow; lab = slab;
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double s = 0.0;

@@ -1447,9 +1447,10 @@ PILOT_API int pilot_ot_cell_cohort_create(const float *X, const long long *offse
     c->n_cu = current_cu_count();
     hipError_t e = hipGetDevice(&c->device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dX), sizeof(float) * (size_t)c->C * D);
-    // (+ a zeroed pad: the column sweep of the fp16-piece kernel reads up to 15 cells past a patient's last one)
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dXb), (size_t)c->C * c->KB * 3 * 64 + 1024);
-    if (e == hipSuccess) e = hipMemset(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + 1024);
+    // (+ a zeroed pad: the pipelined column sweep of the fp16-piece kernel reads up to 31 cells past a patient's last one,
+    // pilot::CELL_PAD_BYTES in cellw2_kernels.hpp)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dXb), (size_t)c->C * c->KB * 3 * 64 + pilot::CELL_PAD_BYTES);
+    if (e == hipSuccess) e = hipMemset(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + pilot::CELL_PAD_BYTES);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dnrm), sizeof(float) * (size_t)c->C);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->doffs), sizeof(long long) * (size_t)(N + 1));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->dQ), sizeof(int));
@@ -1522,7 +1523,7 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
         half = c->max_abs * op_scale < 3.0e4f && !(force && *force && *force != '0') ? 1 : 0;
         const int one_slot = half && c->D <= 32 * c->KB - 2 && !getenv("PILOT_OT_CELL_NO_AUG") ? 1 : 0;
         if (c->xb_scale != op_scale || c->xb_half != half || c->xb_one_slot != one_slot) {
-            if (c->xb_half != half) HIP_TRY(hipMemsetAsync(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + 1024, c->stream));   // (the piece count changes the planes)
+            if (c->xb_half != half) HIP_TRY(hipMemsetAsync(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + pilot::CELL_PAD_BYTES, c->stream));   // (the piece count changes the planes)
             hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, c->dX,
                                (long)c->C, c->D, c->KB, op_scale, half, one_slot, reinterpret_cast<unsigned short *>(c->dXb), c->dnrm);
             HIP_TRY(hipGetLastError());

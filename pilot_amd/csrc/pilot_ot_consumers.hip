@@ -2,6 +2,7 @@
 // reference call sites they replace: consumer_kernels.hpp).  Device-resident forms (`_dev`: device pointers + a stream, no
 // allocation, no synchronisation), fused host chains (the matrix goes up once, only the result comes back) and the plain
 // host-buffer forms on top of them.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -49,11 +50,15 @@ PILOT_API int pilot_ot_silhouette_dev(const double *d_D, const int *d_labels, in
     if (!d_D || !d_labels || !d_sizes_scratch || !d_samples) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (N <= 0 || n_clusters <= 0 || n_clusters > 4096) return fail(PILOT_OT_EINVAL, "N=%d n_clusters=%d out of range", N, n_clusters);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // the row and the labels are staged in LDS while they fit; beyond (N > ~12 700) the kernel reads them from global memory
+    // in the same order (round 3 returned ENOTSUP there: ADVICE r03)
+    size_t lds = sizeof(double) * ((size_t)N + n_clusters) + sizeof(int) * (size_t)N;
+    const char *force = getenv("PILOT_OT_SIL_UNSTAGED");       // (tests: the large-N form on a small matrix)
+    const int staged = (lds <= 150 * 1024 && !(force && *force && *force != '0')) ? 1 : 0;
+    if (!staged) lds = sizeof(double) * (size_t)n_clusters;
     hipLaunchKernelGGL(pilot::label_sizes_kernel, dim3(1), dim3(256), 0, s, d_labels, N, n_clusters, d_sizes_scratch);
-    const size_t lds = sizeof(double) * ((size_t)N + n_clusters) + sizeof(int) * (size_t)N;
-    if (lds > 150 * 1024) return fail(PILOT_OT_ENOTSUP, "N=%d samples do not fit the LDS row of the silhouette kernel", N);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::silhouette_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pilot::silhouette_kernel, dim3(N), dim3(256), lds, s, d_D, d_labels, d_sizes_scratch, N, n_clusters, d_samples);
+    hipLaunchKernelGGL(pilot::silhouette_kernel, dim3(N), dim3(256), lds, s, d_D, d_labels, d_sizes_scratch, N, n_clusters, staged, d_samples);
     HIP_TRY(hipGetLastError());
     return PILOT_OT_OK;
 }

@@ -53,11 +53,13 @@ struct RcclApi {
 RcclApi g_rccl;
 
 std::mutex g_rccl_mutex;
+void rccl_log_to_stderr();
 
 int rccl_load() {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);      // first use may come from several host threads at once
     if (g_rccl.h) return PILOT_OT_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    rccl_log_to_stderr();                                   // (before the library reads its environment)
     void *h = nullptr;
     for (const char *n : names)
         if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
@@ -109,28 +111,16 @@ int launch_interleave(const double *stage, int G, int n_pad, int N, double *full
     return PILOT_OT_OK;
 }
 
-// RCCL prints a version banner to stdout when a communicator is created; a host program whose stdout is a data channel
-// (bench.py prints one JSON line) must not receive it: while the guard lives, fd 1 points at stderr.  fd 1 is process-wide:
-// communicator creation is serialised by g_banner_mutex, and another thread that writes to stdout during those
-// milliseconds lands on stderr -- PILOT_OT_KEEP_RCCL_STDOUT=1 leaves fd 1 alone (the banner then goes to stdout).
-std::mutex g_banner_mutex;
-struct StdoutToStderr {
-    int saved = -1;
-    std::unique_lock<std::mutex> lock;
-    StdoutToStderr() : lock(g_banner_mutex) {
-        const char *keep = getenv("PILOT_OT_KEEP_RCCL_STDOUT");
-        if (keep && *keep && *keep != '0') return;
-        fflush(stdout);
-        saved = dup(1);
-        if (saved >= 0) dup2(2, 1);
-    }
-    ~StdoutToStderr() {
-        if (saved < 0) return;
-        fflush(stdout);
-        dup2(saved, 1);
-        close(saved);
-    }
-};
+// RCCL writes its version banner (and every NCCL_DEBUG line) to stdout unless NCCL_DEBUG_FILE names another sink; a host
+// program whose stdout is a data channel (bench.py prints one JSON line) must not receive it.  Before librccl is loaded
+// its log is pointed at stderr through RCCL's OWN switch -- round 3 swapped fd 1 for fd 2 around communicator creation,
+// which also moved whatever another thread wrote to stdout in those milliseconds.  A caller that sets NCCL_DEBUG_FILE
+// itself, or PILOT_OT_KEEP_RCCL_STDOUT=1, keeps RCCL's default.
+void rccl_log_to_stderr() {
+    const char *keep = getenv("PILOT_OT_KEEP_RCCL_STDOUT");
+    if (keep && *keep && *keep != '0') return;
+    (void)setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);      // (0: an existing setting wins)
+}
 
 struct DeviceGuard {   // restores the calling thread's current device
     int saved = -1;
@@ -172,7 +162,6 @@ PILOT_API int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pi
     memcpy(&id, uid, sizeof(id));
     ncclResult_t r;
     {
-        StdoutToStderr quiet;
         r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
     }
     if (r != ncclSuccess) { delete c; return fail(PILOT_OT_ERCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
@@ -370,7 +359,6 @@ PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shar
             std::vector<ncclComm_t> comms(n_shards, nullptr);
             ncclResult_t r;
             {
-                StdoutToStderr quiet;
                 r = g_rccl.CommInitAll(comms.data(), n_shards, devices);
             }
             if (r != ncclSuccess) rc = fail(PILOT_OT_ERCCL, "ncclCommInitAll over %d devices: %s", n_shards, g_rccl.GetErrorString(r));
@@ -765,7 +753,6 @@ PILOT_API int pilot_ot_cell_w2_grid_multi(const float *X, const long long *offse
             std::vector<ncclComm_t> comms(G, nullptr);
             ncclResult_t r;
             {
-                StdoutToStderr quiet;
                 r = g_rccl.CommInitAll(comms.data(), G, devices);
             }
             if (r != ncclSuccess) return fail(PILOT_OT_ERCCL, "ncclCommInitAll over %d devices: %s", G, g_rccl.GetErrorString(r));

@@ -113,6 +113,12 @@ def _first_appearance_codes(series):
     if arr.dtype == object and arr.ndim == 1 and arr.strides == (arr.itemsize,) and arr.size:
         ptrs = np.ctypeslib.as_array((ctypes.c_size_t * arr.size).from_address(arr.ctypes.data))      # (arr stays alive here)
         pcodes, puniq = pd.factorize(ptrs, sort=False)
+        #  the shortcut only pays while the labels are few shared objects: a column built row by row holds one
+        # str object per cell (as many pointers as cells: the Python-level loop below would take seconds at 1.8 M cells), and a
+        # NULL slot cannot be turned back into an object -- both go the plain way
+        if len(puniq) > max(4096, arr.size // 8) or (puniq == 0).any():
+            codes, uniques = pd.factorize(series, sort=False, use_na_sentinel=True)
+            return codes, np.asarray(uniques)
         objs = np.empty(len(puniq), dtype=object)
         objs[:] = [ctypes.cast(int(a), ctypes.py_object).value for a in puniq]
         vcodes, uniques = pd.factorize(objs, sort=False, use_na_sentinel=True)
@@ -284,40 +290,11 @@ def _device_worker():
         return _worker
 
 
-def _leiden_backend():
-    """scanpy (neighbors + leiden), needed only for the ARI of ``return_sil_ari=True``; downstream of the accelerated path
-    (SURVEY.md section 2 #6) and not a dependency of this package."""
-    try:
-        import scanpy
-    except ImportError as e:
-        raise NotImplementedError("return_sil_ari=True: the ARI needs scanpy/leidenalg for the Leiden clustering of the finished "
-                                  "matrix (Trajectory.py:525-588); the silhouette alone is tl.Sil_computing(EMD / EMD.max(), "
-                                  "adata.uns['real_labels'])") from e
-    return scanpy
-
-
-def Clustering(EMD, df, category="status", sample_col=1, res=0.01, metric="cosine", steper=0.01):
-    """Leiden clustering of the samples on the distance matrix until the number of clusters equals the number of status
-    values, and its Rand index against the true labels (Trajectory.py:525-588).  A consumer of the finished matrix: runs
-    scanpy on the host exactly like the reference; returns ``(labels, rand_index, true_labels)``."""
-    sc = _leiden_backend()
-    from sklearn.metrics import rand_score
-    n_status = len(df[category].unique())
-    while True:
-        ad = sc.AnnData(EMD)
-        sc.pp.neighbors(ad, metric=metric)
-        sc.tl.leiden(ad, resolution=res)
-        labels = np.array(ad.obs.leiden)
-        n_found = len(np.unique(labels))
-        if n_status > n_found:
-            res = res + steper
-        elif n_status < n_found:
-            res = res - 0.001
-        else:
-            labels = labels.astype(int)
-            break
-    true_labels = return_real_labels(df, category=category, sample_col=sample_col)
-    return labels, rand_score(true_labels, labels), true_labels
+_SIL_ARI_MESSAGE = ("return_sil_ari=True: the ARI is the Rand index of a Leiden clustering of the finished matrix "
+                    "(pilotpy.tl.Clustering, Trajectory.py:525-588: scanpy neighbors + leiden) -- a consumer of adata.uns['EMD'] "
+                    "outside this engine's scope (SURVEY.md section 2 #6).  Run wasserstein_distance without it, then the "
+                    "reference's own Clustering on adata.uns['EMD'] / adata.uns['EMD'].max(); the silhouette alone is "
+                    "tl.Sil_computing(EMD / EMD.max(), adata.uns['real_labels']) (INTEGRATION.md, 'Sil / ARI')")
 
 
 def Sil_computing(EMD, real_labels, metric="cosine"):
@@ -346,8 +323,8 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     ``{"precision": "fp64"}``; ``{"n_devices": G}`` (or ``{"devices": [0, 1, ...]}``) row-shards the pair grid over G GPUs
     of this node with one RCCL all-gather -- same bits as the single-GPU matrix.
     """
-    if return_sil_ari:
-        _leiden_backend()      # ARI needs scanpy's Leiden clustering (Trajectory.py:108-113): refuse BEFORE any device work
+    if return_sil_ari:      # (Trajectory.py:108-113) refused BEFORE any device work, whatever is installed
+        raise NotImplementedError(_SIL_ARI_MESSAGE)
     if metric not in engine._lib.METRICS:
         raise NotImplementedError("metric %r: the device kernel implements scipy's pdist names %s" % (metric, sorted(engine._lib.METRICS)))
     global path_to_results
@@ -415,10 +392,6 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     status_col = annot["status"]
     real_labels = [status_col.iloc[int(r)] for r in first_rows]
     adata.uns["real_labels"] = real_labels
-    if return_sil_ari:
-        labels, ARI, _ = Clustering(EMD / EMD.max(), annot, metric=metric, res=res, steper=steper)
-        adata.uns["Sil"] = Sil_computing(EMD / EMD.max(), real_labels, metric=metric)
-        adata.uns["ARI"] = ARI
 
 
 def Precomputed_distance(adata, distances, cost_df, features_matrix, emb_matrix="X_PCA",
