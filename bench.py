@@ -772,17 +772,23 @@ def bench_emd(args, L, P, M, cfg):
         ncpu = host_cores()
         step = max(1, N // 4)
         t = time.perf_counter()
-        Eo = O.emd_grid(P, M, row_step=step, n_threads=1, fast=True)
+        Eo = O.emd_grid(P, M, row_step=step, n_threads=1, fast="ns")
         dt1 = time.perf_counter() - t
         out["cpu_baseline"] = {"value": round(Eo.size / dt1, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
-                               "sample": "rows 0,%d,.. x all columns (%d pairs), the HIP kernel's successive-shortest-path algorithm on one CPU "
-                                         "thread (oracle/pilot_oracle.c::pilot_oracle_emd2_fast; POT's LEMON network simplex is not "
-                                         "available on this box and would be faster still); "
+                               "sample": "rows 0,%d,.. x all columns (%d pairs), one thread: a NETWORK SIMPLEX on the bipartite transportation "
+                                         "graph (oracle/pilot_oracle.c::pilot_oracle_emd2_ns: spanning-tree basis, block-search pricing), the "
+                                         "algorithm family of POT's own solver (LEMON network simplex; not available on this box); "
                                          "max|gpu-oracle| = %.2e" % (step, Eo.size, float(np.abs(E[::step] - Eo).max()))}
         t = time.perf_counter()
-        Eo2 = O.emd_grid(P, M, row_step=max(1, step // 8), n_threads=ncpu, fast=True)
+        Es = O.emd_grid(P, M, row_step=step, n_threads=1, fast=True)
+        dts = time.perf_counter() - t
+        out["cpu_baseline_ssp"] = {"value": round(Es.size / dts, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": "the same pairs by the HIP kernel's own algorithm (successive shortest paths, diagonal warm start) on "
+                                             "one CPU thread; max|gpu-oracle| = %.2e" % float(np.abs(E[::step] - Es).max())}
+        t = time.perf_counter()
+        Eo2 = O.emd_grid(P, M, row_step=max(1, step // 8), n_threads=ncpu, fast="ns")
         out["cpu_baseline_all_cores"] = {"value": round(Eo2.size / (time.perf_counter() - t), 1), "unit": "pairs/s",
-                                         "cores": ncpu, "kind": "port", "sample": "%d pairs, OpenMP over pairs" % Eo2.size}
+                                         "cores": ncpu, "kind": "port", "sample": "%d pairs, network simplex, OpenMP over pairs" % Eo2.size}
     return out
 
 

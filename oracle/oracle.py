@@ -87,6 +87,10 @@ def lib() -> ctypes.CDLL:
                                            ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ip, dp]
         L.pilot_oracle_emd_grid_fast.restype = ctypes.c_int
         L.pilot_oracle_emd_grid_fast.argtypes = L.pilot_oracle_emd_grid.argtypes
+        L.pilot_oracle_emd_grid_ns.restype = ctypes.c_int
+        L.pilot_oracle_emd_grid_ns.argtypes = L.pilot_oracle_emd_grid.argtypes
+        L.pilot_oracle_emd2_ns.restype = ctypes.c_double
+        L.pilot_oracle_emd2_ns.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ip]
         _lib = L
     return _lib
 
@@ -157,14 +161,23 @@ def emd2(a, b, M, return_plan=False):
     return (val, G) if return_plan else val
 
 
+def emd2_ns(a, b, M, return_pivots=False):
+    """ot.emd2(a, b, M) by the network simplex leg (pilot_oracle.c::pilot_oracle_emd2_ns) -- same LP value."""
+    a, b, M = _f64(a), _f64(b), _f64(M)
+    piv = ctypes.c_int(0)
+    val = lib().pilot_oracle_emd2_ns(_dptr(a), _dptr(b), _dptr(M), a.size, b.size, None, ctypes.byref(piv))
+    return (val, piv.value) if return_pivots else val
+
+
 def emd_grid(P, M, row_begin=0, row_end=None, row_step=1, n_threads=1, fast=False):
     """All ordered pairs, exact OT -- Trajectory.py:507-511.  ``fast``: the quicker successive-shortest-path solver
-    (the HIP kernel's algorithm on one CPU thread; the CPU baseline of ``bench.py --mode emd``), same LP value."""
+    (the HIP kernel's algorithm on one CPU thread), ``fast="ns"``: the network simplex leg (the algorithm family of POT's
+    own solver; the CPU baseline of ``bench.py --mode emd``) -- same LP value."""
     P, M = _f64(P), _f64(M)
     N, K = P.shape
     row_end, nrows = _rows(N, row_begin, row_end, row_step)
     emd = np.zeros((nrows, N))
-    fn = lib().pilot_oracle_emd_grid_fast if fast else lib().pilot_oracle_emd_grid
+    fn = lib().pilot_oracle_emd_grid_ns if fast == "ns" else (lib().pilot_oracle_emd_grid_fast if fast else lib().pilot_oracle_emd_grid)
     rc = fn(_dptr(P), N, K, _dptr(M), row_begin, row_end, row_step,
                                      int(n_threads), _dptr(emd))
     if rc != 0:

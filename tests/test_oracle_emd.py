@@ -93,3 +93,29 @@ def test_fast_solver_of_the_cpu_baseline_returns_the_same_lp_value():
             assert abs(res.fun - fast[0, 3]) <= 1e-10
     Pc, Mc = make_problem(**CONFIGS["c2"])
     assert np.abs(O.emd_grid(Pc, Mc, row_end=3) - O.emd_grid(Pc, Mc, row_end=3, fast=True)).max() <= 1e-13
+
+
+def test_network_simplex_leg_returns_the_same_lp_value():
+    """oracle.emd_grid(fast="ns") / oracle.emd2_ns -- a network simplex (spanning-tree basis, block-search pricing), the CPU
+    baseline of `bench.py --mode emd` -- against the successive-shortest-path oracle and HiGHS: rectangular problems, empty
+    bins (degenerate pivots), quantised costs (ties), PILOT-shaped pairs."""
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        na, nb = rng.integers(1, 13, 2)
+        a, b, M = rng.random(na), rng.random(nb), rng.random((na, nb))
+        if rng.random() < 0.4:
+            M = np.round(M * 4) / 4
+        if rng.random() < 0.4 and na > 1:
+            a[rng.integers(0, na)] = 0.0
+        if rng.random() < 0.4 and nb > 1:
+            b[rng.integers(0, nb)] = 0.0
+        v, pivots = O.emd2_ns(a, b, M, return_pivots=True)
+        assert abs(v - O.emd2(a, b, M)) <= 1e-12 and pivots < 200 * (na + nb + 1)
+    for na, nb in [(3, 7), (8, 8), (12, 5)]:
+        a = rng.dirichlet(np.ones(na)); b = rng.dirichlet(np.ones(nb)); M = rng.random((na, nb))
+        assert abs(O.emd2_ns(a, b, M) - lp_emd(a, b, M)) < 1e-10
+    for cfg in ("c1", "c2"):
+        P, M = make_problem(**CONFIGS[cfg])
+        assert np.abs(O.emd_grid(P, M, row_end=4, fast="ns") - O.emd_grid(P, M, row_end=4)).max() <= 1e-13
+    P, M = make_problem(**CONFIGS["c3"])
+    assert np.abs(O.emd_grid(P, M, row_end=1, fast="ns", n_threads=4) - O.emd_grid(P, M, row_end=1, fast=True)).max() <= 1e-13
