@@ -154,7 +154,8 @@ def main():
     per_rank = None
     if single_process_multi:
         devices = [0] * args.gpus if args.logical_shards else list(range(args.gpus))
-        mp = multi.MultiPlan(P, M, devices=devices)
+        with multi.stdout_to_stderr():       # (RCCL's version banner is a printf: this program's stdout carries one JSON line)
+            mp = multi.MultiPlan(P, M, devices=devices)
 
         def step():
             mp.sinkhorn(args.reg, precision=prec)
@@ -168,7 +169,8 @@ def main():
         n_pad = sharding.n_padded_rows(N, world)
         plan = engine.DevicePlan(P, M, n_rows_max=max(n_pad, 1))       # P, M -> HBM (resident from here on)
         plan.enable_timing(True)
-        comm = multi.Comm(rank, world) if (world > 1 or args.force_comm) else None
+        with multi.stdout_to_stderr():       # (RCCL's version banner is a printf: this program's stdout carries one JSON line)
+            comm = multi.Comm(rank, world) if (world > 1 or args.force_comm) else None
         if comm:
             d_stage, d_full = DevBuf(L, 8 * world * n_pad * N), DevBuf(L, 8 * N * N)
             zeros = np.zeros(n_pad * N)                                  # (kept alive across the copy)
@@ -580,7 +582,8 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
     N = P.shape[0]
     if single_process_multi:
         devices = [0] * args.gpus if args.logical_shards else list(range(args.gpus))
-        mp = multi.MultiPlan(P, M, devices=devices)
+        with multi.stdout_to_stderr():
+            mp = multi.MultiPlan(P, M, devices=devices)
         mp.sinkhorn(0.1, precision="auto"); mp.sync()
         t = time.perf_counter()
         for _ in range(steps):

@@ -111,11 +111,13 @@ int launch_interleave(const double *stage, int G, int n_pad, int N, double *full
     return PILOT_OT_OK;
 }
 
-// RCCL writes its version banner (and every NCCL_DEBUG line) to stdout unless NCCL_DEBUG_FILE names another sink; a host
-// program whose stdout is a data channel (bench.py prints one JSON line) must not receive it.  Before librccl is loaded
-// its log is pointed at stderr through RCCL's OWN switch -- round 3 swapped fd 1 for fd 2 around communicator creation,
-// which also moved whatever another thread wrote to stdout in those milliseconds.  A caller that sets NCCL_DEBUG_FILE
-// itself, or PILOT_OT_KEEP_RCCL_STDOUT=1, keeps RCCL's default.
+// RCCL writes its NCCL_DEBUG lines to stdout unless NCCL_DEBUG_FILE names another sink: before librccl is loaded its log is
+// pointed at stderr through RCCL's OWN switch (a caller that sets NCCL_DEBUG_FILE itself, or PILOT_OT_KEEP_RCCL_STDOUT=1,
+// keeps RCCL's default).  The five-line version banner of RCCL 2.27 is a plain printf that no switch reaches; the library
+// no longer swaps fd 1 around communicator creation as round 3 did (process-wide, and it moved whatever another thread wrote
+// to stdout in those milliseconds): it only flushes stdio right after the communicator exists, so the banner appears THEN and
+// not at exit behind the caller's own output.  A host program whose stdout is a data channel redirects it itself around the
+// call (pilot_amd/multi.py::stdout_to_stderr, what bench.py does).
 void rccl_log_to_stderr() {
     const char *keep = getenv("PILOT_OT_KEEP_RCCL_STDOUT");
     if (keep && *keep && *keep != '0') return;
@@ -163,6 +165,7 @@ PILOT_API int pilot_ot_comm_init_rank(const char *uid, int n_ranks, int rank, pi
     ncclResult_t r;
     {
         r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+        fflush(stdout);
     }
     if (r != ncclSuccess) { delete c; return fail(PILOT_OT_ERCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
     *comm = c;
@@ -360,6 +363,7 @@ PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shar
             ncclResult_t r;
             {
                 r = g_rccl.CommInitAll(comms.data(), n_shards, devices);
+                fflush(stdout);
             }
             if (r != ncclSuccess) rc = fail(PILOT_OT_ERCCL, "ncclCommInitAll over %d devices: %s", n_shards, g_rccl.GetErrorString(r));
             else for (int s = 0; s < n_shards; ++s) m->sh[s].comm = comms[s];

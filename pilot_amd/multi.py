@@ -13,8 +13,10 @@ bits of the single-device matrix:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import sys
 import tempfile
 import time
 
@@ -34,6 +36,25 @@ def _devices(devices=None, n_devices=None):
     if not devices:
         raise ValueError("empty device list")
     return np.ascontiguousarray(devices, dtype=np.int32)
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """While the block runs, file descriptor 1 points at stderr: RCCL prints a version banner with a plain printf when a
+    communicator is created, and a program whose stdout is a data channel (bench.py: one JSON line) wraps communicator
+    creation in this.  The APPLICATION's choice -- the library itself never touches file descriptors."""
+    sys.stdout.flush()
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class MultiPlan:

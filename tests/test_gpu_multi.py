@@ -114,6 +114,7 @@ def test_bench_multi_paths_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--logical-shards", "--steps", "3",
                         "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:500]          # ONE JSON line: RCCL's banner went to stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 1e7 and len(line["multi_gpu"]["grid_ms_per_shard"]) == 2
     # one-process-per-GPU path with a world of one: RCCL communicator through the temp-file rendezvous, all-gather, max
@@ -121,6 +122,7 @@ def test_bench_multi_paths_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-comm", "--steps", "3",
                         "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:500]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e7 and "rank0_kernel_ms" in line["multi_gpu"]
 
