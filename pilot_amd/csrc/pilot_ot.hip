@@ -192,6 +192,7 @@ __global__ void cost_matrix_kernel(const double *__restrict__ X, int K, int D, i
 constexpr int MAX_K = 128;          // the MFMA pair-grid kernels (8 row-tiles of 16 cell types)
 constexpr int GENERIC_MAX_K = 2048;  // the reference-semantics fallback kernel (vectors in LDS)
 constexpr int EMD_MAX_K = 256;       // exact-OT kernel: 4 rows / columns per lane
+constexpr int WIDE_MAX_K = 256;      // sinkhorn_wide_kernel: 128 < K <= 256, eight waves per 16-pair tile
 constexpr int CTRL_INTS = pilot::CTRL_INTS;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
@@ -232,6 +233,8 @@ struct pilot_ot_plan {
     int emdg_wgs;
     double *kws;       // generic Sinkhorn kernel: K' and its transpose per workgroup (allocated on first use)
     int generic_wgs;
+    float *wide_rec;   // 128 < K <= 256: one record per pair of the grid for sinkhorn_wide_kernel (allocated on first use)
+    size_t wide_rec_n; //   pairs it holds
     int *nan_list;     // pairs that ended in NaN (grown on demand)
     size_t nan_list_n;
     int n_cu;
@@ -418,6 +421,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     pl->N = N; pl->K = K; pl->max_cost = 1.0;
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
     pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->emdg_slab = nullptr; pl->emdg_wgs = 0; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
+    pl->wide_rec = nullptr; pl->wide_rec_n = 0;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->flags_ws = nullptr; pl->flags_ws_n = 0;
     pl->timing = 0; pl->n_timed = 0;
@@ -439,6 +443,8 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
         if (bs > img_bytes) img_bytes = bs;
         if (bh > img_bytes) img_bytes = bh;
         if (e == hipSuccess) e = hipMalloc(&pl->img, img_bytes);
+    } else if (K <= WIDE_MAX_K) {       // the 8-waves-per-tile kernel: the fp16-split operand block at 16 row-tiles
+        if (e == hipSuccess) e = hipMalloc(&pl->img, pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float));
     }
     if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * ((size_t)N * kp + N));   // + one stop threshold per patient
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
@@ -485,6 +491,7 @@ PILOT_API int pilot_ot_plan_destroy(pilot_ot_plan *pl) {
     if (pl->emdg_slab) (void)hipFree(pl->emdg_slab);
     if (pl->kws) (void)hipFree(pl->kws);
     if (pl->nan_list) (void)hipFree(pl->nan_list);
+    if (pl->wide_rec) (void)hipFree(pl->wide_rec);
     if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
     if (pl->gstream) (void)hipStreamDestroy(pl->gstream);
     for (int i = 0; i < TIMING_RING; ++i) for (int j = 0; j < 4; ++j) if (pl->ev[i][j]) (void)hipEventDestroy(pl->ev[i][j]);
@@ -812,6 +819,71 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     return PILOT_OT_OK;
 }
 
+// 128 < K <= 256 with a symmetric cost inside the fp16-split range: sinkhorn_wide_kernel (wide_kernels.hpp) on the operand
+// block the ordinary prep kernel writes for 16 row-tiles, then the value kernel; hand-overs (tau-absorbing / NaN pairs, or
+// every pair when the histograms carry unequal mass) are solved by the POT-literal kernel like those of the stream kernels.
+int run_wide(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg, int num_iter_max, double stop_thr, double tau,
+             int check_period, double floor_ulps, int row_begin, int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err,
+             int *d_flags, hipStream_t s) {
+    const int N = pl->N, K = pl->K, RT = 16;
+    pl->order_hist = pl->track_count + CTRL_INTS;
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int), s));
+    if (n_rows == 0) return PILOT_OT_OK;
+    const int n_pairs = n_rows * N;
+    if (!d_flags) {
+        if ((size_t)n_pairs > pl->flags_ws_n) {
+            if (pl->flags_ws) HIP_TRY(hipFree(pl->flags_ws));
+            pl->flags_ws = nullptr; pl->flags_ws_n = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->flags_ws), sizeof(int) * (size_t)n_pairs));
+            pl->flags_ws_n = (size_t)n_pairs;
+        }
+        d_flags = pl->flags_ws;
+    }
+    if ((size_t)n_pairs > pl->nan_list_n) {
+        if (pl->nan_list) HIP_TRY(hipFree(pl->nan_list));
+        pl->nan_list = nullptr; pl->nan_list_n = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->nan_list), 2 * sizeof(int) * (size_t)n_pairs));
+        pl->nan_list_n = (size_t)n_pairs;
+    }
+    if ((size_t)n_pairs > pl->wide_rec_n) {     // (first call of this size: the one allocation of the path)
+        if (pl->wide_rec) HIP_TRY(hipFree(pl->wide_rec));
+        pl->wide_rec = nullptr; pl->wide_rec_n = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->wide_rec), sizeof(float) * pilot::wide_rec_elems() * (size_t)n_pairs));
+        pl->wide_rec_n = (size_t)n_pairs;
+    }
+    int ob = (n_pairs + 1023) / 1024;
+    if (ob > pl->n_cu) ob = pl->n_cu;
+    HIP_TRY(pilot::launch_prep(pilot::CFG_H32, d_M, K, RT, reg, pl->img, d_P, pl->p_slot, N, 0, stop_thr, floor_ulps, n_rows, row_begin, row_step,
+                               pl->order_bucket, pl->order_hist, pl->order_list, pl->track_count + 4, pl->track_count + 1, 0, ob, s));
+    pilot::GridParams p;
+    p.P = pl->p_slot; p.img = pl->img; p.N = N; p.K = K;
+    p.n_pairs = n_pairs;
+    p.list = pl->order_list; p.list_len = nullptr;
+    p.solo_len = nullptr; p.solo_head = nullptr; p.solo_blocks = 0;
+    p.row_begin = row_begin; p.row_step = row_step;
+    p.max_iter = num_iter_max; p.period = check_period;
+    p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
+    p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
+    p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
+    p.ring = 0; p.bands = 1;
+    p.fb_list = nullptr; p.fb_count = nullptr;
+    p.nan_list = pl->nan_list; p.nan_count = pl->track_count + 10;
+    p.unequal = pl->track_count + pilot::CTRL_UNEQUAL;
+    p.debug = 0;
+    hipEvent_t *ev = pl->timing ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
+    const int tiles = (n_pairs + 15) / 16;
+    int wgs = pl->n_cu < tiles ? pl->n_cu : tiles;            // one 512-thread workgroup per CU (230 VGPRs: two waves per SIMD)
+    HIP_TRY(pilot::launch_wide(dim3(wgs), s, p, pl->wide_rec));
+    if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
+    int vwgs = (tiles + pilot::WAVES_PER_WG - 1) / pilot::WAVES_PER_WG;
+    if (vwgs > 2 * pl->n_cu) vwgs = 2 * pl->n_cu;
+    HIP_TRY(pilot::launch_wide_value(dim3(vwgs), s, p, pl->wide_rec));
+    if (ev) { HIP_TRY(hipEventRecord(ev[3], s)); ++pl->n_timed; }
+    return run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows, row_step, d_emd, d_iters, d_err,
+                       d_flags, s, pl->nan_list, pl->track_count + 10, pl->track_count + 11);
+}
+
 }  // namespace
 
 PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg,
@@ -826,6 +898,15 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     {
         const int n_rows_g = (row_end - row_begin + row_step - 1) / row_step;
         // K beyond the MFMA kernels, a reg beyond the f64 range of exp(-M/reg) (judged by the plan's max_cost), or on request: POT's loop literally, absorbed kernel rebuilt per pair
+        // 128 < K <= 256 (the fixed Gibbs image no longer fits one wave's registers and LDS): eight waves per tile while the
+        // call is inside the fp16-split range with a symmetric cost; an explicit f64 / POT-literal request, a non-symmetric cost
+        // or a smaller reg keep the POT-literal kernel
+        if (pl->K > MAX_K && pl->K <= WIDE_MAX_K && cost_is_symmetric && precision != PILOT_OT_PREC_GENERIC && precision != PILOT_OT_PREC_F64 &&
+            pl->max_cost / reg <= h_max_cost_over_reg() && tau <= pilot::H_MAX_TAU && !getenv("PILOT_OT_NO_WIDE")) {
+            if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
+            return run_wide(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, row_begin, n_rows_g, row_step, d_emd,
+                            d_iters, d_err, d_flags, static_cast<hipStream_t>(stream));
+        }
         if (precision == PILOT_OT_PREC_GENERIC || pl->K > MAX_K || pl->max_cost / reg > MAX_COST_OVER_REG)
             return run_generic(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, row_begin, n_rows_g, row_step, d_emd,
                                d_iters, d_err, d_flags, static_cast<hipStream_t>(stream));

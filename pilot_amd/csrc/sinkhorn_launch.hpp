@@ -25,6 +25,11 @@ hipError_t launch_stream_tv(int cfg, int tv, int RT, bool sym, bool track, dim3 
 hipError_t launch_prep(int cfg, const double *M, int K, int RT, double reg, void *img, const double *P, void *Pslot, int N, int write_tail,
                        double stop_thr, double floor_ulps, int n_rows, int row_begin, int row_step, unsigned char *bucket, int *hist, int *list, int *split,
                        int *main_queue_head, int mode, int n_blocks, hipStream_t s);
+// 128 < K <= 256, symmetric cost, fp16-split range (wide_kernels.hpp): the pair-grid kernel (8 waves per 16-pair tile; one
+// record of wide_rec_elems() 4-byte words per pair in `rec`) and the kernel that turns the records into costs
+hipError_t launch_wide(dim3 grid, hipStream_t s, const GridParams &p, float *rec);
+hipError_t launch_wide_value(dim3 grid, hipStream_t s, const GridParams &p, const float *rec);
+size_t wide_rec_elems();
 // elements of T in the operand block of a call (see img_layout in sinkhorn_kernels.hpp)
 size_t img_elems(int cfg, int RT);
 size_t form_elems_rt(int cfg, int RT);

@@ -49,7 +49,7 @@ hipError_t prep_any(const double *M, int K, int RT, double reg, void *img, const
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sinkhorn_prep_kernel<C>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      // (K = 256: 140 KB of column tile)
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }

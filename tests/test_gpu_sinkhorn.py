@@ -107,18 +107,54 @@ def test_every_tile_shape(K, prec, tol):
 
 @pytest.mark.parametrize("K", [130, 200])
 def test_k_above_128_runs_the_reference_semantics_kernel(K):
-    """The reference has no limit on the number of cell types (Trajectory.py:479-523): beyond the MFMA kernels' 128 the
-    pair grid runs POT's loop literally in fp64 (generic_kernels.hpp) and must follow the oracle update for update."""
+    """The reference has no limit on the number of cell types (Trajectory.py:479-523).  Asked for fp64 (or POT-literal)
+    arithmetic, or outside the fp16-split range, a grid beyond the single-wave MFMA kernels' 128 runs POT's loop literally in
+    fp64 (generic_kernels.hpp) and must follow the oracle update for update."""
     P, M = make_problem(9, K, 4, seed=K, cells_per_patient=2000)
     Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
-    Eg, ig = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.1, return_info=True, precision="fp64")
     assert np.abs(Eg - Eo).max() <= 1e-12
     np.testing.assert_array_equal(ig["iters"], io["iters"])
     assert np.all((ig["flags"] & _lib.FLAG_F64) > 0)
-    part = engine.sinkhorn_grid(P, M, 0.1, row_begin=2, row_end=7, row_step=3)
+    part = engine.sinkhorn_grid(P, M, 0.1, row_begin=2, row_end=7, row_step=3, precision="fp64")
     np.testing.assert_array_equal(part, Eg[2:7:3])
+    Eo2 = O.sinkhorn_grid(P, M, 0.04, n_threads=16)                      # max(M)/reg = 25: outside the fp16-split range
+    assert np.abs(engine.sinkhorn_grid(P, M, 0.04) - Eo2).max() <= 1e-12
     # exact mode up to 256 cell types (cost matrix read from L2 instead of LDS)
     assert np.abs(engine.emd_grid(P, M) - O.emd_grid(P, M, n_threads=16)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("K", [129, 130, 160, 192, 250, 256])
+def test_k_129_to_256_runs_eight_waves_per_tile(K):
+    """128 < K <= 256, symmetric cost, max(M)/reg <= 16: sinkhorn_wide_kernel (wide_kernels.hpp) -- the fp16-split products with
+    a tile's cell types spread over the eight waves of a workgroup -- instead of one workgroup per pair (round 3: 600x slower
+    than K = 128).  f32-class tolerance against the fp64 oracle, the f32 stopping rule (same or an earlier check), shard /
+    full identity bit for bit, the diagonal included; pairs it hands over (tau) come back from the POT-literal kernel."""
+    N = 40
+    P, M = make_problem(N, K, 6, seed=K, cells_per_patient=3000)
+    P[7] = P[3]                                                          # duplicate patients: the slowest pairs
+    Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+    assert np.isfinite(Eg).all() and np.abs(Eg - Eo).max() <= TOL32
+    f64 = (ig["flags"] & _lib.FLAG_F64) > 0
+    assert f64.mean() < 0.2                                              # (hand-overs only)
+    assert np.all(ig["iters"][~f64] <= io["iters"][~f64]) and np.all(ig["iters"][~f64] % 20 == 1)
+    for rb, re_, rs in ((0, N, 7), (5, 6, 1), (3, N, 11)):
+        part = engine.sinkhorn_grid(P, M, 0.1, row_begin=rb, row_end=re_, row_step=rs)
+        np.testing.assert_array_equal(part, Eg[rb:re_:rs])
+    np.testing.assert_array_equal(engine.sinkhorn_grid(P, M, 0.1), Eg)   # deterministic
+    # reg 1.0 (few updates) and a tau that makes many pairs hand over
+    assert np.abs(engine.sinkhorn_grid(P, M, 1.0) - O.sinkhorn_grid(P, M, 1.0, n_threads=16)).max() <= TOL32
+    if K not in (130, 256):
+        return
+    for tau in (2.0, 1.2):
+        Et, it_ = engine.sinkhorn_grid(P, M, 0.1, tau=tau, return_info=True)
+        Eot, iot = O.sinkhorn_grid(P, M, 0.1, tau=tau, n_threads=16, return_info=True)
+        edge = ((iot["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((it_["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+        assert np.abs(Et - Eot)[~edge].max() <= TOL32
+        absorbed = (it_["flags"] & _lib.FLAG_ABSORBED) > 0
+        assert np.all((it_["flags"][absorbed] & _lib.FLAG_F64) > 0)      # absorbing pairs were handed to the POT-literal kernel
+    assert absorbed.sum() > 0                                            # (at tau = 1.2 some pair does absorb)
 
 
 def test_generic_kernel_is_pot_literal_including_absorption_and_tiny_reg():
