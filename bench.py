@@ -140,8 +140,13 @@ def main():
     P, M = make_problem(**cfg)
     N, K = P.shape
     prec = args.precision
+    run_prec = prec                       # what the library is asked for
     if prec == "auto":
-        prec = {1: "fp32", 2: "fp64", 3: "bf16x3", 6: "f16x2"}[L.pilot_ot_auto_precision_for(float(M.max()) / args.reg, K, int(np.array_equal(M, M.T)))]
+        # what AUTO resolves to for this shape: the label of the line.  Beyond max(M)/reg = 60 AUTO means the two-band
+        # bf16-split tracking kernel with an f64 pass for the pairs that need it ("mixed"), which only "auto" selects
+        code = L.pilot_ot_auto_precision_for(float(M.max()) / args.reg, K, int(np.array_equal(M, M.T)))
+        prec = {1: "fp32", 2: "mixed", 3: "bf16x3", 6: "f16x2"}[code]
+        run_prec = "auto" if prec == "mixed" else prec
 
     if args.mode == "emd":
         out = bench_emd(args, L, P, M, cfg)
@@ -158,7 +163,7 @@ def main():
             mp = multi.MultiPlan(P, M, devices=devices)
 
         def step():
-            mp.sinkhorn(args.reg, precision=prec)
+            mp.sinkhorn(args.reg, precision=run_prec)
 
         def fence():
             mp.sync()
@@ -177,7 +182,7 @@ def main():
             _lib.check(L.pilot_ot_memcpy_h2d(plan.dE, zeros.ctypes.data, 8 * n_pad * N))   # padding rows = 0
 
         def step():
-            plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=prec)
+            plan.run(args.reg, row_begin=rb, row_end=re_, row_step=rs, precision=run_prec)
             if comm:
                 comm.all_gather_rows(plan.dE, n_pad, N, d_stage.p, d_full.p)
 
@@ -294,7 +299,7 @@ def main():
         out["c4"] = bench_c4(L, rank, world, comm, args, single_process_multi)
     if rank == 0 and world == 1 and not single_process_multi:
         if extras:
-            out["value_host_to_host"] = host_to_host(P, M, args.reg, prec)
+            out["value_host_to_host"] = host_to_host(P, M, args.reg, run_prec)
             out["precision_ladder"] = precision_ladder(P, M, args.reg, args.config)
             out["reg_sweep"] = reg_sweep(P, M, K)
             out["exact_emd"] = exact_emd_brief(L, P, M)
@@ -317,8 +322,9 @@ def main():
 
 
 
-KERNEL_CFG = {"fp32": "CfgF32x16", "fp64": "CfgF64x16", "bf16x3": "CfgS32x16", "f16x2": "CfgH32x16"}
+KERNEL_CFG = {"fp32": "CfgF32x16", "fp64": "CfgF64x16", "bf16x3": "CfgS32x16", "f16x2": "CfgH32x16", "mixed": "CfgS32x16 (two exponent bands, tracking)"}
 DTYPE_NOTE = {"fp32": "f32", "fp64": "f64",
+              "mixed": "f32 (exact 3-way bf16 splits in two exponent bands of the Gibbs kernel; pairs that leave the f32 range redone in f64)",
               "bf16x3": "f32 (products as exact 3-way bf16 splits on the bf16 MFMA, f32 accumulate)",
               "f16x2": "f32 (products as 2-way fp16 splits, 22 significant bits, on the f16 MFMA, f32 accumulate)"}
 
@@ -341,15 +347,15 @@ def make_roofline(prec, K, iters, kern_ms, track_ms, share=1.0):
     t = kern_ms * 1e-3
     alg_tf = flops_launch / t / 1e12
     roofline = {"bound": "mfma", "kernel": "pilot::sinkhorn_stream_kernel<%s, ...>" % KERNEL_CFG[prec]}
-    if prec in ("bf16x3", "f16x2"):
+    if prec in ("bf16x3", "f16x2", "mixed"):
         rt = (K + 15) // 16
-        terms = 6 if prec == "bf16x3" else 3
+        terms = {"bf16x3": 6, "f16x2": 3, "mixed": 9}[prec]      # (mixed: 6 band-0 + 3 band-1 piece products per term block)
         mfma_launch = float(iters.sum()) / 16.0 * 2 * rt * ((rt + 1) // 2) * terms * share
         ex_tf = mfma_launch * 16384.0 / t / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16x3" else PEAK_F16_MFMA_TFLOPS
+        peak = PEAK_F16_MFMA_TFLOPS if prec == "f16x2" else PEAK_BF16_MFMA_TFLOPS
         roofline.update({
             "achieved": round(ex_tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ex_tf / peak, 4),
-            "pipe": "v_mfma_f32_16x16x32_%s (dense 16-bit matrix pipe)" % ("bf16" if prec == "bf16x3" else "f16"),
+            "pipe": "v_mfma_f32_16x16x32_%s (dense 16-bit matrix pipe)" % ("f16" if prec == "f16x2" else "bf16"),
             "achieved_is": "piece-MFMA flop issued per launch / kernel time: %d piece products per term block, K padded %d -> %d "
                            "(contraction) x %d (rows)" % (terms, K, 32 * ((rt + 1) // 2), 16 * rt),
             "mfma_per_launch": mfma_launch,

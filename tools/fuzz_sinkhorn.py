@@ -11,7 +11,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
-    N = int(rng.integers(1, 400 if os.environ.get("FUZZ_BIG") else 70)); K = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 20, 31, 32, 33, 48, 50, 64, 65, 80, 100, 128]))
+    N = int(rng.integers(1, 400 if os.environ.get("FUZZ_BIG") else 70)); K = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 13, 16, 17, 20, 31, 32, 33, 48, 50, 64, 65, 80, 100, 128, 129, 130, 150, 192, 200, 255, 256]))
     reg = float(rng.choice([1.0, 0.3, 0.1, 0.05, 0.02, 0.01]))
     alpha = float(rng.choice([0.2, 1.0, 5.0]))
     P = rng.dirichlet(alpha * np.ones(K), size=N)
