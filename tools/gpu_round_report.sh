@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything the round commits under profiles/: usage tools/gpu_round_report.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/report_$TAG
 mkdir -p $O
@@ -25,6 +25,11 @@ python tools/host_enqueue_time.py > $O/host_enqueue_time.txt 2>&1
 python tools/k_sweep.py > $O/k_sweep.txt 2>&1
 python tools/consumer_rate.py > $O/consumer_rate.txt 2>&1
 python tools/small_reg_probe.py > $O/small_reg_c3_reg0.01.txt 2>&1
+python tools/small_k_probe.py 2 3 4 5 6 7 8 12 > $O/small_k_probe.txt 2>&1
+python tools/real_cohort_probe.py > $O/real_cohort_kidney_igan_g.txt 2>&1
+python tools/big_k_probe.py > $O/big_k_probe.txt 2>&1
+python tools/mid_reg_probe.py > $O/mid_reg_probe.txt 2>&1
+for p in 2 4 12 real 50; do python tools/emd_point.py $p; done > $O/emd_points.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
@@ -51,5 +56,14 @@ cp $O/pmc_k80/summary.txt $O/rocprofv3_pmc_summary_k80.txt
 BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k96 96 > /dev/null 2>&1
 cp $O/pmc_k96/summary.txt $O/rocprofv3_pmc_summary_k96.txt
 python tools/make_traffic_json.py $O > $O/traffic.json
+# the other rungs of the precision ladder: kernel-trace average + the PMC passes, merged into traffic.json
+for prec in fp32 bf16x3 fp64; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$prec -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --precision $prec > /dev/null 2>&1)
+  cp $O/stats_$prec/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_bench_c3_$prec.csv 2>/dev/null
+  bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_$prec --no-extras --precision $prec > /dev/null 2>&1
+  cp $O/pmc_$prec/summary.txt $O/rocprofv3_pmc_summary_bench_c3_$prec.txt
+  TRAFFIC_SUFFIX=_$prec python tools/make_traffic_json.py $O > $O/traffic.json.new && mv $O/traffic.json.new $O/traffic.json
+  rm -rf $O/stats_$prec $O/pmc_$prec
+done
 rm -rf $O/stats $O/stats_emd $O/stats_emd_c4 $O/stats_cellw2 $O/stats_cons $O/stats_k80 $O/stats_k96 $O/pmc $O/pmc_emd $O/pmc_k80 $O/pmc_k96
 cat $O/pytest_gpu.txt $O/smoke.txt; cut -c1-700 $O/bench_c3_reg0.1_n1.json; head -6 $O/rocprofv3_kernel_stats_bench_c3.csv; cat $O/traffic.json
