@@ -826,6 +826,21 @@ int run_wide(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
              int check_period, double floor_ulps, int row_begin, int n_rows, int row_step, double *d_emd, int *d_iters, double *d_err,
              int *d_flags, hipStream_t s) {
     const int N = pl->N, K = pl->K, RT = 16;
+    // the records are 2 KB per pair: a big grid is solved in row chunks of at most WIDE_CHUNK_PAIRS pairs (1 GB of records),
+    // each a complete call of its own (same kernels, same pair -> same bits whatever the chunking)
+    long WIDE_CHUNK_PAIRS = 512L * 1024;
+    if (const char *e = getenv("PILOT_OT_WIDE_CHUNK")) { const long v = atol(e); if (v > 0) WIDE_CHUNK_PAIRS = v; }     // (tests)
+    if ((long)n_rows * N > WIDE_CHUNK_PAIRS && n_rows > 1) {
+        const int rows_per = (int)(WIDE_CHUNK_PAIRS / N) > 0 ? (int)(WIDE_CHUNK_PAIRS / N) : 1;
+        for (int r0 = 0; r0 < n_rows; r0 += rows_per) {
+            const int nr = n_rows - r0 < rows_per ? n_rows - r0 : rows_per;
+            const size_t off = (size_t)r0 * N;
+            const int rc = run_wide(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, floor_ulps, row_begin + r0 * row_step, nr, row_step,
+                                    d_emd + off, d_iters ? d_iters + off : nullptr, d_err ? d_err + off : nullptr, d_flags ? d_flags + off : nullptr, s);
+            if (rc != PILOT_OT_OK) return rc;
+        }
+        return PILOT_OT_OK;
+    }
     pl->order_hist = pl->track_count + CTRL_INTS;
     HIP_TRY(hipMemsetAsync(pl->track_count, 0, (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int), s));
     if (n_rows == 0) return PILOT_OT_OK;

@@ -106,9 +106,15 @@ __global__ void __launch_bounds__(WAVE * WIDE_WAVES, 2) sinkhorn_wide_kernel(Gri
         const unsigned long long wmask = __ballot(want) & colmask;
         if (wmask) {
             if (res_next >= res_end && !exhausted) {
-                if (threadIdx.x == 0) sh_base[draws & 1] = __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                const int base = __builtin_amdgcn_readfirstlane(sh_base[draws & 1]);
+                int base;
+                if (draws == 0) {                   // the first batch is the workgroup's own number: no atomic, no barrier
+                    base = (int)blockIdx.x * TILE;
+                } else {
+                    if (threadIdx.x == 0)
+                        sh_base[draws & 1] = (int)gridDim.x * TILE + __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    base = __builtin_amdgcn_readfirstlane(sh_base[draws & 1]);
+                }
                 ++draws;
                 exhausted = base >= n_items;
                 res_next = exhausted ? n_items : base;

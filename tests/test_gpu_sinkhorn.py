@@ -125,7 +125,7 @@ def test_k_above_128_runs_the_reference_semantics_kernel(K):
 
 
 @pytest.mark.parametrize("K", [129, 130, 160, 192, 250, 256])
-def test_k_129_to_256_runs_eight_waves_per_tile(K):
+def test_k_129_to_256_runs_eight_waves_per_tile(K, monkeypatch):
     """128 < K <= 256, symmetric cost, max(M)/reg <= 16: sinkhorn_wide_kernel (wide_kernels.hpp) -- the fp16-split products with
     a tile's cell types spread over the eight waves of a workgroup -- instead of one workgroup per pair (round 3: 600x slower
     than K = 128).  f32-class tolerance against the fp64 oracle, the f32 stopping rule (same or an earlier check), shard /
@@ -147,6 +147,9 @@ def test_k_129_to_256_runs_eight_waves_per_tile(K):
     assert np.abs(engine.sinkhorn_grid(P, M, 1.0) - O.sinkhorn_grid(P, M, 1.0, n_threads=16)).max() <= TOL32
     if K not in (130, 256):
         return
+    monkeypatch.setenv("PILOT_OT_WIDE_CHUNK", "300")                     # row chunks of 7 rows (the 1 GB cap of the records, forced)
+    np.testing.assert_array_equal(engine.sinkhorn_grid(P, M, 0.1), Eg)
+    monkeypatch.delenv("PILOT_OT_WIDE_CHUNK")
     for tau in (2.0, 1.2):
         Et, it_ = engine.sinkhorn_grid(P, M, 0.1, tau=tau, return_info=True)
         Eot, iot = O.sinkhorn_grid(P, M, 0.1, tau=tau, n_threads=16, return_info=True)
