@@ -45,3 +45,25 @@ def test_device_list_validation():
         multi._devices(None, None)
     assert list(multi._devices(None, 3)) == [0, 1, 2]
     assert list(multi._devices([0, 0], None)) == [0, 0]
+
+
+def test_stdout_to_stderr_moves_c_level_prints_and_restores():
+    """multi.stdout_to_stderr(): what bench.py wraps communicator creation in (RCCL prints its version banner with a plain
+    printf).  In a child process: a C-level write to fd 1 inside the block lands on stderr, stdout works again afterwards."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, ctypes\n"
+        "sys.path.insert(0, %r)\n"
+        "from pilot_amd import multi\n"
+        "libc = ctypes.CDLL(None)\n"
+        "print('before', flush=True)\n"
+        "with multi.stdout_to_stderr():\n"
+        "    libc.printf(b'banner from C\\n')\n"
+        "    os.write(1, b'raw write\\n')\n"
+        "print('after', flush=True)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["before", "after"]
+    assert "banner from C" in r.stderr and "raw write" in r.stderr
