@@ -55,8 +55,9 @@ extern "C" {
                                    * tells which).  Falls back to F64 where the images do not fit LDS or max(M)/reg > 140. */
 #define PILOT_OT_PREC_GENERIC 5 /* reference-semantics fallback: POT's sinkhorn_stabilized loop literally in fp64, one workgroup per
                                 * pair, absorbed kernel exp(-(M - alpha - beta)/reg) rebuilt at every tau-absorption.  Taken
-                                * automatically when K > 128 or max(M)/reg > 600 (where the fixed Gibbs image of the fast kernels
-                                * leaves the f64 range); NaN handling is POT's (revert to the last good iterate). */
+                                * automatically when K > 256, when 128 < K <= 256 falls outside the range of the eight-waves-per-tile
+                                * kernel (below), or max(M)/reg > 600 (where the fixed Gibbs image of the fast kernels leaves the
+                                * f64 range); NaN handling is POT's (revert to the last good iterate). */
 #define PILOT_OT_PREC_BF16X3 3 /* f32 values, products on v_mfma_f32_16x16x32_bf16 through exact 3-way bf16 operand splits
                                 * (six piece products per term, f32 accumulation): f32-level rounding, not bit-identical
                                 * to PREC_F32, ~2x its speed */
@@ -162,9 +163,11 @@ int pilot_ot_cost_matrix_dev_ex(const double *d_centroids, int K, int D, int met
  * num_iter_max=1000, stop_thr=1e-9, tau=1e3, check_period=20.  In f32 the stop threshold is
  * floored at f32_floor_ulps * FLT_EPSILON * ||b||_2 (pass 0 for the default of 8).
  * cost_is_symmetric: 1 if M == M^T exactly (always true for pdist output), 0 otherwise.
- * Range: K <= 128 and max(M)/reg <= 600 run on the MFMA kernels (they keep total scalings against the fixed exp(-M/reg), so
- * the ratio must fit the f64 exponent range); larger K (<= 2048) or smaller reg run PILOT_OT_PREC_GENERIC, whatever precision
- * was asked for.  The device-resident form cannot see max(M): it judges the range by the plan's max_cost / reg, which is
+ * Range: K <= 128 and max(M)/reg <= 600 run on the one-wave-per-tile MFMA kernels (they keep total scalings against the fixed
+ * exp(-M/reg), so the ratio must fit the f64 exponent range).  128 < K <= 256 with a symmetric cost, max(M)/reg <= 16 and
+ * tau <= 2000 runs the fp16-split products with a tile's cell types spread over the eight waves of a workgroup (any f32-class
+ * precision request, AUTO included; f32 tolerance; PILOT_OT_PREC_F64 / _GENERIC keep the POT-literal kernel).  Larger K
+ * (<= 2048), the rest of 128 < K <= 256, or a smaller reg run PILOT_OT_PREC_GENERIC, whatever precision was asked for.  The device-resident form cannot see max(M): it judges the range by the plan's max_cost / reg, which is
  * 1/reg (M divided by its max, Trajectory.py:101) until pilot_ot_plan_set_max_cost says otherwise.
  * emd / iters / err / flags: n_rows x N; iters, err, flags may be NULL. */
 int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, double reg,
