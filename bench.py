@@ -173,7 +173,10 @@ def main():
         n_local = sharding.n_local_rows(N, rank, world)
         n_pad = sharding.n_padded_rows(N, world)
         plan = engine.DevicePlan(P, M, n_rows_max=max(n_pad, 1))       # P, M -> HBM (resident from here on)
-        plan.enable_timing(True)
+        # HIP events around the pair-grid kernel on every 4th step of the timed region (on every step the four event records
+        # cost a 0.69 ms step 2 %; `roofline.kernel_ms` is the mean of the steps that carry them)
+        TIMING_STRIDE = 4 if args.steps >= 8 else 1
+        plan.enable_timing(TIMING_STRIDE)
         with multi.stdout_to_stderr():       # (RCCL's version banner is a printf: this program's stdout carries one JSON line)
             comm = multi.Comm(rank, world) if (world > 1 or args.force_comm) else None
         if comm:
@@ -203,6 +206,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if not single_process_multi:
+        plan.enable_timing(TIMING_STRIDE)          # (counters restart: the timed steps 0, 4, 8, .. carry the events)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -224,7 +229,7 @@ def main():
                     "rccl_ranks": rn, "rccl_user_rank": rr,
                     "rccl_note": "ncclCommCount / ncclCommUserRank of every shard's communicator (0 / -1: peer-copy gather, no RCCL)"}
     else:
-        main_ms, track = plan.kernel_times_ms(max_n=min(args.steps, 64))
+        main_ms, track = plan.kernel_times_ms(max_n=min((args.steps + TIMING_STRIDE - 1) // TIMING_STRIDE, 64))
         kern_ms = float(np.mean(main_ms)) if len(main_ms) else float("nan")
         track_ms = float(np.mean(track)) if len(track) else None
         if track_ms is not None and track_ms > kern_ms:        # small reg: every pair runs the tau-tracking launch
@@ -372,7 +377,7 @@ def make_roofline(prec, K, iters, kern_ms, track_ms, share=1.0):
                          "achieved_is": "algorithmic flop of SURVEY 8(d) per launch / kernel time"})
     roofline.update({
         "traffic": None,
-        "kernel_ms": round(kern_ms, 4), "kernel_ms_source": "HIP events on the launch stream, mean over the timed steps",
+        "kernel_ms": round(kern_ms, 4), "kernel_ms_source": "HIP events on the launch stream inside the timed region (every 4th step when steps >= 8), mean",
         "track_kernel_ms": round(track_ms, 4) if track_ms is not None else None,
         "algorithmic_flop_per_launch": flops_launch, "pairs_per_launch": pairs_launch,
         "mean_updates_per_pair": round(float(iters.mean()), 2)})

@@ -339,6 +339,7 @@ class DevicePlan:
             ctypes.c_void_p(stream) if stream else None))
 
     def enable_timing(self, enable=True):
+        """HIP events around the pair-grid kernels of every call (``True``) or of every n-th call (``enable=n``)."""
         _lib.check(self.L.pilot_ot_plan_enable_timing(self.plan, int(enable)))
 
     def enable_graph(self, enable=True):
