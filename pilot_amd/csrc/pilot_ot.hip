@@ -193,6 +193,12 @@ constexpr int MAX_K = 128;          // the MFMA pair-grid kernels (8 row-tiles o
 constexpr int GENERIC_MAX_K = 2048;  // the reference-semantics fallback kernel (vectors in LDS)
 constexpr int EMD_MAX_K = 256;       // exact-OT kernel: 4 rows / columns per lane
 constexpr int WIDE_MAX_K = 256;      // sinkhorn_wide_kernel: 128 < K <= 256, eight waves per 16-pair tile
+// (experiment switch PILOT_OT_WIDE_MIN_K: the eight-waves-per-tile kernel from a smaller K on)
+static int wide_min_k() {
+    const char *e = getenv("PILOT_OT_WIDE_MIN_K");
+    const int v = e && *e ? atoi(e) : 0;
+    return v > 0 && v < MAX_K ? v : MAX_K;
+}
 constexpr int CTRL_INTS = pilot::CTRL_INTS;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
@@ -443,6 +449,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
         if (b32 > img_bytes) img_bytes = b32;
         if (bs > img_bytes) img_bytes = bs;
         if (bh > img_bytes) img_bytes = bh;
+        if (K > wide_min_k() && pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float) > img_bytes) img_bytes = pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float);
         if (e == hipSuccess) e = hipMalloc(&pl->img, img_bytes);
     } else if (K <= WIDE_MAX_K) {       // the 8-waves-per-tile kernel: the fp16-split operand block at 16 row-tiles
         if (e == hipSuccess) e = hipMalloc(&pl->img, pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float));
@@ -917,7 +924,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
         // 128 < K <= 256 (the fixed Gibbs image no longer fits one wave's registers and LDS): eight waves per tile while the
         // call is inside the fp16-split range with a symmetric cost; an explicit f64 / POT-literal request, a non-symmetric cost
         // or a smaller reg keep the POT-literal kernel
-        if (pl->K > MAX_K && pl->K <= WIDE_MAX_K && cost_is_symmetric && precision != PILOT_OT_PREC_GENERIC && precision != PILOT_OT_PREC_F64 &&
+        if (pl->K > wide_min_k() && pl->K <= WIDE_MAX_K && cost_is_symmetric && precision != PILOT_OT_PREC_GENERIC && precision != PILOT_OT_PREC_F64 &&
             pl->max_cost / reg <= h_max_cost_over_reg() && tau <= pilot::H_MAX_TAU && !getenv("PILOT_OT_NO_WIDE")) {
             if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
             return run_wide(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, row_begin, n_rows_g, row_step, d_emd,

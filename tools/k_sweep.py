@@ -5,7 +5,7 @@ import numpy as np
 from pilot_amd import engine
 from pilot_amd.synthetic import make_problem
 N = 600
-for K in (4, 8, 12, 16, 17, 20, 24, 30, 32, 33, 36, 40, 48, 49, 50, 52, 56, 64, 65, 68, 72, 80, 81, 96, 100, 112, 113, 128):
+for K in (2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 20, 24, 30, 32, 33, 36, 40, 48, 49, 50, 52, 56, 64, 65, 68, 72, 80, 81, 96, 100, 112, 113, 128, 129, 160, 192, 256):
     P, M = make_problem(N, K, 8, seed=K, cells_per_patient=200)
     plan = engine.DevicePlan(P, M)
     for _ in range(20): plan.run(0.1)
