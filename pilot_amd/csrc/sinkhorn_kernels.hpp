@@ -584,7 +584,10 @@ __device__ inline void panel_product_pieces(const typename C::T *form, const typ
 // the LDS bandwidth (one ds_read_b128 = 4 LDS cycles per 16-cycle MFMA and SIMD, MI355X_MICROARCH.md "LDS").
 template <int RT, int NP> struct SplitImage { u32x4_t a[NP][split_kblocks(RT)][RT]; };
 #ifndef PILOT_AREG_ORDER
-#define PILOT_AREG_ORDER 1
+#define PILOT_AREG_ORDER 2      // (round 4: 1 -> 2, c3 kernel 0.634 -> 0.617 ms on one box; orders 0, 3, 4: 0.634, 0.626, 0.619)
+#endif
+#ifndef PILOT_DEFER_HANDOVER
+#define PILOT_DEFER_HANDOVER 1
 #endif
 template <class C, int RT>
 __device__ inline void panel_product_pieces_regs(const SplitImage<RT, C::NP> &A, const SplitPanel<RT, C::NP> &B,
@@ -602,6 +605,41 @@ __device__ inline void panel_product_pieces_regs(const SplitImage<RT, C::NP> &A,
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][kb][t], B.p[term_b<NP>(i)][kb], OUT[t]);
+#elif PILOT_AREG_ORDER == 2
+    // chains interleaved up to the last k-block, the last one tile after tile: tile t is complete 3 (RT - 1 - t) MFMAs before
+    // the end, so its element-wise work can run under the MFMAs of the later tiles (same per-tile term order: same bits)
+#pragma unroll
+    for (int kb = 0; kb < KB - 1; ++kb)
+#pragma unroll
+        for (int i = 0; i < n_terms<NP>(); ++i)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][kb][t], B.p[term_b<NP>(i)][kb], OUT[t]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][KB - 1][t], B.p[term_b<NP>(i)][KB - 1], OUT[t]);
+#elif PILOT_AREG_ORDER == 3
+    // every k-block tile after tile
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][kb][t], B.p[term_b<NP>(i)][kb], OUT[t]);
+#elif PILOT_AREG_ORDER == 4
+    // like 2, the last k-block in tile PAIRS (two chains interleaved)
+#pragma unroll
+    for (int kb = 0; kb < KB - 1; ++kb)
+#pragma unroll
+        for (int i = 0; i < n_terms<NP>(); ++i)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][kb][t], B.p[term_b<NP>(i)][kb], OUT[t]);
+#pragma unroll
+    for (int t0 = 0; t0 < RT; t0 += 2)
+#pragma unroll
+        for (int i = 0; i < n_terms<NP>(); ++i)
+#pragma unroll
+            for (int t = t0; t < (t0 + 2 < RT ? t0 + 2 : RT); ++t) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][KB - 1][t], B.p[term_b<NP>(i)][KB - 1], OUT[t]);
 #else
     // the RT accumulator chains interleaved
 #pragma unroll
@@ -1526,8 +1564,9 @@ sinkhorn_stream_kernel(GridParams p) {
                 const unsigned long long zmask = column_any_mask<C>(over && z);
                 if ((zmask >> col) & 1ull) U[0][0] = __builtin_nanf("");
             }
-        } else {
-            // hand the pair to the tracking kernel (it restarts the pair from its first update)
+        }
+        // hand the pair to the tracking kernel (it restarts the pair from its first update)
+        auto hand_over = [&]() {
             if (omask) {
                 if (over) {
                     if (grp == 0) hb[hb_cnt + (int)__popcll(omask & ((1ull << col) - 1ull))] = q;
@@ -1537,12 +1576,17 @@ sinkhorn_stream_kernel(GridParams p) {
                 hb_cnt += (int)__popcll(omask);                         // (wave-uniform; <= HANDOVER_FLUSH - 1 + TILE <= HANDOVER_BUF)
                 if (hb_cnt >= HANDOVER_FLUSH) hb_flush();
             }
-        }
+        };
+        // (fp16-split configuration: the hand-over -- a wave-uniform branch -- waits until the second product is issued, so that
+        // quotients, both products and the tau maximum are ONE basic block and the scheduler may run the element-wise work of
+        // the first tiles under the MFMAs of the later ones; the product of a column that is being handed over is wasted work)
+        if constexpr (!TRACK && !(C::HALF && PILOT_DEFER_HANDOVER)) hand_over();
         ++ii;   // ii updates of (v, u) are done for this column
 
         // ---- ACC = G^T u: feeds the stopping test of this update and the next v ----------------------
         if constexpr (C::HALF) product_h(a_gt.img, PU, ACC);
         else product(a_gt, w_gt, U, ACC, PADC);
+        if constexpr (!TRACK && C::HALF && PILOT_DEFER_HANDOVER) hand_over();
 
         // ---- POT's stopping rule: the error of update ii-1 is evaluated when (ii-1) % period == 0 ---
         const bool pending = active && ii == chk;

@@ -5,7 +5,7 @@ cd $R/pilot_amd/csrc
 cp ../libpilot_ot.so /tmp/libpilot_ot.keep.so
 for v in "" "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $v -c -o /tmp/pilot_ot_var.o pilot_ot.hip 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_var.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_inst_*.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_var.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_wide.o build/sk_inst_*.o -ldl
   for pt in ${POINTS:-4 real 50}; do
     echo "[$v] $(timeout 120 python3 $R/tools/emd_point.py $pt 2>&1 | tail -1)"
   done

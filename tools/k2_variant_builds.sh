@@ -22,7 +22,7 @@ for v in "$@"; do
     host=/tmp/pilot_ot_var.o
   fi
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so $host build/pilot_ot_multi.o build/pilot_ot_consumers.o $objs -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so $host build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_wide.o $objs -ldl
   run "$v"
 done
 cp /tmp/libpilot_ot.keep.so ../libpilot_ot.so
