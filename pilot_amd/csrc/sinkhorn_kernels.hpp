@@ -586,6 +586,9 @@ template <int RT, int NP> struct SplitImage { u32x4_t a[NP][split_kblocks(RT)][R
 #ifndef PILOT_AREG_ORDER
 #define PILOT_AREG_ORDER 2      // (round 4: 1 -> 2, c3 kernel 0.634 -> 0.617 ms on one box; orders 0, 3, 4: 0.634, 0.626, 0.619)
 #endif
+#ifndef PILOT_E2_EARLY
+#define PILOT_E2_EARLY 0      // (tried: neutral, c3 kernel 0.611 - 0.614 ms either way)
+#endif
 #ifndef PILOT_DEFER_HANDOVER
 #define PILOT_DEFER_HANDOVER 1
 #endif
@@ -1592,11 +1595,9 @@ sinkhorn_stream_kernel(GridParams p) {
         const bool pending = active && ii == chk;
         if (pending) chk += p.period;
         const bool capped = active && ii >= p.max_iter;
-        if (__ballot(pending || capped)) {
+        // squared marginal error of this lane's slots, per-tile partial sums added in tile order
+        auto lane_e2 = [&](T sc) {
             T e2 = T(0);
-            T sc = T(1);
-            if constexpr (TRACK) sc = (abs_at == ii - 1) ? T(1) / kk : T(1);  // u, v were just reset to 1/K each
-            // per-tile partial sums added in tile order
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 T et = T(0);
@@ -1610,6 +1611,19 @@ sinkhorn_stream_kernel(GridParams p) {
                 }
                 e2 += et;
             }
+            return e2;
+        };
+        // (fast split kernels: the lane's part of the error is formed on EVERY update, in the block of the product that feeds it --
+        // its ~26 vector instructions issue under the last MFMAs of that product, where the wave otherwise waits for the matrix
+        // pipe -- instead of in the 56 % of the updates that test some column, where nothing covers them; same operations in
+        // the same order: same bits)
+        constexpr bool E2_EARLY = C::SPLIT && !TRACK && PILOT_E2_EARLY;
+        T e2_early = T(0);
+        if constexpr (E2_EARLY) e2_early = lane_e2(T(1));
+        if (__ballot(pending || capped)) {
+            T sc = T(1);
+            if constexpr (TRACK) sc = (abs_at == ii - 1) ? T(1) / kk : T(1);  // u, v were just reset to 1/K each
+            T e2 = E2_EARLY ? e2_early : lane_e2(sc);
             e2 = group_sum<C>(e2);
             const T e = sqrt(e2);
             bool fin = capped;
