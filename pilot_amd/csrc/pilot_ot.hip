@@ -616,7 +616,6 @@ StreamLds stream_lds(size_t fixed, size_t slot_bytes, int want, int min_ring = 4
 bool split_fits_lds(int K, bool sym, int bands = 1) {
     const int RT = (K + 15) / 16, KP = RT * 16;
     const size_t fixed = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * 4 * bands + (size_t)KP * 4 +
-                         (size_t)pilot::WAVES_PER_WG * pilot::prefetch_wave_elems<pilot::CfgS32x16>(RT) * 4 +
                          (size_t)pilot::WAVES_PER_WG * pilot::HANDOVER_BUF * sizeof(int);
     return fixed + (size_t)4 * pilot::WAVES_PER_WG * (2 * KP + 4) * 4 <= LDS_BYTES;
 }
@@ -640,11 +639,9 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     const char *dbg = getenv("PILOT_OT_DEBUG");
     const int debug = dbg ? atoi(dbg) : 0;
     const size_t form = pilot::form_elems_rt(cfg, RT);
-    // the wave-private prefetch slots of the f32-class kernels (rows of the next one or two work items)
-    // (+ the per-wave hand-over buffers of the fast kernels)
-    const size_t pf_bytes = (f64 ? 0 : (size_t)pilot::WAVES_PER_WG * pilot::prefetch_wave_elems<pilot::CfgF32x16>(RT) * sizeof(float)) +
-                            (size_t)pilot::WAVES_PER_WG * pilot::HANDOVER_BUF * sizeof(int);
-    size_t fixed = (size_t)(sym ? 1 : 2) * form * ts + (size_t)KP * ts + pf_bytes;   // operand image(s) + first-product table + prefetch slots
+    // the per-wave hand-over buffers of the fast kernels
+    const size_t hb_bytes = (size_t)pilot::WAVES_PER_WG * pilot::HANDOVER_BUF * sizeof(int);
+    size_t fixed = (size_t)(sym ? 1 : 2) * form * ts + (size_t)KP * ts + hb_bytes;   // operand image(s) + first-product table + hand-over buffers
     // K mod 16 in 1..4: the (at most four) cell types of the last row-tile are computed on the VALU (tail_rows)
     int tv = 0;
     // split: skip the dead registers of the last tile (beyond 4 row-tiles those variants run out of registers and spill
@@ -771,7 +768,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     size_t fixed_t = fixed;
     if (half) {     // tracking pass of the fp16-split configuration: the bf16-split kernel on its own operand block
         p.img = static_cast<float *>(img) + pilot::track_img_elems(cfg, RT);
-        fixed_t = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * ts + (size_t)KP * ts + pf_bytes;
+        fixed_t = (size_t)(sym ? 1 : 2) * pilot::form_elems_rt(pilot::CFG_S32, RT) * ts + (size_t)KP * ts + hb_bytes;
     }
     if (track_all) { p.list = pl->order_list; p.list_len = nullptr; }     // EVERY pair goes through the tracking kernel (longest first)
     if (mixed) {
@@ -779,7 +776,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         // for the f64 pass
         p.bands = 2;
         p.fb_list = pl->track_list; p.fb_count = pl->track_count + 8;
-        fixed_t = (size_t)(sym ? 1 : 2) * form * ts * 2 + (size_t)KP * ts + pf_bytes;
+        fixed_t = (size_t)(sym ? 1 : 2) * form * ts * 2 + (size_t)KP * ts + hb_bytes;
     }
     {
         // (the tracking kernel's result need not match the fast kernels' bits: a pair is always solved by one of them)

@@ -1039,16 +1039,6 @@ template <class C, int RT, bool TRACK> constexpr bool parked_flush() { return C:
 
 constexpr int HANDOVER_BUF = 32, HANDOVER_FLUSH = 16;      // per-wave hand-over buffer of the fast kernels (ints), flush level
 constexpr int GREG_MAX = 64;
-// Row prefetch (f32-class configurations): the proportion rows (and the stop threshold) of the next one or two work items of a
-// wave are requested while the current update runs and parked in a wave-private LDS slot, so a refill reads LDS instead of
-// waiting for L2 in front of the update (see the refill of the stream kernel).  Elements of T per slot: A row, B row, threshold.
-#ifndef PILOT_PREFETCH
-#define PILOT_PREFETCH 0      // (tried in round 4: 16 more VGPRs, c3 0.629 -> 0.658 ms kernel on the same box -- profiles/r04/ab_experiments.md)
-#endif
-template <class C> __host__ __device__ constexpr bool prefetch_rows() { return PILOT_PREFETCH && sizeof(typename C::T) == 4; }
-template <class C> __host__ __device__ constexpr int prefetch_depth(int RT) { return !prefetch_rows<C>() ? 0 : (2 * RT * 4 <= 32 ? 2 : 1); }
-template <class C> __host__ __device__ constexpr int prefetch_slot_elems(int RT) { return 2 * RT * C::TILE + 4; }
-template <class C> __host__ __device__ constexpr int prefetch_wave_elems(int RT) { return prefetch_depth<C>(RT) * prefetch_slot_elems<C>(RT); }
 #ifndef PILOT_AREG_MAX_RT
 #define PILOT_AREG_MAX_RT 4
 #endif
@@ -1157,18 +1147,12 @@ sinkhorn_stream_kernel(GridParams p) {
     // (fp16-split configuration: the packed pieces of U, [part][k-block] x 16 bytes per lane)
     constexpr int PARK_LANE = park_lane_elems<C>(RT);
     T *park = lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (threadIdx.x / WAVE) * (PARK_LANE * WAVE) + (threadIdx.x % WAVE) * 4;
-    // (PF) rows of the wave's next PF_D work items, behind the park area: see the refill
-    constexpr bool PF = prefetch_rows<C>();
-    constexpr int PF_D = prefetch_depth<C>(RT), PF_SLOT = prefetch_slot_elems<C>(RT);
-    constexpr int PF_ROW_LANES = KP / 4, PF_ITEM_LANES = 2 * PF_ROW_LANES;        // 16-byte pieces of one row / of one item's two rows
-    T *pf = lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (PARK ? WAVES_PER_WG * PARK_LANE * WAVE : 0) +
-            (threadIdx.x / WAVE) * (PF_D * PF_SLOT);
     // hand-over buffer (fast kernels): pairs in which POT would tau-absorb wait here, HANDOVER_BUF to a wave, and go to the
     // tracking list HANDOVER_FLUSH or more at a time.  One atomic on track_count per hand-over was 11 ns of one L2 atomic
     // unit per pair -- at K = 2, where a third of the 360 000 pairs absorb, 1.2 of the fast launch's 1.27 ms
     // (profiles/r04/small_k_scaling.txt).
-    int *hb = reinterpret_cast<int *>(lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (PARK ? WAVES_PER_WG * PARK_LANE * WAVE : 0) +
-                                      WAVES_PER_WG * (PF_D * PF_SLOT)) + (threadIdx.x / WAVE) * HANDOVER_BUF;
+    int *hb = reinterpret_cast<int *>(lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (PARK ? WAVES_PER_WG * PARK_LANE * WAVE : 0)) +
+              (threadIdx.x / WAVE) * HANDOVER_BUF;
     int hb_cnt = 0;
     auto hb_flush = [&]() {
         int base = 0;
@@ -1307,29 +1291,10 @@ sinkhorn_stream_kernel(GridParams p) {
     const int wave_id = block * WAVES_PER_WG + (int)(threadIdx.x / WAVE);
     const int n_tile_waves = ((int)gridDim.x - (solo_in_stream<C, RT, SYM, TRACK, TV>() ? p.solo_blocks : 0)) * WAVES_PER_WG;
     const int queue_start = (solo_in_stream<C, RT, SYM, TRACK, TV>() && p.solo_len && p.solo_blocks > 0) ? *p.solo_len : 0;
-    // row prefetch: items [res_next, pf_ready) have their rows in LDS; loads for [pf_lo, pf_pend_end) are in flight (pf_tmp)
-    int pf_ready = 0, pf_lo = 0, pf_pend_end = 0;
-    bool pf_pending = false;
-    typename C::vec4_t pf_tmp = {};
-    T pf_thr_tmp = T(0);
     bool want = true;  // column asks for a (new) pair
     const bool hand_all_over = C::HALF && p.unequal && *p.unequal != 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
-        if constexpr (PF) {
-            // the rows requested during the last update have arrived (or are waited for here, one update later): park them
-            if (pf_pending) {                                   // wave-uniform
-                const int k = lane / PF_ITEM_LANES, pc = lane % PF_ITEM_LANES;
-                const int it = pf_lo + k;
-                if (k < PF_D && it < pf_pend_end) {
-                    T *slot = pf + (it & (PF_D - 1)) * PF_SLOT;
-                    *reinterpret_cast<typename C::vec4_t *>(slot + pc * 4) = pf_tmp;        // [A row][B row]: piece pc of 2 KP / 4
-                    if (pc == 0) slot[2 * KP] = pf_thr_tmp;
-                }
-                pf_ready = pf_pend_end;
-                pf_pending = false;
-            }
-        }
         const unsigned long long wmask = __ballot(want) & colmask;
         if (wmask) {
             if (res_next >= res_end && !exhausted) {
@@ -1388,23 +1353,13 @@ sinkhorn_stream_kernel(GridParams p) {
                 active = true;
                 q = qsel;
                 const int i = isel, j = jsel;
-                // rows from the wave's prefetch slot when they are there (LDS), from L2 otherwise (the first items of a batch,
-                // three or more columns refilled by one update)
-                const bool parked = PF && item < pf_ready;
-                if (parked) {       // (two address spaces: two copies of the loads, no flat addressing)
-                    const T *sa = pf + (item & (PF_D - 1)) * PF_SLOT + grp * NREG;
+                const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
 #pragma unroll
-                    for (int t = 0; t < RT; ++t) { load_regs<C>(sa + t * NGRP * NREG, A[t]); load_regs<C>(sa + KP + t * NGRP * NREG, B[t]); }
-                    thr = sa[2 * KP - grp * NREG] * IN_SCALE;
-                } else {
-                    const T *pa = Pt + (size_t)i * KP + grp * NREG, *pb = Pt + (size_t)j * KP + grp * NREG;
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        load_regs<C>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
-                        load_regs<C>(pb + t * NGRP * NREG, B[t]);
-                    }
-                    thr = Pt[(size_t)N * KP + j] * IN_SCALE;      // stop threshold of column patient j (prep: f32 floor folded in)
+                for (int t = 0; t < RT; ++t) {
+                    load_regs<C>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
+                    load_regs<C>(pb + t * NGRP * NREG, B[t]);
                 }
+                thr = Pt[(size_t)N * KP + j] * IN_SCALE;      // stop threshold of column patient j (prep: f32 floor folded in)
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     load_regs<C>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
@@ -1446,27 +1401,6 @@ sinkhorn_stream_kernel(GridParams p) {
             }
         }
         if (__ballot(active || want) == 0ull) break;
-        if constexpr (PF) {
-            // request the rows of the next PF_D items of this wave's batch that are not parked yet: lane -> (item, piece)
-            if (!pf_pending) {                                  // wave-uniform
-                if (pf_ready < res_next) pf_ready = res_next;   // (items handed out without their slot)
-                int hi = res_next + PF_D;
-                if (hi > res_end) hi = res_end;
-                if (pf_ready < hi) {
-                    const int k = lane / PF_ITEM_LANES, pc = lane % PF_ITEM_LANES;
-                    const int it = pf_ready + k;
-                    const bool on = k < PF_D && it < hi;
-                    const int bsel = 4 * ((it - res_base) & (TILE - 1));
-                    const int ii_ = __builtin_amdgcn_ds_bpermute(bsel, ibatch), jj_ = __builtin_amdgcn_ds_bpermute(bsel, jbatch);
-                    if (on) {
-                        const int pat = pc < PF_ROW_LANES ? ii_ : jj_;
-                        pf_tmp = *reinterpret_cast<const typename C::vec4_t *>(Pt + (size_t)pat * KP + (pc % PF_ROW_LANES) * 4);
-                        if (pc == 0) pf_thr_tmp = Pt[(size_t)N * KP + jj_];
-                    }
-                    pf_lo = pf_ready; pf_pend_end = hi; pf_pending = true;
-                }
-            }
-        }
 
         T mx = T(0);
         if constexpr (C::HALF) {
