@@ -128,6 +128,12 @@ __device__ inline double wave_sum_f64(double x) {
 
 // lane `lane` of `old` <- the wave-uniform `value` (v_writelane_b32: one instruction instead of compare + select; gfx950
 // reads at most one SGPR per VALU instruction, so the lane select travels in M0)
+#ifndef EMD_BITSET
+#define EMD_BITSET 1
+#endif
+#ifndef EMD_SELECT            // 1: the relaxation writes its label with selects instead of a branch around two moves
+#define EMD_SELECT 1
+#endif
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"       // M0 is reserved (never live across statements); the clobber is declared anyway
 __device__ inline int wl_i32(int old, int value, int lane) {
@@ -135,6 +141,16 @@ __device__ inline int wl_i32(int old, int value, int lane) {
     return old;
 }
 #pragma clang diagnostic pop
+// m with bit `bit` cleared, in ONE scalar instruction (m &= m - 1 is s_add_u32 + s_addc_u32 + s_and_b64; the scalar unit is as
+// busy as the vector unit in the exact-OT kernel, profiles/r04/rocprofv3_pmc_summary_emd_c3.txt)
+__device__ inline unsigned long long clear_bit(unsigned long long m, int bit) {
+#if EMD_BITSET
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
+    return m;
+#else
+    return m & (m - 1ull);
+#endif
+}
 __device__ inline unsigned int hi_word(double x) {
     union { double d; unsigned int u[2]; } v;
     v.d = x;
@@ -160,6 +176,18 @@ __device__ inline bool bits_less(double a, double b) {
 // at most two workgroups per CU -- with 8 waves each that is 4 waves per SIMD, too few to hide the latencies of this
 // kernel; 2 x 16 waves of <= 64 registers run c4 in 0.47 s instead of 0.55 s (ab_experiments.md)
 __host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? 16 : 8; }
+// Row pitch of the LDS copy of M (doubles).  K <= 64: 64, one lane per column of a padded row -- the relaxation of a row reads
+// its 64 entries without a bounds test (the pad columns' labels are closed for good) and addresses it by a shift: two scalar
+// instructions and a branch less per relaxed row in a kernel whose scalar unit is as busy as its vector unit.
+#ifndef EMD_PITCH64
+#define EMD_PITCH64 1
+#endif
+__host__ __device__ constexpr int emd_m_pitch(int K) { return (EMD_PITCH64 && K <= 64) ? 64 : K; }
+// dynamic LDS of emd_grid_kernel: M (K <= 128), the row minima, and for K <= 64 the two K x K byte tables of the source order
+__host__ __device__ constexpr size_t emd_lds_bytes(int K) {
+    return K > 128 ? sizeof(double) * (size_t)K
+                   : sizeof(double) * ((size_t)K * emd_m_pitch(K) + K) + (K <= 64 ? 2 * (size_t)K * K : 0);
+}
 #ifndef EMD_LAZY
 #define EMD_LAZY 1
 #endif
@@ -174,6 +202,18 @@ __host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? 16 : 8; }
 #ifndef EMD_ZERO_PER_PAIR      // 1: round 3's form, the whole K x K flow slab zeroed per pair (A/B switch)
 #define EMD_ZERO_PER_PAIR 0
 #endif
+// EMD_PROF = n (diagnostic builds, tools/emd_prof_builds.sh): n_aug reports the wave's clock64() ticks / 16 spent in section n
+// of a pair: 1 whole pair, 2 label set-up of a search, 3 arg-min, 4 ties + targets (augmentations included), 5 augmentations
+// alone, 6 row reach + relaxations, 7 final cost, 8 pair set-up, 9 potentials
+#ifdef EMD_PROF
+#define PROF_BEGIN(n) if constexpr (EMD_PROF == (n)) { prof_t0 = clock64(); }
+#define PROF_END(n) if constexpr (EMD_PROF == (n)) { prof_acc += clock64() - prof_t0; }
+#else
+#define PROF_BEGIN(n) do {} while (0)
+#define PROF_END(n) do {} while (0)
+#endif
+// EMD_PERTURB = eps (robustness experiment): every reduced cost below 1e-13 -- the tight arcs -- is replaced by eps, i.e. the
+// labels that tie at a step's minimum no longer do; the LP values must not move (ab_experiments.md r04)
 // dynamic pair queue: EMD_NQ counters, EMD_Q_STRIDE ints apart (one 128-byte line each)
 constexpr int EMD_NQ = 64, EMD_Q_STRIDE = 32;
 #if EMD_WPE
@@ -190,15 +230,20 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     double *Msh = reinterpret_cast<double *>(smem_raw);   // K*K (not with MG)
-    double *rowmin = MG ? Msh : Msh + (size_t)K * K;      // K: min_j M_ij (initial row potentials)
+    constexpr bool PAD = NK == 1 && !MG && EMD_PITCH64;   // rows of M padded to 64 entries (zeros)
+    const int MP = PAD ? 64 : K;                          // row pitch of Mrd
+    double *rowmin = MG ? Msh : Msh + (size_t)K * MP;     // K: min_j M_ij (initial row potentials)
     if constexpr (!MG) {
-        for (int t = threadIdx.x; t < K * K; t += blockDim.x) Msh[t] = p.M[t];
+        for (int t = threadIdx.x; t < K * MP; t += blockDim.x) {
+            const int i = t / MP, j = t % MP;
+            Msh[t] = j < K ? p.M[(size_t)i * K + j] : 0.0;
+        }
         __syncthreads();
     }
     const double *Mrd = MG ? p.M : Msh;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         double m = __builtin_inf();
-        for (int j = 0; j < K; ++j) { const double v = Mrd[(size_t)i * K + j]; m = v < m ? v : m; }
+        for (int j = 0; j < K; ++j) { const double v = Mrd[(size_t)i * MP + j]; m = v < m ? v : m; }
         rowmin[i] = m;
     }
     __syncthreads();
@@ -215,10 +260,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
     if constexpr (ORD) {
         for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
             const int i = t / K, j = t % K;
-            const double c = Msh[(size_t)i * K + j] - rowmin[i];
+            const double c = Msh[(size_t)i * MP + j] - rowmin[i];
             int rank = 0;
             for (int i2 = 0; i2 < K; ++i2) {
-                const double c2 = Msh[(size_t)i2 * K + j] - rowmin[i2];
+                const double c2 = Msh[(size_t)i2 * MP + j] - rowmin[i2];
                 rank += (c2 < c || (c2 == c && i2 < i)) ? 1 : 0;
             }
             ord[j * K + rank] = (unsigned char)i;
@@ -287,6 +332,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
         }
         const long q = (long)r * N + j_s;
         const int i_s = p.row_begin + r * p.row_step;
+#ifdef EMD_PROF
+        long long prof_t0 = 0, prof_acc = 0;
+#endif
+        PROF_BEGIN(1); PROF_BEGIN(8);
 
         double pu[NK], pv[NK], ra[NK], rb[NK], dC[NK];
         int parR[NK], parC[NK];
@@ -318,13 +367,14 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             pu[e] = idx < K ? rowmin[idx] : 0.0;   // pu_i = min_j M_ij keeps every reduced cost >= 0 at the start
 #pragma unroll
             for (int w = 0; w < NK; ++w) ship[e][w] = 0ull;
-            if (idx < K && Mrd[(size_t)idx * K + idx] - pu[e] == 0.0) {
+            if (idx < K && Mrd[(size_t)idx * MP + idx] - pu[e] == 0.0) {
                 const double f = ra[e] < rb[e] ? ra[e] : rb[e];
                 if (f > 0.0) { F[(size_t)idx * K + idx] = f; ship[e][e] = 1ull << lane; ra[e] -= f; rb[e] -= f; }
             }
         }
         EMD_FENCE();
         __builtin_amdgcn_wave_barrier();
+        PROF_END(8);
         int n_aug = 0, n_search = 0;
 #ifdef EMD_STAT     // diagnostic builds: 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows in A rebuilds, 5 searches
         int n_stat = 0;
@@ -362,6 +412,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #endif
             // initial column labels min over sources i of rc(i, j) = (A_j - pv_j)+ with A_j = min_i (M_ij - pu_i): a source's
             // potential never moves (its distance is 0), so A and its arg-min only change when a source runs dry
+            PROF_BEGIN(2);
             bool src_changed = false;
 #pragma unroll
             for (int e = 0; e < NK; ++e) { src_changed = src_changed || srcmask[e] != prev_src[e]; prev_src[e] = srcmask[e]; }
@@ -383,7 +434,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         }
                         if (lane < K) {
                             Apar[0] = ord[lane * K + best];
-                            A[0] = Msh[(size_t)Apar[0] * K + lane] - rowmin[Apar[0]];
+                            A[0] = Msh[(size_t)Apar[0] * MP + lane] - rowmin[Apar[0]];
                         }
                     }
                 }
@@ -398,14 +449,14 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         ++n_stat;
 #endif
                         const int l = __builtin_ctzll(m);
-                        m &= m - 1ull;
+                        m = clear_bit(m, l);
                         const int in = l + 64 * e;
                         const double pu_i = rl_f64(pu[e], l);
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
                             const int idx = lane + 64 * e2;
                             if (idx < K) {
-                                const double v = Mrd[(size_t)in * K + idx] - pu_i;
+                                const double v = Mrd[(size_t)in * MP + idx] - pu_i;
                                 if (v < A[e2]) { A[e2] = v; Apar[e2] = in; }
                             }
                         }
@@ -423,11 +474,17 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             for (int e = 0; e < NK; ++e) {
                 const bool valid = lane + 64 * e < K;
                 const bool src = ra[e] > tol && valid;
+#ifdef EMD_PERTURB
+                double rc = __builtin_fmax(A[e] - pv[e], 0.0);
+                if (rc < 1e-13) rc = EMD_PERTURB;
+#else
                 const double rc = __builtin_fmax(A[e] - pv[e], 0.0);        // (one v_max_f64; rc is never NaN)
+#endif
                 dC[e] = valid ? rc + 0.0 : NEG; fC[e] = INF; parC[e] = Apar[e];   // (+ 0.0: never -0, whose pattern would sort last)
                 fR[e] = src ? 0.0 : INF; parR[e] = -1;
                 demand[e] = __ballot(rb[e] > 0.0);                          // (rb is 0 beyond K)
             }
+            PROF_END(2);
             double dstar = 0.0, last_bd = 0.0;
             bool exhausted = false, stale = false;
             for (int step = 0;; ++step) {
@@ -437,16 +494,19 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #endif
                 // smallest open label; ALL columns that carry it are final and are scanned in this one step (after the
                 // first augmentations most arcs around the sources are tight, so dozens of nodes tie at the same label)
+                PROF_BEGIN(3);
                 double best = dC[0];
 #pragma unroll
                 for (int e = 1; e < NK; ++e) best = bits_less(dC[e], best) ? dC[e] : best;
                 const double bd = uni_f64(wave_min_f64(best));
+                PROF_END(3);
                 if (hi_word(bd) >= 0x7ff00000u) {   // +inf or NEG: nothing (more) reachable
                     if (LAZY && stale) dstar = last_bd;     // ... from a tree that is out of date: search again
                     else exhausted = true;                  // ... at all: only rounding dust is left
                     break;
                 }
                 if constexpr (LAZY) last_bd = bd;
+                PROF_BEGIN(4);
                 unsigned long long tieC[NK], tieR[NK];
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
@@ -468,6 +528,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     while (dm) {                                   // wave-uniform
                         const int target = __builtin_ctzll(dm) + 64 * et;
                         dm &= dm - 1ull;
+                        PROF_BEGIN(5);
                         // walk target <- ... <- source row once with wave-uniform indices; hop h is recorded in lane h (h % 64, slot
                         // h / 64; v_writelane): forward arc (hi -> hj) gains flow, backward arc (hi -> hb) loses it (hb < 0 at the
                         // source row).  The forward arcs enter the support right here (the bottleneck is positive: support arcs carry
@@ -598,13 +659,16 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         }
                         ++n_aug;
                         demand[et] = __ballot(rb[et] > 0.0);
+                        PROF_END(5);
                         // a dry root, or a target that keeps demand (its path gave out first): the tree is out of date below them
                         if (__ballot(dry) || ((demand[et] >> (target % 64)) & 1ull)) stale = true;
                         if (!LAZY && stale) { broke = true; break; }        // restart at once: every path found is usable
                     }
                 }
+                PROF_END(4);
                 if (tripped) break;
                 if (broke) { dstar = bd; break; }
+                PROF_BEGIN(6);
                 // columns: backward arcs to the rows that ship to ANY of the tied columns (reduced cost 0): the ballot
                 // mask of the tied columns IS a column bit mask, so one AND with the row's support finds them
 #pragma unroll
@@ -633,22 +697,32 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         ++n_stat;
 #endif
                         const int l = __builtin_ctzll(m);
-                        m &= m - 1ull;
+                        m = clear_bit(m, l);
                         const int in = l + 64 * e;
                         const double pu_i = rl_f64(pu[e], l);
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
                             const int idx = lane + 64 * e2;
-                            if (idx < K) {                                   // (guards the read of M only: dC is NEG beyond K)
-                                double rc = Mrd[(size_t)in * K + idx] - pu_i - pv[e2];
+                            if (PAD || idx < K) {                            // (guards the read of M only: dC is NEG beyond K)
+                                double rc = Mrd[(size_t)in * MP + idx] - pu_i - pv[e2];
                                 rc = __builtin_fmax(rc, 0.0);
+#ifdef EMD_PERTURB
+                                if (rc < 1e-13) rc = EMD_PERTURB;
+#endif
                                 const double nd = bd + rc;
+#if EMD_SELECT
+                                const bool lt = nd < dC[e2];                         // never true for a scanned column (NEG)
+                                dC[e2] = lt ? nd : dC[e2];
+                                parC[e2] = lt ? in : parC[e2];
+#else
                                 if (nd < dC[e2]) { dC[e2] = nd; parC[e2] = in; }     // never true for a scanned column (NEG)
+#endif
                             }
                         }
                     }
                 }
                 }
+                PROF_END(6);
             }
             if (tripped) break;
             if (exhausted) {    // numerically exhausted: drop the dust (<= tol-scale mass) of every remaining source
@@ -656,6 +730,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 for (int e = 0; e < NK; ++e) ra[e] = 0.0;
                 break;
             }
+            PROF_BEGIN(9);
             // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the tree (so on every path used)
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
@@ -663,11 +738,13 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 pv[e] += __builtin_fmin(fC[e], dstar);
             }
             ++n_search;
+            PROF_END(9);
 #if defined(EMD_STAT) && EMD_STAT == 5
             ++n_stat;
 #endif
         }
         // cost = sum over the support of F_ij * M_ij (lane i walks the bits of row i)
+        PROF_BEGIN(7);
         double cost = 0.0;
 #pragma unroll
         for (int e = 0; e < NK; ++e) {
@@ -678,7 +755,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 while (m) {
                     const int j = __builtin_ctzll(m) + 64 * w;
                     m &= m - 1ull;
-                    cost += F[(size_t)idx * K + j] * Mrd[(size_t)idx * K + j];
+                    cost += F[(size_t)idx * K + j] * Mrd[(size_t)idx * MP + j];
 #if !EMD_ZERO_PER_PAIR
                     F[(size_t)idx * K + j] = 0.0;           // the slab goes back to all zeros for the wave's next pair
 #endif
@@ -686,12 +763,15 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             }
         }
         cost = uni_f64(wave_sum_f64(cost));
+        PROF_END(7); PROF_END(1);
         if (tripped) {          // (never seen; a guard that tripped mid-augmentation may leave entries outside the masks)
             for (int t = lane; t < K * K; t += 64) F[t] = 0.0;
         }
         if (lane == 0) {
             p.emd[q] = tripped ? __builtin_nan("") : cost;
-#ifdef EMD_STAT
+#if defined(EMD_PROF)
+            if (p.n_aug) p.n_aug[q] = (int)(prof_acc >> 4);
+#elif defined(EMD_STAT)
             if (p.n_aug) p.n_aug[q] = n_stat;
 #else
             if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;

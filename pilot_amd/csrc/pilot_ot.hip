@@ -207,7 +207,7 @@ constexpr size_t LDS_BYTES = 160 * 1024;
 static int emd_nk(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : (K <= 192 ? 3 : 4)); }
 static int emd_wgs_per_cu(int K) {
     if (K > 128) return 1;                      // cost matrix in global memory, 3-4 rows per lane: one workgroup per CU
-    const size_t lds = sizeof(double) * ((size_t)K * K + K) + (K <= 64 ? 2 * (size_t)K * K : 0);     // (+ the per-column source order and its inverse, K <= 64)
+    const size_t lds = pilot::emd_lds_bytes(K);     // (M, row minima; K <= 64: + the per-column source order and its inverse)
     int by_lds = (int)(LDS_BYTES / lds);
     const int by_regs = K <= 64 ? 4 : 2;        // <= 64 VGPRs per lane: 4 x 8 or 2 x 16 waves = 8 per SIMD
     if (by_lds > by_regs) by_lds = by_regs;
@@ -1248,7 +1248,7 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         hipLaunchKernelGGL(pilot::emd_generic_kernel, dim3((unsigned)wgs), dim3(pilot::EMDG_WG), lds, s, p, rowmin);
     } else {
         if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
-        const size_t lds = K > 128 ? sizeof(double) * (size_t)K : sizeof(double) * ((size_t)K * K + K) + (K <= 64 ? 2 * (size_t)K * K : 0);
+        const size_t lds = pilot::emd_lds_bytes(K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
         const int waves = pilot::emd_waves(emd_nk(K));
         long wgs = (total + waves - 1) / waves;
