@@ -131,6 +131,19 @@ __device__ inline double wave_sum_f64(double x) {
 #ifndef EMD_BITSET
 #define EMD_BITSET 1
 #endif
+// UL (template parameter; EMD_ULAB = 0 / 1 forces it off / on for A/B builds, default: by K, see emd_ul()): a column's label is
+// kept PLUS its potential, L_j = d_j + pv_j = min over the scanned rows i of M_ij + (d_i - pu_i): relaxing a row is one add and one
+// compare per column (was: two subtracts, a clamp, an add, a compare), and the label itself, max(L_j - pv_j, 0), is formed once
+// per step for the arg-min.  The scanned columns are a wave-uniform bit mask (lane = column), so closing a column costs no
+// vector instruction and the final labels are read off L once per search.  It pays when a step relaxes rows over many
+// columns: K = 50 -2.4 %, K = 100 -9 %; the 14 clusters of the kidney cohort +4.5 % (profiles/r04/ab_experiments.md)
+__host__ __device__ constexpr bool emd_ul(int K) {
+#ifdef EMD_ULAB
+    return EMD_ULAB != 0;
+#else
+    return K > 32;
+#endif
+}
 #ifndef EMD_SELECT            // 1: the relaxation writes its label with selects instead of a branch around two moves
 #define EMD_SELECT 1
 #endif
@@ -186,7 +199,7 @@ __host__ __device__ constexpr int emd_m_pitch(int K) { return (EMD_PITCH64 && K 
 // dynamic LDS of emd_grid_kernel: M (K <= 128), the row minima, and for K <= 64 the two K x K byte tables of the source order
 __host__ __device__ constexpr size_t emd_lds_bytes(int K) {
     return K > 128 ? sizeof(double) * (size_t)K
-                   : sizeof(double) * ((size_t)K * emd_m_pitch(K) + K) + (K <= 64 ? 2 * (size_t)K * K : 0);
+                   : sizeof(double) * ((size_t)K * emd_m_pitch(K) + K) + (K <= 64 ? (size_t)K * K + (size_t)K * emd_m_pitch(K) : 0);
 }
 #ifndef EMD_LAZY
 #define EMD_LAZY 1
@@ -223,7 +236,7 @@ constexpr int EMD_NQ = 64, EMD_Q_STRIDE = 32;
 #endif
 
 // MG: the cost matrix is read from global memory (L2) instead of LDS -- K > 128, where K*K doubles no longer fit LDS
-template <int NK, bool MG = false>
+template <int NK, bool MG = false, bool UL = true>
 __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
     constexpr int EMD_WAVES = emd_waves(NK);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -267,7 +280,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 rank += (c2 < c || (c2 == c && i2 < i)) ? 1 : 0;
             }
             ord[j * K + rank] = (unsigned char)i;
-            rnk[i * K + j] = (unsigned char)rank;
+            rnk[i * MP + j] = (unsigned char)rank;
         }
         __syncthreads();
     }
@@ -428,8 +441,8 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                             ++n_stat;
 #endif
                             const int i = __builtin_ctzll(m);
-                            m &= m - 1ull;
-                            const unsigned int r = rl[i * K];
+                            m = clear_bit(m, i);
+                            const unsigned int r = rl[i * MP];
                             best = r < best ? r : best;
                         }
                         if (lane < K) {
@@ -469,6 +482,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             // pending: a row is reached only over a zero-reduced-cost backward arc from a column being scanned, takes that
             // column's label and is scanned in the same step; fR is its final distance (0 for the sources, +inf: not reached).
             double fR[NK], fC[NK];
+            unsigned long long closedm[NK];         // UL: columns scanned in this search, and the lanes beyond K
             unsigned long long demand[NK];
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
@@ -480,7 +494,9 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #else
                 const double rc = __builtin_fmax(A[e] - pv[e], 0.0);        // (one v_max_f64; rc is never NaN)
 #endif
-                dC[e] = valid ? rc + 0.0 : NEG; fC[e] = INF; parC[e] = Apar[e];   // (+ 0.0: never -0, whose pattern would sort last)
+                if constexpr (UL) { dC[e] = A[e]; closedm[e] = ~__ballot(valid); }
+                else { dC[e] = valid ? rc + 0.0 : NEG; closedm[e] = 0ull; }   // (+ 0.0: never -0, whose pattern would sort last)
+                fC[e] = INF; parC[e] = Apar[e];
                 fR[e] = src ? 0.0 : INF; parR[e] = -1;
                 demand[e] = __ballot(rb[e] > 0.0);                          // (rb is 0 beyond K)
             }
@@ -495,9 +511,21 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 // smallest open label; ALL columns that carry it are final and are scanned in this one step (after the
                 // first augmentations most arcs around the sources are tight, so dozens of nodes tie at the same label)
                 PROF_BEGIN(3);
-                double best = dC[0];
+                double cur[NK];
 #pragma unroll
-                for (int e = 1; e < NK; ++e) best = bits_less(dC[e], best) ? dC[e] : best;
+                for (int e = 0; e < NK; ++e) {
+                    if constexpr (UL) {
+                        union { double d; unsigned int u[2]; } c;
+                        c.d = __builtin_fmax(dC[e] - pv[e], 0.0);       // (a label that rounds a hair below zero is zero)
+                        c.u[1] = ((closedm[e] >> lane) & 1ull) ? 0x7ff00000u : c.u[1];     // closed: never the minimum (>= +inf)
+                        cur[e] = c.d;
+                    } else {
+                        cur[e] = dC[e];
+                    }
+                }
+                double best = cur[0];
+#pragma unroll
+                for (int e = 1; e < NK; ++e) best = bits_less(cur[e], best) ? cur[e] : best;
                 const double bd = uni_f64(wave_min_f64(best));
                 PROF_END(3);
                 if (hi_word(bd) >= 0x7ff00000u) {   // +inf or NEG: nothing (more) reachable
@@ -510,9 +538,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 unsigned long long tieC[NK], tieR[NK];
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
-                    const bool tc = dC[e] == bd;
+                    const bool tc = cur[e] == bd;
                     tieC[e] = __ballot(tc);
-                    if (tc) { fC[e] = bd; dC[e] = NEG; }
+                    if constexpr (UL) closedm[e] |= tieC[e];
+                    else if (tc) { fC[e] = bd; dC[e] = NEG; }
                 }
                 // Tied columns with demand left are targets: augment along the tree path right away, WITHOUT touching the
                 // potentials, and let the search go on with the target as one more scanned column.  The labels are exact
@@ -539,11 +568,19 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         int n_hops = 0, src_row = -1;
                         for (int j = target;;) {
                             if (n_hops >= 64 * NK || j < 0) { tripped = true; trip_code = 2; break; }
-                            int i = 0;
+                            int i = 0, jb = 0;
+                            if constexpr (NK == 1) {        // (0 <= j < K <= 64 and n_hops < 64 here: no slot selects -- scalar work)
+                                i = rl_i32(parC[0], j);
+                                if (i < 0) { tripped = true; trip_code = 3; break; }
+                                jb = rl_i32(parR[0], i);
+                                hi[0] = wl_i32(hi[0], i, n_hops);
+                                hj[0] = wl_i32(hj[0], j, n_hops);
+                                hb[0] = wl_i32(hb[0], jb, n_hops);
+                                ship[0][0] |= lane == i ? 1ull << j : 0ull;
+                            } else {
 #pragma unroll
                             for (int e = 0; e < NK; ++e) if (e == j / 64) i = rl_i32(parC[e], j % 64);
                             if (i < 0) { tripped = true; trip_code = 3; break; }
-                            int jb = 0;
 #pragma unroll
                             for (int e = 0; e < NK; ++e) if (e == i / 64) jb = rl_i32(parR[e], i % 64);
 #pragma unroll
@@ -559,6 +596,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #pragma unroll
                                     for (int w = 0; w < NK; ++w) if (w == j / 64) ship[e][w] |= 1ull << (j % 64);
                                 }
+                            }
                             ++n_hops;
 #if defined(EMD_STAT) && EMD_STAT == 3
                             ++n_stat;
@@ -689,6 +727,9 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 // pv_j, clamp, add and compare per step: 7.27 -> 7.48 ms at c3, the two extra live values cost more than the
                 // fp64 operations they save at 64 registers per lane)
                 {
+                double tR[NK];                                               // UL: d_i - pu_i of the rows reached in this step (d_i = bd)
+#pragma unroll
+                for (int e = 0; e < NK; ++e) tR[e] = bd - pu[e];
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = tieR[e];
@@ -699,23 +740,30 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         const int l = __builtin_ctzll(m);
                         m = clear_bit(m, l);
                         const int in = l + 64 * e;
-                        const double pu_i = rl_f64(pu[e], l);
+                        const double t_i = rl_f64(UL ? tR[e] : pu[e], l);    // (!UL: pu_i)
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
                             const int idx = lane + 64 * e2;
                             if (PAD || idx < K) {                            // (guards the read of M only: dC is NEG beyond K)
-                                double rc = Mrd[(size_t)in * MP + idx] - pu_i - pv[e2];
-                                rc = __builtin_fmax(rc, 0.0);
+                                double nd;
+                                bool lt;
+                                if constexpr (UL) {
+                                    nd = Mrd[(size_t)in * MP + idx] + t_i;
+                                    lt = nd < dC[e2] && !((closedm[e2] >> lane) & 1ull);
+                                } else {
+                                    double rc = Mrd[(size_t)in * MP + idx] - t_i - pv[e2];
+                                    rc = __builtin_fmax(rc, 0.0);
 #ifdef EMD_PERTURB
-                                if (rc < 1e-13) rc = EMD_PERTURB;
+                                    if (rc < 1e-13) rc = EMD_PERTURB;
 #endif
-                                const double nd = bd + rc;
+                                    nd = bd + rc;
+                                    lt = nd < dC[e2];                                // never true for a scanned column (NEG)
+                                }
 #if EMD_SELECT
-                                const bool lt = nd < dC[e2];                         // never true for a scanned column (NEG)
                                 dC[e2] = lt ? nd : dC[e2];
                                 parC[e2] = lt ? in : parC[e2];
 #else
-                                if (nd < dC[e2]) { dC[e2] = nd; parC[e2] = in; }     // never true for a scanned column (NEG)
+                                if (lt) { dC[e2] = nd; parC[e2] = in; }
 #endif
                             }
                         }
@@ -735,6 +783,8 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
                 pu[e] -= __builtin_fmin(fR[e], dstar);          // (not reached: +inf)
+                if constexpr (UL)    // (the label a column was scanned with: L and pv have not moved since)
+                    fC[e] = ((closedm[e] >> lane) & 1ull) && lane + 64 * e < K ? __builtin_fmax(dC[e] - pv[e], 0.0) : INF;
                 pv[e] += __builtin_fmin(fC[e], dstar);
             }
             ++n_search;

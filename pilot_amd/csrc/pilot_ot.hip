@@ -1254,16 +1254,17 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         long wgs = (total + waves - 1) / waves;
         const long cap = (long)pl->n_cu * emd_wgs_per_cu(K);
         if (wgs > cap) wgs = cap;
+        constexpr bool UL = pilot::emd_ul(128);      // (labels without the column potential: always beyond 64 cell types)
         if (K > 192) {
-            hipLaunchKernelGGL((pilot::emd_grid_kernel<4, true>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
+            hipLaunchKernelGGL((pilot::emd_grid_kernel<4, true, UL>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else if (K > 128) {
-            hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
+            hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true, UL>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else if (K <= 64) {
-            auto kern = pilot::emd_grid_kernel<1>;
+            auto kern = pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true> : pilot::emd_grid_kernel<1, false, false>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else {
-            auto kern = pilot::emd_grid_kernel<2>;
+            auto kern = pilot::emd_grid_kernel<2, false, UL>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         }
