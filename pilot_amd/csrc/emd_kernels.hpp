@@ -37,6 +37,9 @@ struct EmdParams {
     int *queue;         // dynamic pair queue (zeroed before the launch)
 };
 
+// the lanes where `b` holds, as a wave-uniform mask (HIP's __ballot takes an int: the bool is first materialised as 0 / 1 in a
+// register and compared again -- two vector instructions per call in a kernel that ballots three times per Dijkstra step)
+__device__ inline unsigned long long ballot_b(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ inline double rl_f64(double x, int lane) {
     union { double d; int i[2]; } u, r;
     u.d = x;
@@ -109,9 +112,9 @@ __device__ inline double wave_min_f64(double x) {
     union { double d; unsigned int u[2]; } v, o;
     v.d = x;
     const unsigned int mh = wave_min_u32(v.u[1]);
-    const unsigned long long top = __ballot(v.u[1] == mh);
+    const unsigned long long top = ballot_b(v.u[1] == mh);
     unsigned int ml = (unsigned int)__builtin_amdgcn_readlane((int)v.u[0], __builtin_ctzll(top));
-    if (__ballot(v.u[1] == mh && v.u[0] != ml)) ml = wave_min_u32(v.u[1] == mh ? v.u[0] : 0xffffffffu);   // wave-uniform
+    if (ballot_b(v.u[1] == mh && v.u[0] != ml)) ml = wave_min_u32(v.u[1] == mh ? v.u[0] : 0xffffffffu);   // wave-uniform
     o.u[0] = ml; o.u[1] = mh;
     return o.d;
 }
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             bool any_src = false;
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
-                srcmask[e] = __ballot(lane + 64 * e < K && ra[e] > tol);
+                srcmask[e] = ballot_b(ra[e] > tol);                 // (ra is 0 beyond K)
                 any_src = any_src || srcmask[e] != 0ull;
             }
             if (!any_src) break;
@@ -432,7 +435,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             if constexpr (ORD) {
                 if (src_changed) {
                     const unsigned long long sm = srcmask[0];
-                    if (__ballot(lane < K && (Apar[0] < 0 || !((sm >> Apar[0]) & 1ull)))) {     // some column lost its source
+                    if (ballot_b(lane < K && (Apar[0] < 0 || !((sm >> Apar[0]) & 1ull)))) {     // some column lost its source
                         unsigned int best = 0xffu;
                         const unsigned char *rl = rnk + (lane < K ? lane : 0);
                         unsigned long long m = sm;
@@ -481,24 +484,26 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             // the relaxation need no "scanned" flag; fC keeps the final distance (+inf: never scanned).  Rows are never
             // pending: a row is reached only over a zero-reduced-cost backward arc from a column being scanned, takes that
             // column's label and is scanned in the same step; fR is its final distance (0 for the sources, +inf: not reached).
-            double fR[NK], fC[NK];
+            // (rows: reachedm = the rows reached so far, a wave-uniform mask -- lane = row --, sources included; puN = the potential a
+            // reached row takes when the search ends, pu_i - d_i, formed when the row is reached)
+            double puN[NK], fC[NK];
+            unsigned long long reachedm[NK];
             unsigned long long closedm[NK];         // UL: columns scanned in this search, and the lanes beyond K
             unsigned long long demand[NK];
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
                 const bool valid = lane + 64 * e < K;
-                const bool src = ra[e] > tol && valid;
 #ifdef EMD_PERTURB
                 double rc = __builtin_fmax(A[e] - pv[e], 0.0);
                 if (rc < 1e-13) rc = EMD_PERTURB;
 #else
                 const double rc = __builtin_fmax(A[e] - pv[e], 0.0);        // (one v_max_f64; rc is never NaN)
 #endif
-                if constexpr (UL) { dC[e] = A[e]; closedm[e] = ~__ballot(valid); }
+                if constexpr (UL) { dC[e] = A[e]; closedm[e] = ~ballot_b(valid); }
                 else { dC[e] = valid ? rc + 0.0 : NEG; closedm[e] = 0ull; }   // (+ 0.0: never -0, whose pattern would sort last)
                 fC[e] = INF; parC[e] = Apar[e];
-                fR[e] = src ? 0.0 : INF; parR[e] = -1;
-                demand[e] = __ballot(rb[e] > 0.0);                          // (rb is 0 beyond K)
+                puN[e] = pu[e]; reachedm[e] = srcmask[e]; parR[e] = -1;
+                demand[e] = ballot_b(rb[e] > 0.0);                          // (rb is 0 beyond K)
             }
             PROF_END(2);
             double dstar = 0.0, last_bd = 0.0;
@@ -517,7 +522,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     if constexpr (UL) {
                         union { double d; unsigned int u[2]; } c;
                         c.d = __builtin_fmax(dC[e] - pv[e], 0.0);       // (a label that rounds a hair below zero is zero)
-                        c.u[1] = ((closedm[e] >> lane) & 1ull) ? 0x7ff00000u : c.u[1];     // closed: never the minimum (>= +inf)
+                        c.u[1] = __builtin_amdgcn_inverse_ballot_w64(closedm[e]) ? 0x7ff00000u : c.u[1];   // closed: never the minimum (>= +inf)
                         cur[e] = c.d;
                     } else {
                         cur[e] = dC[e];
@@ -539,7 +544,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     const bool tc = cur[e] == bd;
-                    tieC[e] = __ballot(tc);
+                    tieC[e] = ballot_b(tc);
                     if constexpr (UL) closedm[e] |= tieC[e];
                     else if (tc) { fC[e] = bd; dC[e] = NEG; }
                 }
@@ -638,7 +643,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #pragma unroll
                             for (int e = 0; e < NK; ++e) {
                                 const bool act = lane + 64 * e < n_hops;
-                                unsigned long long z = __ballot(act && F[(size_t)hi[e] * K + hj[e]] == 0.0);
+                                unsigned long long z = ballot_b(act && F[(size_t)hi[e] * K + hj[e]] == 0.0);
                                 while (z) {
                                     const int h = __builtin_ctzll(z);
                                     z &= z - 1ull;
@@ -667,7 +672,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                                     F[(size_t)hi[e] * K + hj[e]] += delta;
                                     if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
                                 }
-                                emptied[e] = __ballot(act && hb[e] >= 0 && fb[e] == delta);
+                                emptied[e] = ballot_b(act && hb[e] >= 0 && fb[e] == delta);
                                 if (emptied[e]) stale = true;          // a tree arc is gone
                             }
                             // backward arcs that ran empty leave the support
@@ -696,10 +701,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                             if (lane + 64 * e == target) rb[e] -= delta;
                         }
                         ++n_aug;
-                        demand[et] = __ballot(rb[et] > 0.0);
+                        demand[et] = ballot_b(rb[et] > 0.0);
                         PROF_END(5);
                         // a dry root, or a target that keeps demand (its path gave out first): the tree is out of date below them
-                        if (__ballot(dry) || ((demand[et] >> (target % 64)) & 1ull)) stale = true;
+                        if (ballot_b(dry) || ((demand[et] >> (target % 64)) & 1ull)) stale = true;
                         if (!LAZY && stale) { broke = true; break; }        // restart at once: every path found is usable
                     }
                 }
@@ -709,6 +714,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 PROF_BEGIN(6);
                 // columns: backward arcs to the rows that ship to ANY of the tied columns (reduced cost 0): the ballot
                 // mask of the tied columns IS a column bit mask, so one AND with the row's support finds them
+                double pb[NK];                                               // pu_i - d_i of the rows reached in this step (d_i = bd)
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long hit = 0ull;
@@ -718,18 +724,19 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         const unsigned long long h = ship[e][w] & tieC[w];
                         if (h) { hit = h; wsel = w; }
                     }
-                    const bool reach = hit != 0ull && fR[e] == INF;
-                    tieR[e] = __ballot(reach);
-                    if (reach) { parR[e] = __builtin_ctzll(hit) + 64 * wsel; fR[e] = bd; }
+                    tieR[e] = ballot_b(hit != 0ull) & ~reachedm[e];
+                    reachedm[e] |= tieR[e];
+                    pb[e] = pu[e] - bd;
+                    if (__builtin_amdgcn_inverse_ballot_w64(tieR[e])) { parR[e] = __builtin_ctzll(hit) + 64 * wsel; puN[e] = pb[e]; }
                 }
                 // those rows: forward arcs to every open column
                 // (tried: rows tied in one step sharing the per-column tail -- min_i (M_ij - pu_i) first, then one subtract of
                 // pv_j, clamp, add and compare per step: 7.27 -> 7.48 ms at c3, the two extra live values cost more than the
                 // fp64 operations they save at 64 registers per lane)
                 {
-                double tR[NK];                                               // UL: d_i - pu_i of the rows reached in this step (d_i = bd)
+                bool open[NK];                                               // UL: the lane's column is not scanned yet
 #pragma unroll
-                for (int e = 0; e < NK; ++e) tR[e] = bd - pu[e];
+                for (int e = 0; e < NK; ++e) open[e] = !__builtin_amdgcn_inverse_ballot_w64(closedm[e]);
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = tieR[e];
@@ -740,7 +747,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         const int l = __builtin_ctzll(m);
                         m = clear_bit(m, l);
                         const int in = l + 64 * e;
-                        const double t_i = rl_f64(UL ? tR[e] : pu[e], l);    // (!UL: pu_i)
+                        const double t_i = rl_f64(UL ? pb[e] : pu[e], l);    // (UL: pu_i - d_i; !UL: pu_i)
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
                             const int idx = lane + 64 * e2;
@@ -748,8 +755,8 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                                 double nd;
                                 bool lt;
                                 if constexpr (UL) {
-                                    nd = Mrd[(size_t)in * MP + idx] + t_i;
-                                    lt = nd < dC[e2] && !((closedm[e2] >> lane) & 1ull);
+                                    nd = Mrd[(size_t)in * MP + idx] - t_i;
+                                    lt = (nd < dC[e2]) & open[e2];
                                 } else {
                                     double rc = Mrd[(size_t)in * MP + idx] - t_i - pv[e2];
                                     rc = __builtin_fmax(rc, 0.0);
@@ -782,9 +789,9 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             // potentials: rc'(i,j) = rc(i,j) + min(d_i, d*) - min(d_j, d*) >= 0, and 0 on the tree (so on every path used)
 #pragma unroll
             for (int e = 0; e < NK; ++e) {
-                pu[e] -= __builtin_fmin(fR[e], dstar);          // (not reached: +inf)
+                pu[e] = __builtin_amdgcn_inverse_ballot_w64(reachedm[e]) ? puN[e] : pu[e] - dstar;     // (reached: d_i <= d*)
                 if constexpr (UL)    // (the label a column was scanned with: L and pv have not moved since)
-                    fC[e] = ((closedm[e] >> lane) & 1ull) && lane + 64 * e < K ? __builtin_fmax(dC[e] - pv[e], 0.0) : INF;
+                    fC[e] = __builtin_amdgcn_inverse_ballot_w64(closedm[e]) && lane + 64 * e < K ? __builtin_fmax(dC[e] - pv[e], 0.0) : INF;
                 pv[e] += __builtin_fmin(fC[e], dstar);
             }
             ++n_search;
