@@ -479,13 +479,14 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     }
                 }
             }
-            // Labels.  Columns: dC is the tentative distance while the column is open and NEG (-1) once it is scanned (or
+            // Labels.  Columns, !UL: dC is the tentative distance while the column is open and NEG (-1) once it is scanned (or
             // beyond K) -- as bit patterns NEG sorts above every distance and above +inf, so the arg-min, the tie test and
-            // the relaxation need no "scanned" flag; fC keeps the final distance (+inf: never scanned).  Rows are never
-            // pending: a row is reached only over a zero-reduced-cost backward arc from a column being scanned, takes that
-            // column's label and is scanned in the same step; fR is its final distance (0 for the sources, +inf: not reached).
-            // (rows: reachedm = the rows reached so far, a wave-uniform mask -- lane = row --, sources included; puN = the potential a
-            // reached row takes when the search ends, pu_i - d_i, formed when the row is reached)
+            // the relaxation need no "scanned" flag; fC keeps the final distance (+inf: never scanned).  UL: dC is distance +
+            // column potential and closedm the scanned columns (see emd_ul above).  Rows are never pending: a row is reached
+            // only over a zero-reduced-cost backward arc from a column being scanned, takes that column's label d_i and is
+            // scanned in the same step.  reachedm = the rows reached so far (sources included), a wave-uniform mask (lane =
+            // row); puN = the potential a reached row takes when the search ends, pu_i - d_i, formed when the row is reached
+            // (the labels never exceed d*, the label the search ends at).
             double puN[NK], fC[NK];
             unsigned long long reachedm[NK];
             unsigned long long closedm[NK];         // UL: columns scanned in this search, and the lanes beyond K
