@@ -134,6 +134,13 @@ __device__ inline double wave_sum_f64(double x) {
 #ifndef EMD_BITSET
 #define EMD_BITSET 1
 #endif
+// BF (NK >= 3, or 1 with padded rows): the loops over a row of M -- the relaxation, the rebuild of the source minima -- read
+// without a bounds test (a lane beyond K reads column K - 1; its label is closed for good, its minimum never used) and write
+// through selects.  K = 160: 333 -> 246 ms per 600 x 600 grid.  Not for NK = 2: at its 64 registers the two clamped column
+// indices cost more spills than the branches they remove (K = 100: 36.1 -> 41.6 ms), ab_experiments.md r04.
+#ifndef EMD_BF_MIN_NK
+#define EMD_BF_MIN_NK 3
+#endif
 // UL (template parameter; EMD_ULAB = 0 / 1 forces it off / on for A/B builds, default: by K, see emd_ul()): a column's label is
 // kept PLUS its potential, L_j = d_j + pv_j = min over the scanned rows i of M_ij + (d_i - pu_i): relaxing a row is one add and one
 // compare per column (was: two subtracts, a clamp, an add, a compare), and the label itself, max(L_j - pv_j, 0), is formed once
@@ -288,6 +295,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
         __syncthreads();
     }
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
+    constexpr bool BF = NK >= EMD_BF_MIN_NK;
+    int mcol[NK];                                                             // BF: the lane's columns, clamped into the matrix
+#pragma unroll
+    for (int e = 0; e < NK; ++e) mcol[e] = PAD || lane + 64 * e < K ? lane + 64 * e : K - 1;
     const double INF = __builtin_inf(), NEG = -1.0;
     // LAZY: keep a search going after an augmentation dried its root / emptied an arc / left its target open, and restart
     // only when a later path turns out to be unusable.  At K = 50 the searches drop from 41 to 22 per pair but the steps do
@@ -470,10 +481,17 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         const double pu_i = rl_f64(pu[e], l);
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
-                            const int idx = lane + 64 * e2;
-                            if (idx < K) {
-                                const double v = Mrd[(size_t)in * MP + idx] - pu_i;
-                                if (v < A[e2]) { A[e2] = v; Apar[e2] = in; }
+                            if constexpr (BF) {
+                                const double v = Mrd[(size_t)in * MP + mcol[e2]] - pu_i;
+                                const bool lt = __builtin_amdgcn_inverse_ballot_w64(ballot_b(v < A[e2]));
+                                A[e2] = lt ? v : A[e2];
+                                Apar[e2] = lt ? in : Apar[e2];
+                            } else {
+                                const int idx = lane + 64 * e2;
+                                if (idx < K) {
+                                    const double v = Mrd[(size_t)in * MP + idx] - pu_i;
+                                    if (v < A[e2]) { A[e2] = v; Apar[e2] = in; }
+                                }
                             }
                         }
                     }
@@ -735,9 +753,6 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 // pv_j, clamp, add and compare per step: 7.27 -> 7.48 ms at c3, the two extra live values cost more than the
                 // fp64 operations they save at 64 registers per lane)
                 {
-                bool open[NK];                                               // UL: the lane's column is not scanned yet
-#pragma unroll
-                for (int e = 0; e < NK; ++e) open[e] = !__builtin_amdgcn_inverse_ballot_w64(closedm[e]);
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
                     unsigned long long m = tieR[e];
@@ -751,13 +766,15 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         const double t_i = rl_f64(UL ? pb[e] : pu[e], l);    // (UL: pu_i - d_i; !UL: pu_i)
 #pragma unroll
                         for (int e2 = 0; e2 < NK; ++e2) {
-                            const int idx = lane + 64 * e2;
-                            if (PAD || idx < K) {                            // (guards the read of M only: dC is NEG beyond K)
+                            // (PAD / BF: no bounds test -- a lane beyond K reads a pad column / column K - 1, its own label is closed for good)
+                            if (PAD || BF || lane + 64 * e2 < K) {
+                                const int idx = BF ? mcol[e2] : lane + 64 * e2;
                                 double nd;
                                 bool lt;
                                 if constexpr (UL) {
                                     nd = Mrd[(size_t)in * MP + idx] - t_i;
-                                    lt = (nd < dC[e2]) & open[e2];
+                                    // (through the masks: the compiler otherwise turns `open` into a branch around the read)
+                                    lt = __builtin_amdgcn_inverse_ballot_w64(ballot_b(nd < dC[e2]) & ~closedm[e2]);
                                 } else {
                                     double rc = Mrd[(size_t)in * MP + idx] - t_i - pv[e2];
                                     rc = __builtin_fmax(rc, 0.0);
