@@ -198,7 +198,13 @@ __device__ inline bool bits_less(double a, double b) {
 // waves per workgroup: 8 (two per SIMD) in general; 16 for 64 < K <= 128, where the LDS copy of M (up to 128 KB) allows
 // at most two workgroups per CU -- with 8 waves each that is 4 waves per SIMD, too few to hide the latencies of this
 // kernel; 2 x 16 waves of <= 64 registers run c4 in 0.47 s instead of 0.55 s (ab_experiments.md)
-__host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? 16 : 8; }
+#ifndef EMD_NK2_WAVES          // A/B: waves per workgroup and per SIMD of the 64 < K <= 128 variant
+#define EMD_NK2_WAVES 16
+#endif
+#ifndef EMD_NK2_WPE
+#define EMD_NK2_WPE 8
+#endif
+__host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? EMD_NK2_WAVES : 8; }
 // Row pitch of the LDS copy of M (doubles).  K <= 64: 64, one lane per column of a padded row -- the relaxation of a row reads
 // its 64 entries without a bounds test (the pad columns' labels are closed for good) and addresses it by a shift: two scalar
 // instructions and a branch less per relaxed row in a kernel whose scalar unit is as busy as its vector unit.
@@ -240,7 +246,7 @@ __host__ __device__ constexpr size_t emd_lds_bytes(int K) {
 // dynamic pair queue: EMD_NQ counters, EMD_Q_STRIDE ints apart (one 128-byte line each)
 constexpr int EMD_NQ = 64, EMD_Q_STRIDE = 32;
 #if EMD_WPE
-#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK <= 2 ? 8 : 2, 8)))
+#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK == 1 ? 8 : (NK == 2 ? EMD_NK2_WPE : 2), 8)))
 #else
 #define EMD_WPE_ATTR
 #endif
