@@ -39,7 +39,10 @@ struct EmdParams {
 
 // the lanes where `b` holds, as a wave-uniform mask (HIP's __ballot takes an int: the bool is first materialised as 0 / 1 in a
 // register and compared again -- two vector instructions per call in a kernel that ballots three times per Dijkstra step)
+#ifndef PILOT_BALLOT_B_DEFINED
+#define PILOT_BALLOT_B_DEFINED
 __device__ inline unsigned long long ballot_b(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+#endif
 __device__ inline double rl_f64(double x, int lane) {
     union { double d; int i[2]; } u, r;
     u.d = x;

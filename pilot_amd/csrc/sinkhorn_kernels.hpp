@@ -187,6 +187,21 @@ __device__ inline double sum_xor16(double x) {
     a.u[0] = lo[0]; a.u[1] = hi[0]; b.u[0] = lo[1]; b.u[1] = hi[1];
     return a.d + b.d;
 }
+// the lanes where `b` holds (HIP's __ballot(int) materialises the bool as 0 / 1 in a register and compares it again: two
+// vector instructions per call; PILOT_BALLOT_INT=1 is that form, for A/B)
+#ifndef PILOT_BALLOT_INT
+#define PILOT_BALLOT_INT 0
+#endif
+#ifndef PILOT_BALLOT_B_DEFINED
+#define PILOT_BALLOT_B_DEFINED
+__device__ inline unsigned long long ballot_b(bool b) {
+#if PILOT_BALLOT_INT
+    return __ballot(b);
+#else
+    return __builtin_amdgcn_ballot_w64(b);
+#endif
+}
+#endif
 template <class C> __device__ inline typename C::T group_sum(typename C::T x) {
     // sum over the lane groups that hold the same column (lane % TILE); every lane of the column gets the total
     x = sum_xor32(x);
@@ -195,7 +210,7 @@ template <class C> __device__ inline typename C::T group_sum(typename C::T x) {
 }
 // "does any lane of my column satisfy pred": one ballot + scalar folds, no cross-lane data movement
 template <class C> __device__ inline unsigned long long column_any_mask(bool pred) {
-    const unsigned long long m = __ballot(pred);
+    const unsigned long long m = ballot_b(pred);
     unsigned long long f = m | (m >> 32);
     if constexpr (C::NGRP == 4) f |= f >> 16;
     return f & ((1ull << C::TILE) - 1ull);
@@ -818,7 +833,7 @@ __device__ inline void solo_pairs(const GridParams &p, unsigned char *solo_smem,
             r1 = live ? r1 : T(1);
             u = a * C::rcp(r1);
             if constexpr (TRACK) {
-                if (__ballot(live && (u * ru > tau || v * rv > tau))) {     // POT: absorb, u = v = 1/K (see the stream kernel)
+                if (ballot_b(live && (u * ru > tau || v * rv > tau))) {     // POT: absorb, u = v = 1/K (see the stream kernel)
                     ru = live ? C::rcp(u * T(K)) : T(0);
                     rv = live ? T(K) * C::rcp(v) : T(0);
                     abs_at = ii;
@@ -826,11 +841,11 @@ __device__ inline void solo_pairs(const GridParams &p, unsigned char *solo_smem,
                     {   // empty bins / scalings out of the exact range: see the stream kernel
                         constexpr T BIG = sizeof(T) == 4 ? T(1.2676506e30) : T(8.452712498170644e270);
                         constexpr T SMALL = T(1) / BIG;
-                        if (__ballot(live && !(u >= SMALL && u < BIG && v >= SMALL && v < BIG))) u = T(__builtin_nanf(""));
+                        if (ballot_b(live && !(u >= SMALL && u < BIG && v >= SMALL && v < BIG))) u = T(__builtin_nanf(""));
                     }
                 }
             } else {
-                if (__ballot(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
+                if (ballot_b(live && (u > tau || v > tau))) {      // POT would absorb: the tracking kernel redoes the pair
                     if (lane == 0) p.track_list[__hip_atomic_fetch_add(p.track_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = q;
                     break;
                 }
@@ -1295,7 +1310,7 @@ sinkhorn_stream_kernel(GridParams p) {
     const bool hand_all_over = C::HALF && p.unequal && *p.unequal != 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
-        const unsigned long long wmask = __ballot(want) & colmask;
+        const unsigned long long wmask = ballot_b(want) & colmask;
         if (wmask) {
             if (res_next >= res_end && !exhausted) {
                 // A wave's FIRST batch is the one of its own number (behind the exact duplicates the solo waves take), the later
@@ -1389,7 +1404,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 // two fp16 pieces hold 22 bits (fuzz: 1.1e-5 / 2.4e-5 off at 40 capped updates).  The prep kernel flags such
                 // a P, and this pass only forwards its pairs to the tracking kernel, which iterates f32 values.
                 if (hand_all_over) {                                     // (wave-uniform)
-                    const unsigned long long tm = __ballot(take) & colmask;
+                    const unsigned long long tm = ballot_b(take) & colmask;
                     if (tm) {
                         int base = 0;
                         if (lane == 0) base = __hip_atomic_fetch_add(p.track_count, (int)__popcll(tm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1400,7 +1415,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 }
             }
         }
-        if (__ballot(active || want) == 0ull) break;
+        if (ballot_b(active || want) == 0ull) break;
 
         T mx = T(0);
         if constexpr (C::HALF) {
@@ -1554,7 +1569,7 @@ sinkhorn_stream_kernel(GridParams p) {
         constexpr bool E2_EARLY = C::SPLIT && !TRACK && PILOT_E2_EARLY;
         T e2_early = T(0);
         if constexpr (E2_EARLY) e2_early = lane_e2(T(1));
-        if (__ballot(pending || capped)) {
+        if (ballot_b(pending || capped)) {
             T sc = T(1);
             if constexpr (TRACK) sc = (abs_at == ii - 1) ? T(1) / kk : T(1);  // u, v were just reset to 1/K each
             T e2 = E2_EARLY ? e2_early : lane_e2(sc);
@@ -1567,7 +1582,7 @@ sinkhorn_stream_kernel(GridParams p) {
                 else if (e != e) { fin = true; flags |= FLAG_NAN; }   // POT: "Numerical errors at iteration"
             }
             // ---- retire finished pairs: (u, v) go to the wave's ring, the slot asks for the next pair ----
-            unsigned long long fmask = __ballot(fin) & colmask;
+            unsigned long long fmask = ballot_b(fin) & colmask;
             if (fmask) {
                 T scale = T(1);
                 if constexpr (TRACK) {
@@ -1649,7 +1664,7 @@ sinkhorn_stream_kernel(GridParams p) {
                             meta[1] = flags;
                         }
                     }
-                    const unsigned long long taken = __ballot(put) & colmask;
+                    const unsigned long long taken = ballot_b(put) & colmask;
                     fmask &= ~taken;
                     ring_cnt = __builtin_amdgcn_readfirstlane(ring_cnt + (int)__popcll(taken));
                     if constexpr (!PARK) {
@@ -1865,11 +1880,11 @@ constexpr int CTRL_INTS = 16, CTRL_UNEQUAL = 12;
 // wave-aggregated LDS counter: lanes with equal `b` share one atomic; returns the lane's slot (base + rank among equals)
 __device__ inline int lds_count_aggregated(int *counters, int b, bool valid) {
     int slot = 0;
-    unsigned long long todo = __ballot(valid);
+    unsigned long long todo = ballot_b(valid);
     while (todo) {
         const int leader = __builtin_ctzll(todo);
         const int b0 = __builtin_amdgcn_readlane(b, leader);
-        const unsigned long long same = __ballot(valid && b == b0);
+        const unsigned long long same = ballot_b(valid && b == b0);
         const int lane = threadIdx.x % WAVE;
         int base = 0;
         if (lane == leader) base = atomicAdd(&counters[b0], (int)__popcll(same));
