@@ -29,7 +29,8 @@ python tools/small_k_probe.py 2 3 4 5 6 7 8 12 > $O/small_k_probe.txt 2>&1
 python tools/real_cohort_probe.py > $O/real_cohort_kidney_igan_g.txt 2>&1
 python tools/big_k_probe.py > $O/big_k_probe.txt 2>&1
 python tools/mid_reg_probe.py > $O/mid_reg_probe.txt 2>&1
-for p in 2 4 12 real 50; do python tools/emd_point.py $p; done > $O/emd_points.txt 2>&1
+for p in 2 4 12 real 30 50 64 100 160 256; do python tools/emd_point.py $p; done > $O/emd_points.txt 2>&1
+python tools/emd_point.py 100 2000 >> $O/emd_points.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
@@ -55,6 +56,10 @@ BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k
 cp $O/pmc_k80/summary.txt $O/rocprofv3_pmc_summary_k80.txt
 BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k96 96 > /dev/null 2>&1
 cp $O/pmc_k96/summary.txt $O/rocprofv3_pmc_summary_k96.txt
+bash tools/profile_pmc_scalar.sh gpurun_out/report_$TAG/pmc_emd_sca --mode emd > /dev/null 2>&1
+cp $O/pmc_emd_sca/summary.txt $O/rocprofv3_pmc_scalar_emd_c3.txt
+rm -rf $O/pmc_emd_sca
+bash tools/emd_prof_builds.sh c3 > $O/emd_prof_c3.txt 2>&1
 python tools/make_traffic_json.py $O > $O/traffic.json
 # the other rungs of the precision ladder: kernel-trace average + the PMC passes, merged into traffic.json
 for prec in fp32 bf16x3 fp64; do
