@@ -37,10 +37,11 @@ def test_emd_modes_and_symmetry():
         engine.emd_grid(P, M, row_begin=1, mode="mirror")
 
 
-@pytest.mark.parametrize("K", [1, 2, 17, 64, 65, 100, 128, 129, 192, 193, 256])
+@pytest.mark.parametrize("K", [1, 2, 17, 32, 33, 64, 65, 100, 128, 129, 192, 193, 256])
 def test_emd_every_k_regime(K):
-    """K <= 64: one row/column per lane; K > 64: two (flow support masks of 2 x 64 bits per row, lazy restarts); K > 128:
-    three / four, cost matrix read from global memory."""
+    """K <= 64: one row/column per lane (labels with the column potential up to K = 32, without it beyond: emd_ul); K > 64:
+    two (flow support masks of 2 x 64 bits per row); K > 128: three / four, cost matrix read from global memory, lazy
+    restarts, row loops without bounds tests."""
     P, M = make_problem(12, K, 6, seed=200 + K, cells_per_patient=500)
     if K == 1:
         M = np.zeros((1, 1))
