@@ -22,6 +22,18 @@ def test_emd_parity(cfg, step):
     assert (info["n_aug"] >= 0).all() and info["n_aug"].max() > 0      # >= 0: the warm start already solves a == b
 
 
+@pytest.mark.parametrize("cfg,step", [("c3", 1), ("c4", 16)])
+def test_emd_full_size_grid_against_the_network_simplex(cfg, step):
+    """BASELINE.json's full sizes, EVERY pair of c3 (360 000; a sixteenth of c4's rows): the kernel's successive shortest
+    paths against the oracle's network simplex -- a different algorithm, so an LP value that is off shows (the LP optimum
+    is unique); and the properties that do not need an oracle: a symmetric matrix with a zero diagonal."""
+    P, M = make_problem(**CONFIGS[cfg])
+    Eg = engine.emd_grid(P, M)
+    Eo = O.emd_grid(P, M, row_step=step, n_threads=16, fast="ns")
+    assert np.abs(Eg[::step] - Eo).max() <= 1e-12
+    assert np.array_equal(Eg, Eg.T) and np.abs(np.diag(Eg)).max() == 0.0
+
+
 def test_emd_modes_and_symmetry():
     P, M = make_problem(**CONFIGS["c2"])
     full = engine.emd_grid(P, M)                                   # auto -> mirror
