@@ -29,6 +29,8 @@ python tools/small_k_probe.py 2 3 4 5 6 7 8 12 > $O/small_k_probe.txt 2>&1
 python tools/real_cohort_probe.py > $O/real_cohort_kidney_igan_g.txt 2>&1
 python tools/big_k_probe.py > $O/big_k_probe.txt 2>&1
 python tools/mid_reg_probe.py > $O/mid_reg_probe.txt 2>&1
+python tools/sinkhorn_full_grid_check.py 2>&1 | grep -v "^make" > $O/sinkhorn_full_grid_check.txt
+python tools/emd_full_grid_check.py c2 c3 c4 2>&1 | grep -v "^make" > $O/emd_full_grid_check.txt
 for p in 2 4 12 real 30 50 64 100 160 256; do python tools/emd_point.py $p; done > $O/emd_points.txt 2>&1
 python tools/emd_point.py 100 2000 >> $O/emd_points.txt 2>&1
 export TMPDIR=/tmp
