@@ -14,7 +14,8 @@ for spec in (sys.argv[1:] or ["c3:1.0", "c3:0.1", "c3:0.01", "c4:0.1:16"]):
     t = time.perf_counter()
     Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=16, return_info=True)
     dt = time.perf_counter() - t
-    last = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+    last_o, last_g = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0, (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
+    last = last_o | last_g
     d = np.abs(Eg - Eo)
     capped = io["iters"] >= 1000
     print("%s N=%d K=%d reg %g: %d pairs (oracle %.1f s on the host): max|gpu - oracle| %.3e (mean %.1e) outside the %d pairs POT returns "
@@ -22,3 +23,10 @@ for spec in (sys.argv[1:] or ["c3:1.0", "c3:0.1", "c3:0.01", "c4:0.1:16"]):
           % (cfg, N, K, reg, Eo.size, dt, d[~last].max(), d[~last].mean(), last.sum(), capped.sum(),
              ((io["flags"] & O.FLAG_ABSORBED) > 0).sum(), ig["iters"].mean(), io["iters"].mean(), bool(np.all(ig["iters"] <= io["iters"])),
              ((ig["flags"] & _lib.FLAG_F64) > 0).sum()), flush=True)
+    if last.any():
+        both = last_o & last_g
+        same = ig["iters"] == io["iters"]
+        print("   ... of those %d pairs: flagged on both sides %d (max|gpu - oracle| there %.3e), by the oracle alone %d, by the GPU alone %d; "
+              "one-sided flags among pairs with the same update count on both sides: %d"
+              % (last.sum(), both.sum(), np.abs(Eg - Eo)[both].max() if both.any() else 0.0, (last_o & ~last_g).sum(), (last_g & ~last_o).sum(),
+                 ((last_o ^ last_g) & same).sum()), flush=True)
