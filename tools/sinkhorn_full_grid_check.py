@@ -1,4 +1,4 @@
-"""Every ordered pair of a full Sinkhorn grid against the fp64 oracle (default precision): usage sinkhorn_full_grid_check.py [config:reg[:row_step] ...]"""
+"""Every ordered pair of a full Sinkhorn grid against the fp64 oracle (default precision): usage sinkhorn_full_grid_check.py [config|NxK:reg[:row_step] ...]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -8,7 +8,11 @@ from pilot_amd.synthetic import CONFIGS, make_problem
 for spec in (sys.argv[1:] or ["c3:1.0", "c3:0.1", "c3:0.01", "c4:0.1:16"]):
     f = spec.split(":")
     cfg, reg, step = f[0], float(f[1]), int(f[2]) if len(f) > 2 else 1
-    P, M = make_problem(**CONFIGS[cfg])
+    if "x" in cfg:          # "NxK": the cohorts of tools/k_sweep.py (8 PCA dims, 200 cells per patient)
+        n_, k_ = (int(t) for t in cfg.split("x"))
+        P, M = make_problem(n_, k_, 8, seed=k_, cells_per_patient=200)
+    else:
+        P, M = make_problem(**CONFIGS[cfg])
     N, K = P.shape
     Eg, ig = engine.sinkhorn_grid(P, M, reg, row_step=step, return_info=True)
     t = time.perf_counter()
@@ -30,3 +34,8 @@ for spec in (sys.argv[1:] or ["c3:1.0", "c3:0.1", "c3:0.01", "c4:0.1:16"]):
               "one-sided flags among pairs with the same update count on both sides: %d"
               % (last.sum(), both.sum(), np.abs(Eg - Eo)[both].max() if both.any() else 0.0, (last_o & ~last_g).sum(), (last_g & ~last_o).sum(),
                  ((last_o ^ last_g) & same).sum()), flush=True)
+    later = ig["iters"] > io["iters"]
+    if later.any():
+        absorbed = (io["flags"] & O.FLAG_ABSORBED) > 0
+        print("   ... %d pairs stop at a LATER check than the oracle (%d of them tau-absorbing pairs on the tracking kernel; the latest by %d updates); "
+              "max|gpu - oracle| among them %.3e" % (later.sum(), (later & absorbed).sum(), (ig["iters"] - io["iters"])[later].max(), d[later & ~last].max()), flush=True)
