@@ -1,4 +1,4 @@
-"""Every pair of a full exact-OT grid against the CPU network simplex (and a sample against the SSP oracle): usage emd_full_grid_check.py [config ...]"""
+"""Every pair of a full exact-OT grid against the CPU network simplex (and a sample against the SSP oracle): usage emd_full_grid_check.py [config|NxK ...]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -6,7 +6,11 @@ from oracle import oracle as O
 from pilot_amd import engine
 from pilot_amd.synthetic import CONFIGS, make_problem
 for cfg in (sys.argv[1:] or ["c2", "c3"]):
-    P, M = make_problem(**CONFIGS[cfg])
+    if "x" in cfg:          # "NxK": the cohorts of tools/k_sweep.py (8 PCA dims, 200 cells per patient)
+        n_, k_ = (int(t) for t in cfg.split("x"))
+        P, M = make_problem(n_, k_, 8, seed=k_, cells_per_patient=200)
+    else:
+        P, M = make_problem(**CONFIGS[cfg])
     N, K = P.shape
     step = 1 if N <= 600 else 16
     Eg = engine.emd_grid(P, M)
