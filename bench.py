@@ -20,7 +20,9 @@ sample), `exact_emd` (the reference's DEFAULT mode on the same cohort) and `c4` 
 
 `roofline` is for the dominant kernel (the MFMA pair-grid kernel): achieved = algorithmic flop of one launch / its mean
 duration (HIP events on the launch stream, recorded inside the timed region).  `cpu_baseline` is the CPU oracle (C fp64
-restatement of POT's loop) timed on this box's host cores on a bounded sample of the same workload (rank 0, 1 GPU).
+restatement of POT's loop) timed on this box's host cores on a bounded sample of the same workload (rank 0, 1 GPU);
+its all-cores leg covers the whole grid when that takes seconds (c3 does), and `parity` is then max|step output - oracle|
+over EVERY pair the step produced.
 """
 from __future__ import annotations
 
@@ -314,6 +316,9 @@ def main():
             cb, cb_eq, cb_all, upd = cpu_baseline(P, M, args.reg, args.cpu_seconds, E, iters)
             out["cpu_baseline"], out["cpu_baseline_equal_updates"], out["cpu_baseline_all_cores"] = cb, cb_eq, cb_all
             out["equal_work_note"] = upd
+            out["parity"] = {"pairs": cb_all["pairs"], "whole_grid": cb_all["whole_grid"], "max_abs_diff_vs_fp64_oracle": cb_all["max_abs_diff_vs_gpu"],
+                             "tolerance": 1e-5, "what": "the step's output against the fp64 oracle (POT's stopping rule) on the pairs of "
+                                                       "cpu_baseline_all_cores; the oracle is the checker here, never the thing timed as `value`"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if single_process_multi:
@@ -686,13 +691,19 @@ def cpu_baseline(P, M, reg, budget_s, E_gpu, iters_gpu):
           "sample": "the same %d pairs, one thread, stopThr floored at 8 f32 ulps of ||b||_2 like the f32 kernels (NOT POT's rule: "
                     "an equal-work comparison only); max|gpu - this| = %.2e" % (Ee.size, float(np.abs(E_gpu[::step] - Ee).max()))}
     ncpu = host_cores()
+    # all cores: the WHOLE grid when that is ~10 s of host time (c3: 3 s on 16 cores) -- then this leg is also the parity
+    # check of every pair the step produced -- else four times the single-thread sample
+    step2 = 1 if dt1 / Eo.size * N * N / ncpu <= 10.0 else max(1, step // 4)
     t = time.perf_counter()
-    Eo2 = O.sinkhorn_grid(P, M, reg, row_step=max(1, step // 4), n_threads=ncpu)
+    Eo2 = O.sinkhorn_grid(P, M, reg, row_step=step2, n_threads=ncpu)
     dt2 = time.perf_counter() - t
+    err2 = float(np.abs(E_gpu[::step2] - Eo2).max())
     allc = {"value": round(Eo2.size / dt2, 1), "unit": "pairs/s", "cores": ncpu, "kind": "port",
             "cores_source": "len(os.sched_getaffinity(0)) capped by the cgroup CPU quota; os.cpu_count() = %d" % (os.cpu_count() or 1),
             "speedup_over_one_thread": round(Eo2.size / dt2 / (Eo.size / dt1), 2),
-            "sample": "%d ordered pairs, OpenMP over pairs (one scratch block per thread)" % Eo2.size}
+            "max_abs_diff_vs_gpu": err2, "pairs": int(Eo2.size), "whole_grid": step2 == 1,
+            "sample": "%d ordered pairs%s, OpenMP over pairs (one scratch block per thread); max|gpu-oracle| over them = %.2e"
+                      % (Eo2.size, " = EVERY pair of the step" if step2 == 1 else "", err2)}
     mo, mg = float(io["iters"].mean()), float(iters_gpu[::step].mean())
     upd = {"oracle_mean_updates_per_pair": round(mo, 2), "gpu_mean_updates_per_pair_same_sample": round(mg, 2),
            "gpu_over_oracle_updates": round(mg / mo, 4),
@@ -799,10 +810,18 @@ def bench_emd(args, L, P, M, cfg):
         out["cpu_baseline_ssp"] = {"value": round(Es.size / dts, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
                                    "sample": "the same pairs by the HIP kernel's own algorithm (successive shortest paths, diagonal warm start) on "
                                              "one CPU thread; max|gpu-oracle| = %.2e" % float(np.abs(E[::step] - Es).max())}
+        # all cores: the whole grid when that is ~10 s of host time (then also the parity check of EVERY pair), else 8 x the sample
+        step2 = 1 if dt1 / Eo.size * N * N / ncpu <= 10.0 else max(1, step // 8)
         t = time.perf_counter()
-        Eo2 = O.emd_grid(P, M, row_step=max(1, step // 8), n_threads=ncpu, fast="ns")
-        out["cpu_baseline_all_cores"] = {"value": round(Eo2.size / (time.perf_counter() - t), 1), "unit": "pairs/s",
-                                         "cores": ncpu, "kind": "port", "sample": "%d pairs, network simplex, OpenMP over pairs" % Eo2.size}
+        Eo2 = O.emd_grid(P, M, row_step=step2, n_threads=ncpu, fast="ns")
+        dt2 = time.perf_counter() - t
+        err2 = float(np.abs(E[::step2] - Eo2).max())
+        out["cpu_baseline_all_cores"] = {"value": round(Eo2.size / dt2, 1), "unit": "pairs/s", "cores": ncpu, "kind": "port",
+                                         "sample": "%d pairs%s, network simplex, OpenMP over pairs; max|gpu-oracle| over them = %.2e"
+                                                   % (Eo2.size, " = EVERY pair of the step" if step2 == 1 else "", err2)}
+        out["parity"] = {"pairs": int(Eo2.size), "whole_grid": step2 == 1, "max_abs_diff_vs_fp64_oracle": err2, "tolerance": 1e-12,
+                         "what": "the step's output against the oracle's network simplex (a different algorithm from the kernel's; the LP "
+                                 "value is unique) on the pairs of cpu_baseline_all_cores"}
     return out
 
 
