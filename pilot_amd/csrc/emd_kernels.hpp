@@ -549,7 +549,10 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 for (int e = 0; e < NK; ++e) {
                     if constexpr (UL) {
                         union { double d; unsigned int u[2]; } c;
-                        c.d = __builtin_fmax(dC[e] - pv[e], 0.0);       // (a label that rounds a hair below zero is zero)
+                        // (a label that rounds a hair below zero IS zero: the clamp carries that rounding error from search to
+                        // search; anything that turns -eps into a positive label, |.| for one, doubles it per search through the
+                        // potential update -- ab_experiments.md r04 #9)
+                        c.d = __builtin_fmax(dC[e] - pv[e], 0.0);
                         c.u[1] = __builtin_amdgcn_inverse_ballot_w64(closedm[e]) ? 0x7ff00000u : c.u[1];   // closed: never the minimum (>= +inf)
                         cur[e] = c.d;
                     } else {
