@@ -137,6 +137,9 @@ __device__ inline double wave_sum_f64(double x) {
 #ifndef EMD_BITSET
 #define EMD_BITSET 1
 #endif
+#ifndef EMD_SAME_LABEL         // 1: a step whose minimum is the previous step's label skips the wave-wide reduction
+#define EMD_SAME_LABEL 1
+#endif
 // BF (NK >= 3, or 1 with padded rows): the loops over a row of M -- the relaxation, the rebuild of the source minima -- read
 // without a bounds test (a lane beyond K reads column K - 1; its label is closed for good, its minimum never used) and write
 // through selects.  K = 160: 333 -> 246 ms per 600 x 600 grid.  Not for NK = 2: at its 64 registers the two clamped column
@@ -535,6 +538,7 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             }
             PROF_END(2);
             double dstar = 0.0, last_bd = 0.0;
+            double step_bd = 0.0;                   // label of the previous step of this search (0: the sources)
             bool exhausted = false, stale = false;
             for (int step = 0;; ++step) {
                 if (step > 2 * K + 2) { tripped = true; trip_code = 1; break; }  // cannot happen: >= one node is scanned per step
@@ -552,17 +556,29 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                         // (a label that rounds a hair below zero IS zero: the clamp carries that rounding error from search to
                         // search; anything that turns -eps into a positive label, |.| for one, doubles it per search through the
                         // potential update -- ab_experiments.md r04 #9)
-                        c.d = __builtin_fmax(dC[e] - pv[e], 0.0);
+                        c.d = __builtin_fmax(dC[e] - pv[e], EMD_SAME_LABEL ? step_bd : 0.0);
                         c.u[1] = __builtin_amdgcn_inverse_ballot_w64(closedm[e]) ? 0x7ff00000u : c.u[1];   // closed: never the minimum (>= +inf)
                         cur[e] = c.d;
                     } else {
                         cur[e] = dC[e];
                     }
                 }
-                double best = cur[0];
+                // Labels never fall below the label of the previous step (step_bd; the labels are clamped to it), so if an open
+                // column carries exactly that label -- the rows reached in the previous step had tight arcs, the usual case once
+                // a few augmentations are done -- it IS the minimum: no wave-wide reduction, and its compare is the tie mask.
+                unsigned long long tieC[NK], tieR[NK];
+                bool same_label = false;
+#if EMD_SAME_LABEL
 #pragma unroll
-                for (int e = 1; e < NK; ++e) best = bits_less(cur[e], best) ? cur[e] : best;
-                const double bd = uni_f64(wave_min_f64(best));
+                for (int e = 0; e < NK; ++e) { tieC[e] = ballot_b(cur[e] == step_bd); same_label = same_label || tieC[e] != 0ull; }
+#endif
+                double bd = step_bd;
+                if (!same_label) {
+                    double best = cur[0];
+#pragma unroll
+                    for (int e = 1; e < NK; ++e) best = bits_less(cur[e], best) ? cur[e] : best;
+                    bd = uni_f64(wave_min_f64(best));
+                }
                 PROF_END(3);
                 if (hi_word(bd) >= 0x7ff00000u) {   // +inf or NEG: nothing (more) reachable
                     if (LAZY && stale) dstar = last_bd;     // ... from a tree that is out of date: search again
@@ -570,14 +586,13 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                     break;
                 }
                 if constexpr (LAZY) last_bd = bd;
+                step_bd = bd;
                 PROF_BEGIN(4);
-                unsigned long long tieC[NK], tieR[NK];
 #pragma unroll
                 for (int e = 0; e < NK; ++e) {
-                    const bool tc = cur[e] == bd;
-                    tieC[e] = ballot_b(tc);
+                    if (!same_label) tieC[e] = ballot_b(cur[e] == bd);
                     if constexpr (UL) closedm[e] |= tieC[e];
-                    else if (tc) { fC[e] = bd; dC[e] = NEG; }
+                    else if (__builtin_amdgcn_inverse_ballot_w64(tieC[e])) { fC[e] = bd; dC[e] = NEG; }
                 }
                 // Tied columns with demand left are targets: augment along the tree path right away, WITHOUT touching the
                 // potentials, and let the search go on with the target as one more scanned column.  The labels are exact
