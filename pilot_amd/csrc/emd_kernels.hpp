@@ -218,7 +218,22 @@ __host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? EMD_NK2_W
 #define EMD_PITCH64 1
 #endif
 __host__ __device__ constexpr int emd_m_pitch(int K) { return (EMD_PITCH64 && K <= 64) ? 64 : K; }
+// LF (K <= 60): the flow VALUES live in LDS, four (column, value) slots per row and wave -- 93 % of the support arcs of c3's
+// plans are among the first four of their row --, arcs beyond a row's four slots in the global slab as before (a 64-bit mask
+// per row says which).  A row's slots are only ever touched by ONE lane at a time (its own in the warm start and the final sum,
+// the hop's on an augmenting path: a simple path visits a row once).  What it buys is traffic, not time: 4.0 -> 0.6 GB per c3
+// launch and 5 - 7 % MORE time (the kernel is instruction-bound; a slot look-up costs more instructions than a slab access), so
+// it is OPT-IN at run time (PILOT_OT_EMD_LDS_FLOW=1, pilot_ot.hip; profiles/r04/ab_experiments.md #11).  Same bits either way.
+#ifndef EMD_LDS_FLOW
+#define EMD_LDS_FLOW 1
+#endif
+constexpr int EMD_LF_WAVES = 16;                                     // waves per workgroup of the LF variant (M is shared by more)
+__host__ __device__ constexpr size_t emd_lf_wave_bytes(int K) { return (size_t)K * (4 * sizeof(double) + sizeof(unsigned int) + sizeof(unsigned long long)); }
 // dynamic LDS of emd_grid_kernel: M (K <= 128), the row minima, and for K <= 64 the two K x K byte tables of the source order
+__host__ __device__ constexpr size_t emd_lds_bytes(int K);
+__host__ __device__ constexpr size_t emd_lds_bytes_lf(int K) { return ((emd_lds_bytes(K) + 7) & ~(size_t)7) + EMD_LF_WAVES * emd_lf_wave_bytes(K); }
+// LF when two such workgroups fit a CU's 160 KB (K <= 60)
+__host__ __device__ constexpr bool emd_lf(int K) { return EMD_LDS_FLOW && K <= 64 && 2 * emd_lds_bytes_lf(K) <= 160 * 1024; }
 __host__ __device__ constexpr size_t emd_lds_bytes(int K) {
     return K > 128 ? sizeof(double) * (size_t)K
                    : sizeof(double) * ((size_t)K * emd_m_pitch(K) + K) + (K <= 64 ? (size_t)K * K + (size_t)K * emd_m_pitch(K) : 0);
@@ -258,9 +273,10 @@ constexpr int EMD_NQ = 64, EMD_Q_STRIDE = 32;
 #endif
 
 // MG: the cost matrix is read from global memory (L2) instead of LDS -- K > 128, where K*K doubles no longer fit LDS
-template <int NK, bool MG = false, bool UL = true>
-__global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
-    constexpr int EMD_WAVES = emd_waves(NK);
+template <int NK, bool MG = false, bool UL = true, bool LF = false>
+__global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
+    static_assert(!LF || (NK == 1 && !MG), "the LDS flow store is for one column per lane");
+    constexpr int EMD_WAVES = LF ? EMD_LF_WAVES : emd_waves(NK);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -307,6 +323,43 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
         __syncthreads();
     }
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
+    // LF: this wave's slots -- fv[row][4] values, fc[row] = the four column numbers (a byte each, 0xff = free), fo[row] = the
+    // columns of the row whose flow lives in the global slab instead
+    unsigned char *lf_base = smem_raw + ((emd_lds_bytes(K) + 7) & ~(size_t)7) + (size_t)wave * emd_lf_wave_bytes(K);
+    double *fv = reinterpret_cast<double *>(lf_base);
+    unsigned long long *fo = reinterpret_cast<unsigned long long *>(fv + 4 * (LF ? K : 0));
+    unsigned int *fc = reinterpret_cast<unsigned int *>(fo + (LF ? K : 0));
+    // slot (0 .. 3) of column j among the packed bytes c, >= 4 if it is not there: the lowest zero byte of c ^ jjjj
+    auto lf_find = [](unsigned int c, int j) -> int {
+        const unsigned int x = c ^ ((unsigned int)j * 0x01010101u);
+        const unsigned int z = (x - 0x01010101u) & ~x & 0x80808080u;
+        return z ? (__builtin_ctz(z) >> 3) : 4;
+    };
+    auto lf_set = [](unsigned int c, int slot, int j) -> unsigned int {
+        return (c & ~(0xffu << (8 * slot))) | ((unsigned int)j << (8 * slot));
+    };
+    // one hop of an augmenting path on row r, by the lane that owns the hop: the backward arc (r, jb) goes from fb to fb - delta
+    // (jb < 0: none) and leaves its slot when it runs empty, then the forward arc (r, jf) gains delta -- into its slot, or the slab
+    // if that is where it lives, or (a new arc) into a free slot, or (none free) into the slab with its bit in fo
+    auto lf_hop = [&](int r, int jf, int jb, double fb_r, double delta) {
+        unsigned int c = fc[r];
+        unsigned long long o = fo[r];
+        if (jb >= 0) {
+            const double nv = fb_r - delta;
+            const int sb = lf_find(c, jb);
+            if (sb < 4) { fv[4 * r + sb] = nv; if (nv == 0.0) c = lf_set(c, sb, 0xff); }
+            else { F[(size_t)r * K + jb] = nv; if (nv == 0.0) o &= ~(1ull << jb); }
+        }
+        const int sf = lf_find(c, jf);
+        if (sf < 4) fv[4 * r + sf] += delta;
+        else if ((o >> jf) & 1ull) F[(size_t)r * K + jf] += delta;
+        else {
+            const int sn = lf_find(c, 0xff);
+            if (sn < 4) { c = lf_set(c, sn, jf); fv[4 * r + sn] = delta; }
+            else { o |= 1ull << jf; F[(size_t)r * K + jf] = delta; }      // (the slab is zero outside the support)
+        }
+        fc[r] = c; fo[r] = o;
+    };
     constexpr bool BF = NK >= EMD_BF_MIN_NK;
     int mcol[NK];                                                             // BF: the lane's columns, clamped into the matrix
 #pragma unroll
@@ -408,7 +461,13 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
             for (int w = 0; w < NK; ++w) ship[e][w] = 0ull;
             if (idx < K && Mrd[(size_t)idx * MP + idx] - pu[e] == 0.0) {
                 const double f = ra[e] < rb[e] ? ra[e] : rb[e];
-                if (f > 0.0) { F[(size_t)idx * K + idx] = f; ship[e][e] = 1ull << lane; ra[e] -= f; rb[e] -= f; }
+                if (f > 0.0) {
+                    if constexpr (LF) fv[4 * idx] = f; else F[(size_t)idx * K + idx] = f;
+                    ship[e][e] = 1ull << lane; ra[e] -= f; rb[e] -= f;
+                }
+            }
+            if constexpr (LF) {      // (every row starts with its slots free but the diagonal's; this is also the reset after the last pair)
+                if (idx < K) { fc[idx] = ship[e][e] ? 0xffffff00u | (unsigned int)idx : 0xffffffffu; fo[idx] = 0ull; }
             }
         }
         EMD_FENCE();
@@ -673,6 +732,13 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
 #pragma unroll
                             for (int e = 0; e < NK; ++e) {
                                 const bool act = lane + 64 * e < n_hops;
+                                if constexpr (LF) {
+                                    fb[e] = INF;
+                                    if (act && hb[e] >= 0) {
+                                        const int sb = lf_find(fc[hi[e]], hb[e]);
+                                        fb[e] = sb < 4 ? fv[4 * hi[e] + sb] : F[(size_t)hi[e] * K + hb[e]];
+                                    }
+                                } else
                                 fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
                                 fmin = fb[e] < fmin ? fb[e] : fmin;
                             }
@@ -706,7 +772,8 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                             break;
                         }
                         if (n_hops == 1) {
-                            if (lane == 0) F[(size_t)src_row * K + target] += delta;
+                            if constexpr (LF) { if (lane == 0) lf_hop(src_row, target, -1, 0.0, delta); }
+                            else if (lane == 0) F[(size_t)src_row * K + target] += delta;
                         } else {
                             if constexpr (!LAZY) bottleneck();
                             // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
@@ -715,8 +782,11 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                             for (int e = 0; e < NK; ++e) {
                                 const bool act = lane + 64 * e < n_hops;
                                 if (act) {
+                                    if constexpr (LF) lf_hop(hi[e], hj[e], hb[e], fb[e], delta);
+                                    else {
                                     F[(size_t)hi[e] * K + hj[e]] += delta;
                                     if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
+                                    }
                                 }
                                 emptied[e] = ballot_b(act && hb[e] >= 0 && fb[e] == delta);
                                 if (emptied[e]) stale = true;          // a tree arc is gone
@@ -857,10 +927,19 @@ __global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kern
                 while (m) {
                     const int j = __builtin_ctzll(m) + 64 * w;
                     m &= m - 1ull;
-                    cost += F[(size_t)idx * K + j] * Mrd[(size_t)idx * MP + j];
+                    // (one fused multiply-add per arc in either form: the two forms give the same bits)
+                    if constexpr (LF) {
+                        const int sl = lf_find(fc[idx], j);
+                        double fl;
+                        if (sl < 4) fl = fv[4 * idx + sl];
+                        else { fl = F[(size_t)idx * K + j]; F[(size_t)idx * K + j] = 0.0; }
+                        cost = __builtin_fma(fl, Mrd[(size_t)idx * MP + j], cost);
+                    } else {
+                    cost = __builtin_fma(F[(size_t)idx * K + j], Mrd[(size_t)idx * MP + j], cost);
 #if !EMD_ZERO_PER_PAIR
                     F[(size_t)idx * K + j] = 0.0;           // the slab goes back to all zeros for the wave's next pair
 #endif
+                    }
                 }
             }
         }

@@ -205,6 +205,14 @@ constexpr int TIMING_RING = 64;
 constexpr size_t LDS_BYTES = 160 * 1024;
 // exact-EMD kernel: workgroups of pilot::emd_waves(NK) waves, M (+ row minima) in LDS; resident workgroups per CU
 static int emd_nk(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : (K <= 192 ? 3 : 4)); }
+// PILOT_OT_EMD_LDS_FLOW=1 (K <= 60): the exact-OT kernel keeps the flow values in LDS slots instead of the global slab -- 4.0 -> 0.6 GB
+// of HBM traffic per c3 launch, 5 - 7 % slower (instruction-bound kernel: the slot look-ups cost more than the slab accesses),
+// so it is opt-in; same bits either way (tests/test_gpu_emd_cost_tl.py)
+static bool emd_use_lf(int K) {
+    if (!pilot::emd_lf(K)) return false;
+    const char *e = getenv("PILOT_OT_EMD_LDS_FLOW");
+    return e && e[0] == '1';
+}
 static int emd_wgs_per_cu(int K) {
     if (K > 128) return 1;                      // cost matrix in global memory, 3-4 rows per lane: one workgroup per CU
     const size_t lds = pilot::emd_lds_bytes(K);     // (M, row minima; K <= 64: + the per-column source order and its inverse)
@@ -469,7 +477,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) pl->flags_ws_n = (size_t)N * N;
     if (e == hipSuccess && K <= EMD_MAX_K)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
-                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)));
+                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)));   // (the LDS-flow variant: 2 x 16 waves, the same 32 per CU)
     if (e != hipSuccess) {
         pilot_ot_plan_destroy(pl);
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
@@ -1248,11 +1256,12 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         hipLaunchKernelGGL(pilot::emd_generic_kernel, dim3((unsigned)wgs), dim3(pilot::EMDG_WG), lds, s, p, rowmin);
     } else {
         if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
-        const size_t lds = pilot::emd_lds_bytes(K);
+        const bool lf = emd_use_lf(K);
+        const size_t lds = lf ? pilot::emd_lds_bytes_lf(K) : pilot::emd_lds_bytes(K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
-        const int waves = pilot::emd_waves(emd_nk(K));
+        const int waves = lf ? pilot::EMD_LF_WAVES : pilot::emd_waves(emd_nk(K));
         long wgs = (total + waves - 1) / waves;
-        const long cap = (long)pl->n_cu * emd_wgs_per_cu(K);
+        const long cap = (long)pl->n_cu * (lf ? 2 : emd_wgs_per_cu(K));
         if (wgs > cap) wgs = cap;
         constexpr bool UL = pilot::emd_ul(128);      // (labels without the column potential: always beyond 64 cell types)
         if (K > 192) {
@@ -1260,7 +1269,8 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         } else if (K > 128) {
             hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true, UL>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else if (K <= 64) {
-            auto kern = pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true> : pilot::emd_grid_kernel<1, false, false>;
+            auto kern = lf ? (pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true, true> : pilot::emd_grid_kernel<1, false, false, true>)
+                           : (pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true, false> : pilot::emd_grid_kernel<1, false, false, false>);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else {
