@@ -62,6 +62,10 @@ bash tools/profile_pmc_scalar.sh gpurun_out/report_$TAG/pmc_emd_sca --mode emd >
 cp $O/pmc_emd_sca/summary.txt $O/rocprofv3_pmc_scalar_emd_c3.txt
 rm -rf $O/pmc_emd_sca
 bash tools/emd_prof_builds.sh c3 > $O/emd_prof_c3.txt 2>&1
+PILOT_OT_EMD_LDS_FLOW=1 bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_emd_lf --mode emd > /dev/null 2>&1
+cp $O/pmc_emd_lf/summary.txt $O/rocprofv3_pmc_summary_emd_c3_lds_flow.txt
+rm -rf $O/pmc_emd_lf
+for p in 4 12 real 30 50 60; do PILOT_OT_EMD_LDS_FLOW=1 python tools/emd_point.py $p; done > $O/emd_points_lds_flow.txt 2>&1
 python tools/make_traffic_json.py $O > $O/traffic.json
 # the other rungs of the precision ladder: kernel-trace average + the PMC passes, merged into traffic.json
 for prec in fp32 bf16x3 fp64; do
