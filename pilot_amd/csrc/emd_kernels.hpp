@@ -132,21 +132,11 @@ __device__ inline double wave_sum_f64(double x) {
     return x;
 }
 
-// lane `lane` of `old` <- the wave-uniform `value` (v_writelane_b32: one instruction instead of compare + select; gfx950
-// reads at most one SGPR per VALU instruction, so the lane select travels in M0)
-#ifndef EMD_BITSET
-#define EMD_BITSET 1
-#endif
-#ifndef EMD_SAME_LABEL         // 1: a step whose minimum is the previous step's label skips the wave-wide reduction
-#define EMD_SAME_LABEL 1
-#endif
 // BF (NK >= 3, or 1 with padded rows): the loops over a row of M -- the relaxation, the rebuild of the source minima -- read
 // without a bounds test (a lane beyond K reads column K - 1; its label is closed for good, its minimum never used) and write
 // through selects.  K = 160: 333 -> 246 ms per 600 x 600 grid.  Not for NK = 2: at its 64 registers the two clamped column
-// indices cost more spills than the branches they remove (K = 100: 36.1 -> 41.6 ms), ab_experiments.md r04.
-#ifndef EMD_BF_MIN_NK
-#define EMD_BF_MIN_NK 3
-#endif
+// indices cost more spills than the branches they remove (K = 100: 36.1 -> 41.6 ms), profiles/r04/ab_experiments.md.
+constexpr int EMD_BF_MIN_NK = 3;
 // UL (template parameter; EMD_ULAB = 0 / 1 forces it off / on for A/B builds, default: by K, see emd_ul()): a column's label is
 // kept PLUS its potential, L_j = d_j + pv_j = min over the scanned rows i of M_ij + (d_i - pu_i): relaxing a row is one add and one
 // compare per column (was: two subtracts, a clamp, an add, a compare), and the label itself, max(L_j - pv_j, 0), is formed once
@@ -160,9 +150,8 @@ __host__ __device__ constexpr bool emd_ul(int K) {
     return K > 32;
 #endif
 }
-#ifndef EMD_SELECT            // 1: the relaxation writes its label with selects instead of a branch around two moves
-#define EMD_SELECT 1
-#endif
+// lane `lane` of `old` <- the wave-uniform `value` (v_writelane_b32: one instruction instead of compare + select; gfx950
+// reads at most one SGPR per VALU instruction, so the lane select travels in M0)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"       // M0 is reserved (never live across statements); the clobber is declared anyway
 __device__ inline int wl_i32(int old, int value, int lane) {
@@ -173,12 +162,8 @@ __device__ inline int wl_i32(int old, int value, int lane) {
 // m with bit `bit` cleared, in ONE scalar instruction (m &= m - 1 is s_add_u32 + s_addc_u32 + s_and_b64; the scalar unit is as
 // busy as the vector unit in the exact-OT kernel, profiles/r04/rocprofv3_pmc_summary_emd_c3.txt)
 __device__ inline unsigned long long clear_bit(unsigned long long m, int bit) {
-#if EMD_BITSET
     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
     return m;
-#else
-    return m & (m - 1ull);
-#endif
 }
 __device__ inline unsigned int hi_word(double x) {
     union { double d; unsigned int u[2]; } v;
@@ -195,66 +180,37 @@ __device__ inline bool bits_less(double a, double b) {
 
 // NK = rows/columns per lane (1: K <= 64, 2: K <= 128, 3 / 4: K <= 192 / 256 with MG).
 //   * the cost matrix M and its row minima live in LDS (shared by the workgroup);
-//   * the flow VALUES live in an L2-resident global slab of K*K doubles per resident wave (row-major, zeroed per pair) and
-//     are touched only along augmenting paths and for the final cost;
+//   * the flow VALUES live in an L2-resident global slab of K*K doubles per resident wave (row-major, zero outside the support)
+//     and are touched only along augmenting paths and for the final cost;
 //   * the flow SUPPORT lives in registers: lane i keeps a bit mask of the columns row i currently ships to, so "which
 //     rows ship to the columns being scanned" is one 64-bit AND against the ballot mask of those columns.
 // Nothing per wave is in LDS, so occupancy is bounded by registers (and, from K = 91 on, by the LDS copy of M).
-// EMD_LAZY / EMD_WPE: experiment switches (lazy restarts for NK >= 2; per-variant register caps), see ab_experiments.md.
+// (Round 4 also built a variant with the flow values in LDS slots, K <= 60: a seventh of the HBM traffic and 5 - 7 % MORE time on
+// this instruction-bound kernel -- removed in round 5, profiles/r04/ab_experiments.md #11; the small-K kernel of
+// emd_multi_kernels.hpp keeps its flows in LDS.)
 // waves per workgroup: 8 (two per SIMD) in general; 16 for 64 < K <= 128, where the LDS copy of M (up to 128 KB) allows
 // at most two workgroups per CU -- with 8 waves each that is 4 waves per SIMD, too few to hide the latencies of this
-// kernel; 2 x 16 waves of <= 64 registers run c4 in 0.47 s instead of 0.55 s (ab_experiments.md)
-#ifndef EMD_NK2_WAVES          // A/B: waves per workgroup and per SIMD of the 64 < K <= 128 variant
-#define EMD_NK2_WAVES 16
-#endif
-#ifndef EMD_NK2_WPE
-#define EMD_NK2_WPE 8
-#endif
-__host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? EMD_NK2_WAVES : 8; }
+// kernel; 2 x 16 waves of <= 64 registers run c4 in 0.47 s instead of 0.55 s (profiles/r03/ab_experiments.md)
+__host__ __device__ constexpr int emd_waves(int NK) { return NK == 2 ? 16 : 8; }
 // Row pitch of the LDS copy of M (doubles).  K <= 64: 64, one lane per column of a padded row -- the relaxation of a row reads
 // its 64 entries without a bounds test (the pad columns' labels are closed for good) and addresses it by a shift: two scalar
 // instructions and a branch less per relaxed row in a kernel whose scalar unit is as busy as its vector unit.
-#ifndef EMD_PITCH64
-#define EMD_PITCH64 1
-#endif
-__host__ __device__ constexpr int emd_m_pitch(int K) { return (EMD_PITCH64 && K <= 64) ? 64 : K; }
-// LF (K <= 60): the flow VALUES live in LDS, four (column, value) slots per row and wave -- 93 % of the support arcs of c3's
-// plans are among the first four of their row --, arcs beyond a row's four slots in the global slab as before (a 64-bit mask
-// per row says which).  A row's slots are only ever touched by ONE lane at a time (its own in the warm start and the final sum,
-// the hop's on an augmenting path: a simple path visits a row once).  What it buys is traffic, not time: 4.0 -> 0.6 GB per c3
-// launch and 5 - 7 % MORE time (the kernel is instruction-bound; a slot look-up costs more instructions than a slab access), so
-// it is OPT-IN at run time (PILOT_OT_EMD_LDS_FLOW=1, pilot_ot.hip; profiles/r04/ab_experiments.md #11).  Same bits either way.
-#ifndef EMD_LDS_FLOW
-#define EMD_LDS_FLOW 1
-#endif
-constexpr int EMD_LF_WAVES = 16;                                     // waves per workgroup of the LF variant (M is shared by more)
-__host__ __device__ constexpr size_t emd_lf_wave_bytes(int K) { return (size_t)K * (4 * sizeof(double) + sizeof(unsigned int) + sizeof(unsigned long long)); }
+__host__ __device__ constexpr int emd_m_pitch(int K) { return K <= 64 ? 64 : K; }
 // dynamic LDS of emd_grid_kernel: M (K <= 128), the row minima, and for K <= 64 the two K x K byte tables of the source order
-__host__ __device__ constexpr size_t emd_lds_bytes(int K);
-__host__ __device__ constexpr size_t emd_lds_bytes_lf(int K) { return ((emd_lds_bytes(K) + 7) & ~(size_t)7) + EMD_LF_WAVES * emd_lf_wave_bytes(K); }
-// LF when two such workgroups fit a CU's 160 KB (K <= 60)
-__host__ __device__ constexpr bool emd_lf(int K) { return EMD_LDS_FLOW && K <= 64 && 2 * emd_lds_bytes_lf(K) <= 160 * 1024; }
 __host__ __device__ constexpr size_t emd_lds_bytes(int K) {
     return K > 128 ? sizeof(double) * (size_t)K
                    : sizeof(double) * ((size_t)K * emd_m_pitch(K) + K) + (K <= 64 ? (size_t)K * K + (size_t)K * emd_m_pitch(K) : 0);
 }
-#ifndef EMD_LAZY
-#define EMD_LAZY 1
-#endif
-#ifndef EMD_WPE
-#define EMD_WPE 1
-#endif
-#ifdef EMD_NO_FENCE            // timing experiment only (drops the ordering of the flow slab's stores and loads)
-#define EMD_FENCE() do {} while (0)
-#else
 #define EMD_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
-#endif
-#ifndef EMD_ZERO_PER_PAIR      // 1: round 3's form, the whole K x K flow slab zeroed per pair (A/B switch)
-#define EMD_ZERO_PER_PAIR 0
-#endif
-// EMD_PROF = n (diagnostic builds, tools/emd_prof_builds.sh): n_aug reports the wave's clock64() ticks / 16 spent in section n
-// of a pair: 1 whole pair, 2 label set-up of a search, 3 arg-min, 4 ties + targets (augmentations included), 5 augmentations
-// alone, 6 row reach + relaxations, 7 final cost, 8 pair set-up, 9 potentials
+// Build switches (diagnostics and experiments only):
+//   EMD_ULAB = 0 / 1   forces the label form (see emd_ul) for A/B builds
+//   EMD_PROF = n       n_aug reports the wave's clock64() ticks / 16 spent in section n of a pair: 1 whole pair, 2 label set-up of a
+//                      search, 3 arg-min, 4 ties + targets (augmentations included), 5 augmentations alone, 6 row reach +
+//                      relaxations, 7 final cost, 8 pair set-up, 9 potentials
+//   EMD_STAT = n       n_aug reports a count: 1 Dijkstra steps, 2 tied-row relaxations, 3 path hops, 4 source rows in A rebuilds, 5 searches
+//   EMD_PERTURB = eps  robustness experiment: every reduced cost below 1e-13 -- the tight arcs -- is replaced by eps, i.e. the
+//                      labels that tie at a step's minimum no longer do; the LP values must not move (profiles/r04/ab_experiments.md #9)
+//   EMD_NO_CLOCK       no wall-clock watchdog (timing experiment)
 #ifdef EMD_PROF
 #define PROF_BEGIN(n) if constexpr (EMD_PROF == (n)) { prof_t0 = clock64(); }
 #define PROF_END(n) if constexpr (EMD_PROF == (n)) { prof_acc += clock64() - prof_t0; }
@@ -262,26 +218,19 @@ __host__ __device__ constexpr size_t emd_lds_bytes(int K) {
 #define PROF_BEGIN(n) do {} while (0)
 #define PROF_END(n) do {} while (0)
 #endif
-// EMD_PERTURB = eps (robustness experiment): every reduced cost below 1e-13 -- the tight arcs -- is replaced by eps, i.e. the
-// labels that tie at a step's minimum no longer do; the LP values must not move (ab_experiments.md r04)
 // dynamic pair queue: EMD_NQ counters, EMD_Q_STRIDE ints apart (one 128-byte line each)
 constexpr int EMD_NQ = 64, EMD_Q_STRIDE = 32;
-#if EMD_WPE
-#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK == 1 ? 8 : (NK == 2 ? EMD_NK2_WPE : 2), 8)))
-#else
-#define EMD_WPE_ATTR
-#endif
+#define EMD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NK == 1 ? 8 : (NK == 2 ? 8 : 2), 8)))
 
 // MG: the cost matrix is read from global memory (L2) instead of LDS -- K > 128, where K*K doubles no longer fit LDS
-template <int NK, bool MG = false, bool UL = true, bool LF = false>
-__global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
-    static_assert(!LF || (NK == 1 && !MG), "the LDS flow store is for one column per lane");
-    constexpr int EMD_WAVES = LF ? EMD_LF_WAVES : emd_waves(NK);
+template <int NK, bool MG = false, bool UL = true>
+__global__ void __launch_bounds__(64 * emd_waves(NK)) EMD_WPE_ATTR emd_grid_kernel(EmdParams p) {
+    constexpr int EMD_WAVES = emd_waves(NK);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, N = p.N;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     double *Msh = reinterpret_cast<double *>(smem_raw);   // K*K (not with MG)
-    constexpr bool PAD = NK == 1 && !MG && EMD_PITCH64;   // rows of M padded to 64 entries (zeros)
+    constexpr bool PAD = NK == 1 && !MG;                  // rows of M padded to 64 entries (zeros)
     const int MP = PAD ? 64 : K;                          // row pitch of Mrd
     double *rowmin = MG ? Msh : Msh + (size_t)K * MP;     // K: min_j M_ij (initial row potentials)
     if constexpr (!MG) {
@@ -323,43 +272,6 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
         __syncthreads();
     }
     double *F = p.f_slab + ((size_t)blockIdx.x * EMD_WAVES + wave) * K * K;   // F[i*K + j]
-    // LF: this wave's slots -- fv[row][4] values, fc[row] = the four column numbers (a byte each, 0xff = free), fo[row] = the
-    // columns of the row whose flow lives in the global slab instead
-    unsigned char *lf_base = smem_raw + ((emd_lds_bytes(K) + 7) & ~(size_t)7) + (size_t)wave * emd_lf_wave_bytes(K);
-    double *fv = reinterpret_cast<double *>(lf_base);
-    unsigned long long *fo = reinterpret_cast<unsigned long long *>(fv + 4 * (LF ? K : 0));
-    unsigned int *fc = reinterpret_cast<unsigned int *>(fo + (LF ? K : 0));
-    // slot (0 .. 3) of column j among the packed bytes c, >= 4 if it is not there: the lowest zero byte of c ^ jjjj
-    auto lf_find = [](unsigned int c, int j) -> int {
-        const unsigned int x = c ^ ((unsigned int)j * 0x01010101u);
-        const unsigned int z = (x - 0x01010101u) & ~x & 0x80808080u;
-        return z ? (__builtin_ctz(z) >> 3) : 4;
-    };
-    auto lf_set = [](unsigned int c, int slot, int j) -> unsigned int {
-        return (c & ~(0xffu << (8 * slot))) | ((unsigned int)j << (8 * slot));
-    };
-    // one hop of an augmenting path on row r, by the lane that owns the hop: the backward arc (r, jb) goes from fb to fb - delta
-    // (jb < 0: none) and leaves its slot when it runs empty, then the forward arc (r, jf) gains delta -- into its slot, or the slab
-    // if that is where it lives, or (a new arc) into a free slot, or (none free) into the slab with its bit in fo
-    auto lf_hop = [&](int r, int jf, int jb, double fb_r, double delta) {
-        unsigned int c = fc[r];
-        unsigned long long o = fo[r];
-        if (jb >= 0) {
-            const double nv = fb_r - delta;
-            const int sb = lf_find(c, jb);
-            if (sb < 4) { fv[4 * r + sb] = nv; if (nv == 0.0) c = lf_set(c, sb, 0xff); }
-            else { F[(size_t)r * K + jb] = nv; if (nv == 0.0) o &= ~(1ull << jb); }
-        }
-        const int sf = lf_find(c, jf);
-        if (sf < 4) fv[4 * r + sf] += delta;
-        else if ((o >> jf) & 1ull) F[(size_t)r * K + jf] += delta;
-        else {
-            const int sn = lf_find(c, 0xff);
-            if (sn < 4) { c = lf_set(c, sn, jf); fv[4 * r + sn] = delta; }
-            else { o |= 1ull << jf; F[(size_t)r * K + jf] = delta; }      // (the slab is zero outside the support)
-        }
-        fc[r] = c; fo[r] = o;
-    };
     constexpr bool BF = NK >= EMD_BF_MIN_NK;
     int mcol[NK];                                                             // BF: the lane's columns, clamped into the matrix
 #pragma unroll
@@ -369,7 +281,7 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
     // only when a later path turns out to be unusable.  At K = 50 the searches drop from 41 to 22 per pair but the steps do
     // not, and the extra state costs registers (10.5 -> 11.7 ms); at K = 100 it paid at 4 waves per SIMD (0.73 -> 0.66 s) but
     // the eager form at 8 waves per SIMD and <= 64 registers is faster still (0.47 s): kept for the K > 128 variants only
-    constexpr bool LAZY = NK >= 3 && EMD_LAZY;
+    constexpr bool LAZY = NK >= 3;
     const long total = (long)p.n_rows * N;
 
     // Waves draw pairs from one device-wide counter.  (A static deal leaves the waves with very different numbers of SOLVED
@@ -444,9 +356,6 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
         sa = uni_f64(wave_sum_f64(sa)); sb = uni_f64(wave_sum_f64(sb));
         const double scale = sa / sb;
         const double tol = 1e-15 * (sa > 0.0 ? sa : 1.0);
-#if EMD_ZERO_PER_PAIR
-        for (int t = lane; t < K * K; t += 64) F[t] = 0.0;
-#endif
         // warm start: wherever the diagonal arc (i, i) has zero reduced cost (always, for a metric-like cost with a
         // zero diagonal) ship min(a_i, b_i) along it.  Flow only on zero-reduced-cost arcs keeps complementary
         // slackness, so the augmenting-path phase continues from an optimal partial flow and only has to move the
@@ -462,12 +371,9 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
             if (idx < K && Mrd[(size_t)idx * MP + idx] - pu[e] == 0.0) {
                 const double f = ra[e] < rb[e] ? ra[e] : rb[e];
                 if (f > 0.0) {
-                    if constexpr (LF) fv[4 * idx] = f; else F[(size_t)idx * K + idx] = f;
+                    F[(size_t)idx * K + idx] = f;
                     ship[e][e] = 1ull << lane; ra[e] -= f; rb[e] -= f;
                 }
-            }
-            if constexpr (LF) {      // (every row starts with its slots free but the diagonal's; this is also the reset after the last pair)
-                if (idx < K) { fc[idx] = ship[e][e] ? 0xffffff00u | (unsigned int)idx : 0xffffffffu; fo[idx] = 0ull; }
             }
         }
         EMD_FENCE();
@@ -615,7 +521,7 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
                         // (a label that rounds a hair below zero IS zero: the clamp carries that rounding error from search to
                         // search; anything that turns -eps into a positive label, |.| for one, doubles it per search through the
                         // potential update -- ab_experiments.md r04 #9)
-                        c.d = __builtin_fmax(dC[e] - pv[e], EMD_SAME_LABEL ? step_bd : 0.0);
+                        c.d = __builtin_fmax(dC[e] - pv[e], step_bd);
                         c.u[1] = __builtin_amdgcn_inverse_ballot_w64(closedm[e]) ? 0x7ff00000u : c.u[1];   // closed: never the minimum (>= +inf)
                         cur[e] = c.d;
                     } else {
@@ -627,10 +533,8 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
                 // a few augmentations are done -- it IS the minimum: no wave-wide reduction, and its compare is the tie mask.
                 unsigned long long tieC[NK], tieR[NK];
                 bool same_label = false;
-#if EMD_SAME_LABEL
 #pragma unroll
                 for (int e = 0; e < NK; ++e) { tieC[e] = ballot_b(cur[e] == step_bd); same_label = same_label || tieC[e] != 0ull; }
-#endif
                 double bd = step_bd;
                 if (!same_label) {
                     double best = cur[0];
@@ -732,13 +636,6 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
 #pragma unroll
                             for (int e = 0; e < NK; ++e) {
                                 const bool act = lane + 64 * e < n_hops;
-                                if constexpr (LF) {
-                                    fb[e] = INF;
-                                    if (act && hb[e] >= 0) {
-                                        const int sb = lf_find(fc[hi[e]], hb[e]);
-                                        fb[e] = sb < 4 ? fv[4 * hi[e] + sb] : F[(size_t)hi[e] * K + hb[e]];
-                                    }
-                                } else
                                 fb[e] = (act && hb[e] >= 0) ? F[(size_t)hi[e] * K + hb[e]] : INF;
                                 fmin = fb[e] < fmin ? fb[e] : fmin;
                             }
@@ -772,8 +669,7 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
                             break;
                         }
                         if (n_hops == 1) {
-                            if constexpr (LF) { if (lane == 0) lf_hop(src_row, target, -1, 0.0, delta); }
-                            else if (lane == 0) F[(size_t)src_row * K + target] += delta;
+                            if (lane == 0) F[(size_t)src_row * K + target] += delta;
                         } else {
                             if constexpr (!LAZY) bottleneck();
                             // flow values, every hop in its own lane (the arcs of a simple path are distinct entries)
@@ -782,11 +678,8 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
                             for (int e = 0; e < NK; ++e) {
                                 const bool act = lane + 64 * e < n_hops;
                                 if (act) {
-                                    if constexpr (LF) lf_hop(hi[e], hj[e], hb[e], fb[e], delta);
-                                    else {
                                     F[(size_t)hi[e] * K + hj[e]] += delta;
                                     if (hb[e] >= 0) F[(size_t)hi[e] * K + hb[e]] = fb[e] - delta;
-                                    }
                                 }
                                 emptied[e] = ballot_b(act && hb[e] >= 0 && fb[e] == delta);
                                 if (emptied[e]) stale = true;          // a tree arc is gone
@@ -881,12 +774,8 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
                                     nd = bd + rc;
                                     lt = nd < dC[e2];                                // never true for a scanned column (NEG)
                                 }
-#if EMD_SELECT
-                                dC[e2] = lt ? nd : dC[e2];
+                                dC[e2] = lt ? nd : dC[e2];          // (selects, not a branch around two moves)
                                 parC[e2] = lt ? in : parC[e2];
-#else
-                                if (lt) { dC[e2] = nd; parC[e2] = in; }
-#endif
                             }
                         }
                     }
@@ -928,18 +817,8 @@ __global__ void __launch_bounds__(64 * (LF ? EMD_LF_WAVES : emd_waves(NK))) EMD_
                     const int j = __builtin_ctzll(m) + 64 * w;
                     m &= m - 1ull;
                     // (one fused multiply-add per arc in either form: the two forms give the same bits)
-                    if constexpr (LF) {
-                        const int sl = lf_find(fc[idx], j);
-                        double fl;
-                        if (sl < 4) fl = fv[4 * idx + sl];
-                        else { fl = F[(size_t)idx * K + j]; F[(size_t)idx * K + j] = 0.0; }
-                        cost = __builtin_fma(fl, Mrd[(size_t)idx * MP + j], cost);
-                    } else {
                     cost = __builtin_fma(F[(size_t)idx * K + j], Mrd[(size_t)idx * MP + j], cost);
-#if !EMD_ZERO_PER_PAIR
                     F[(size_t)idx * K + j] = 0.0;           // the slab goes back to all zeros for the wave's next pair
-#endif
-                    }
                 }
             }
         }

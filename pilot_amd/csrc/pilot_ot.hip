@@ -16,6 +16,7 @@
 #include "abi_common.hpp"
 #include "sinkhorn_launch.hpp"
 #include "emd_kernels.hpp"
+#include "emd_multi_kernels.hpp"
 #include "prepass_kernels.hpp"
 #include "cellw2_kernels.hpp"
 #include "generic_kernels.hpp"
@@ -193,25 +194,22 @@ constexpr int MAX_K = 128;          // the MFMA pair-grid kernels (8 row-tiles o
 constexpr int GENERIC_MAX_K = 2048;  // the reference-semantics fallback kernel (vectors in LDS)
 constexpr int EMD_MAX_K = 256;       // exact-OT kernel: 4 rows / columns per lane
 constexpr int WIDE_MAX_K = 256;      // sinkhorn_wide_kernel: 128 < K <= 256, eight waves per 16-pair tile
-// (experiment switch PILOT_OT_WIDE_MIN_K: the eight-waves-per-tile kernel from a smaller K on)
-static int wide_min_k() {
-    const char *e = getenv("PILOT_OT_WIDE_MIN_K");
-    const int v = e && *e ? atoi(e) : 0;
-    return v > 0 && v < MAX_K ? v : MAX_K;
-}
+// (Round 4 had an experiment switch that ran the eight-waves-per-tile kernel below K = 128; it under-sized p_slot / img for the
+// wide layout and the experiment is done -- profiles/r04/ab_experiments.md #7 -- so the switch is gone.)
 constexpr int CTRL_INTS = pilot::CTRL_INTS;      // control block of a call: see pilot_ot_plan::track_count
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
 // exact-EMD kernel: workgroups of pilot::emd_waves(NK) waves, M (+ row minima) in LDS; resident workgroups per CU
 static int emd_nk(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : (K <= 192 ? 3 : 4)); }
-// PILOT_OT_EMD_LDS_FLOW=1 (K <= 60): the exact-OT kernel keeps the flow values in LDS slots instead of the global slab -- 4.0 -> 0.6 GB
-// of HBM traffic per c3 launch, 5 - 7 % slower (instruction-bound kernel: the slot look-ups cost more than the slab accesses),
-// so it is opt-in; same bits either way (tests/test_gpu_emd_cost_tl.py)
-static bool emd_use_lf(int K) {
-    if (!pilot::emd_lf(K)) return false;
-    const char *e = getenv("PILOT_OT_EMD_LDS_FLOW");
-    return e && e[0] == '1';
+// K <= 16: four pairs per wavefront (emd_multi_kernels.hpp).  PILOT_OT_EMD_MULTI=0: the one-pair-per-wave kernel instead (A/B and the
+// parity test between the two); =1 / =2 force the flow values into LDS / the global slab (default: LDS up to K = 15, where five or six
+// waves per SIMD still fit beside them; profiles/r05/emd_multi_probe.txt)
+constexpr int EMD_MULTI_MAX_K = 16;
+static int emd_multi_mode(int K) {
+    const char *e = getenv("PILOT_OT_EMD_MULTI");
+    if (e && *e) return atoi(e);
+    return K <= 15 ? 1 : 2;
 }
 static int emd_wgs_per_cu(int K) {
     if (K > 128) return 1;                      // cost matrix in global memory, 3-4 rows per lane: one workgroup per CU
@@ -457,7 +455,6 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
         if (b32 > img_bytes) img_bytes = b32;
         if (bs > img_bytes) img_bytes = bs;
         if (bh > img_bytes) img_bytes = bh;
-        if (K > wide_min_k() && pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float) > img_bytes) img_bytes = pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float);
         if (e == hipSuccess) e = hipMalloc(&pl->img, img_bytes);
     } else if (K <= WIDE_MAX_K) {       // the 8-waves-per-tile kernel: the fp16-split operand block at 16 row-tiles
         if (e == hipSuccess) e = hipMalloc(&pl->img, pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float));
@@ -477,7 +474,8 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) pl->flags_ws_n = (size_t)N * N;
     if (e == hipSuccess && K <= EMD_MAX_K)
         e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
-                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)));   // (the LDS-flow variant: 2 x 16 waves, the same 32 per CU)
+                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)) *
+                          (K <= EMD_MULTI_MAX_K ? 4 : 1));   // (K <= 16: a slab per 16-lane GROUP of a wave)
     if (e != hipSuccess) {
         pilot_ot_plan_destroy(pl);
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
@@ -929,7 +927,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
         // 128 < K <= 256 (the fixed Gibbs image no longer fits one wave's registers and LDS): eight waves per tile while the
         // call is inside the fp16-split range with a symmetric cost; an explicit f64 / POT-literal request, a non-symmetric cost
         // or a smaller reg keep the POT-literal kernel
-        if (pl->K > wide_min_k() && pl->K <= WIDE_MAX_K && cost_is_symmetric && precision != PILOT_OT_PREC_GENERIC && precision != PILOT_OT_PREC_F64 &&
+        if (pl->K > MAX_K && pl->K <= WIDE_MAX_K && cost_is_symmetric && precision != PILOT_OT_PREC_GENERIC && precision != PILOT_OT_PREC_F64 &&
             pl->max_cost / reg <= h_max_cost_over_reg() && tau <= pilot::H_MAX_TAU && !getenv("PILOT_OT_NO_WIDE")) {
             if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
             return run_wide(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, row_begin, n_rows_g, row_step, d_emd,
@@ -1254,14 +1252,24 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         const size_t lds = pilot::emdg_lds_bytes(K);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::emd_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(pilot::emd_generic_kernel, dim3((unsigned)wgs), dim3(pilot::EMDG_WG), lds, s, p, rowmin);
+    } else if (K <= EMD_MULTI_MAX_K && emd_multi_mode(K) != 0) {
+        // four pairs per wavefront
+        if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
+        const pilot::EmdMultiGeom m = pilot::emd_multi_geom(K, emd_multi_mode(K) != 2);
+        const long groups = (total + (64 / m.G) - 1) / (64 / m.G);
+        long wgs = (groups + m.waves - 1) / m.waves;
+        const long cap = (long)pl->n_cu * m.wgs_per_cu;
+        if (wgs > cap) wgs = cap;
+        auto kern = m.flds ? pilot::emd_multi_kernel<16, true> : pilot::emd_multi_kernel<16, false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * m.waves), m.lds, s, p);
     } else {
         if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
-        const bool lf = emd_use_lf(K);
-        const size_t lds = lf ? pilot::emd_lds_bytes_lf(K) : pilot::emd_lds_bytes(K);
+        const size_t lds = pilot::emd_lds_bytes(K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
-        const int waves = lf ? pilot::EMD_LF_WAVES : pilot::emd_waves(emd_nk(K));
+        const int waves = pilot::emd_waves(emd_nk(K));
         long wgs = (total + waves - 1) / waves;
-        const long cap = (long)pl->n_cu * (lf ? 2 : emd_wgs_per_cu(K));
+        const long cap = (long)pl->n_cu * emd_wgs_per_cu(K);
         if (wgs > cap) wgs = cap;
         constexpr bool UL = pilot::emd_ul(128);      // (labels without the column potential: always beyond 64 cell types)
         if (K > 192) {
@@ -1269,8 +1277,7 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         } else if (K > 128) {
             hipLaunchKernelGGL((pilot::emd_grid_kernel<3, true, UL>), dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else if (K <= 64) {
-            auto kern = lf ? (pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true, true> : pilot::emd_grid_kernel<1, false, false, true>)
-                           : (pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true, false> : pilot::emd_grid_kernel<1, false, false, false>);
+            auto kern = pilot::emd_ul(K) ? pilot::emd_grid_kernel<1, false, true> : pilot::emd_grid_kernel<1, false, false>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), lds, s, p);
         } else {

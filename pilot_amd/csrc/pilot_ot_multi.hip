@@ -406,7 +406,8 @@ PILOT_API int pilot_ot_multi_set_inputs(pilot_ot_multi *m, const double *P, cons
     m->max_cost = mx;
     DeviceGuard guard;
     for (Shard &h : m->sh) {
-        if (mx > 0.0) { const int r = pilot_ot_plan_set_max_cost(h.plan, mx); if (r != PILOT_OT_OK) return r; }
+        // (always: an all-zero or NaN-maximum M must not leave a previous call's max_cost on the plan)
+        { const int r = pilot_ot_plan_set_max_cost(h.plan, mx > 0.0 && mx < __builtin_inf() ? mx : 1.0); if (r != PILOT_OT_OK) return r; }
         HIP_TRY(hipSetDevice(h.device));
         HIP_TRY(hipMemcpyAsync(h.dP, P, sizeof(double) * (size_t)m->N * m->K, hipMemcpyHostToDevice, h.stream));
         HIP_TRY(hipMemcpyAsync(h.dM, M, sizeof(double) * (size_t)m->K * m->K, hipMemcpyHostToDevice, h.stream));

@@ -1166,6 +1166,7 @@ sinkhorn_stream_kernel(GridParams p) {
     // tracking list HANDOVER_FLUSH or more at a time.  One atomic on track_count per hand-over was 11 ns of one L2 atomic
     // unit per pair -- at K = 2, where a third of the 360 000 pairs absorb, 1.2 of the fast launch's 1.27 ms
     // (profiles/r04/small_k_scaling.txt).
+    static_assert(HANDOVER_FLUSH - 1 + C::TILE <= HANDOVER_BUF, "a wave's hand-over buffer must hold one flush level plus one tile of pairs");
     int *hb = reinterpret_cast<int *>(lds + n_img + KP + n_tail + WAVES_PER_WG * p.ring * RSTRIDE + (PARK ? WAVES_PER_WG * PARK_LANE * WAVE : 0)) +
               (threadIdx.x / WAVE) * HANDOVER_BUF;
     int hb_cnt = 0;

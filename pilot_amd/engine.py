@@ -305,8 +305,9 @@ class DevicePlan:
         # the device entry point cannot see max(M): the plan carries it, and every range decision (what AUTO means, the
         # fp16-split domain, the hand-over thresholds) is taken on max(M) / reg -- M need not be normalised
         self.max_cost = float(M.max()) if M.size else 1.0
-        if self.max_cost > 0.0:
-            _lib.check(self.L.pilot_ot_plan_set_max_cost(self.plan, self.max_cost))
+        if not (self.max_cost > 0.0 and np.isfinite(self.max_cost)):
+            self.max_cost = 1.0            # (an all-zero / NaN cost: every range decision as for the normalised cost, never a stale value)
+        _lib.check(self.L.pilot_ot_plan_set_max_cost(self.plan, self.max_cost))
         self.n_rows_max = self.N if n_rows_max is None else n_rows_max
         n_out = self.n_rows_max * self.N
         self.dP = self._alloc(P.nbytes)

@@ -292,9 +292,20 @@ def _device_worker():
 
 _SIL_ARI_MESSAGE = ("return_sil_ari=True: the ARI is the Rand index of a Leiden clustering of the finished matrix "
                     "(pilotpy.tl.Clustering, Trajectory.py:525-588: scanpy neighbors + leiden) -- a consumer of adata.uns['EMD'] "
-                    "outside this engine's scope (SURVEY.md section 2 #6).  Run wasserstein_distance without it, then the "
-                    "reference's own Clustering on adata.uns['EMD'] / adata.uns['EMD'].max(); the silhouette alone is "
-                    "tl.Sil_computing(EMD / EMD.max(), adata.uns['real_labels']) (INTEGRATION.md, 'Sil / ARI')")
+                    "outside this engine's scope (SURVEY.md section 2 #6), so it is run by the reference's OWN function and "
+                    "pilotpy (with scanpy / leidenalg) is not importable here: %s.  Run wasserstein_distance without it; the "
+                    "silhouette alone is tl.Sil_computing(EMD / EMD.max(), adata.uns['real_labels']) (INTEGRATION.md, 'Sil / ARI')")
+
+
+def _reference_clustering():
+    """``pilotpy.tools.Trajectory.Clustering`` (Trajectory.py:525-588) when the reference package and its scanpy / leidenalg
+    stack are installed next to this engine -- imported lazily, only for ``return_sil_ari=True``; nothing of it is restated
+    here.  Raises NotImplementedError (before any device work) when it is not importable."""
+    try:
+        from pilotpy.tools.Trajectory import Clustering
+    except Exception as e:            # ImportError, or whatever the eager import chain of pilotpy raises
+        raise NotImplementedError(_SIL_ARI_MESSAGE % (repr(e),)) from e
+    return Clustering
 
 
 def Sil_computing(EMD, real_labels, metric="cosine"):
@@ -323,8 +334,8 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     ``{"precision": "fp64"}``; ``{"n_devices": G}`` (or ``{"devices": [0, 1, ...]}``) row-shards the pair grid over G GPUs
     of this node with one RCCL all-gather -- same bits as the single-GPU matrix.
     """
-    if return_sil_ari:      # (Trajectory.py:108-113) refused BEFORE any device work, whatever is installed
-        raise NotImplementedError(_SIL_ARI_MESSAGE)
+    # (Trajectory.py:108-113) the Leiden / ARI tail is the reference's own function: found, or refused, BEFORE any device work
+    reference_clustering = _reference_clustering() if return_sil_ari else None
     if metric not in engine._lib.METRICS:
         raise NotImplementedError("metric %r: the device kernel implements scipy's pdist names %s" % (metric, sorted(engine._lib.METRICS)))
     global path_to_results
@@ -391,6 +402,12 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     # device pass over the codes
     status_col = annot["status"]
     real_labels = [status_col.iloc[int(r)] for r in first_rows]
+    if reference_clustering is not None:      # Trajectory.py:108-113: the reference's Clustering on the finished matrix, the silhouette on the device
+        _predicted, ARI, real_labels = reference_clustering(EMD / EMD.max(), annot, metric=metric, res=res, steper=steper)
+        adata.uns["real_labels"] = real_labels
+        adata.uns["Sil"] = Sil_computing(EMD / EMD.max(), real_labels, metric=metric)
+        adata.uns["ARI"] = ARI
+        return
     adata.uns["real_labels"] = real_labels
 
 

@@ -34,23 +34,55 @@ def test_emd_full_size_grid_against_the_network_simplex(cfg, step):
     assert np.array_equal(Eg, Eg.T) and np.abs(np.diag(Eg)).max() == 0.0
 
 
-@pytest.mark.parametrize("K", [3, 14, 33, 50, 60])
-def test_emd_flow_values_in_lds_give_the_same_bits(K, monkeypatch):
-    """PILOT_OT_EMD_LDS_FLOW=1 (K <= 60): the flow values in four LDS slots per row, the rest in the slab (opt-in: a seventh of
-    the HBM traffic, 5 - 7 % slower).  The arithmetic on every flow value is the same, so the LP values must be the same BITS,
-    also where rows overflow their slots (sparse histograms against dense ones: one source row ships to dozens of columns)."""
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 8, 11, 14, 15, 16])
+def test_emd_four_pairs_per_wave_kernel_against_the_one_pair_kernel(K, monkeypatch):
+    """K <= 16 (what real cohorts have: the reference test's own has 14 clusters): emd_multi_kernel solves four pairs per
+    wavefront, one per 16-lane DPP row -- group minima by DPP butterflies, the node sets of a search as wave masks, augmentations
+    through path masks instead of a walk.  Same algorithm and the same fp64 arithmetic per pair as the one-pair-per-wave
+    kernel (PILOT_OT_EMD_MULTI=0): the same number of augmentations for every pair and the LP value to rounding, with the flow
+    values in LDS (=1) or in the global slab (=2); a pair's bits depend neither on its slot mates nor on the row subset nor on
+    the mode (all / upper / mirror).  Sparse one-cell-type patients (rows with up to K arcs), duplicates and unequal masses included."""
     rng = np.random.default_rng(K)
-    P, M = make_problem(40, K, 6, seed=900 + K, cells_per_patient=300)
-    P[::5] = 0.0; P[::5, rng.integers(0, K, size=P[::5].shape[0])] = 1.0          # one-cell-type patients: rows with up to K arcs
+    N = 45
+    P, M = make_problem(N, K, 6, seed=900 + K, cells_per_patient=300)
+    if K == 1:
+        M = np.zeros((1, 1))
+    else:
+        P[::5] = 0.0; P[::5, rng.integers(0, K, size=P[::5].shape[0])] = 1.0
+    P[7] = P[8]
+    P[9] *= 0.5
+    Eo = O.emd_grid(P, M, n_threads=16, fast="ns")
+    monkeypatch.setenv("PILOT_OT_EMD_MULTI", "0")
     E0, i0 = engine.emd_grid(P, M, mode="all", return_info=True)
-    monkeypatch.setenv("PILOT_OT_EMD_LDS_FLOW", "1")
-    E1, i1 = engine.emd_grid(P, M, mode="all", return_info=True)
-    np.testing.assert_array_equal(E1, E0)
-    np.testing.assert_array_equal(i1["n_aug"], i0["n_aug"])
+    res = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PILOT_OT_EMD_MULTI", mode)
+        E1, i1 = engine.emd_grid(P, M, mode="all", return_info=True)
+        np.testing.assert_array_equal(i1["n_aug"], i0["n_aug"])
+        assert np.abs(E1 - E0).max() <= 1e-14 and np.abs(E1 - Eo).max() <= 1e-12
+        rows = np.arange(3, N, 7)
+        np.testing.assert_array_equal(engine.emd_grid(P, M, row_begin=3, row_step=7, mode="all"), E1[rows])
+        np.testing.assert_array_equal(engine.emd_grid(P, M, row_begin=3, row_step=7, mode="upper"),
+                                      np.where(np.arange(N)[None, :] >= rows[:, None], E1[rows], 0.0))
+        res[mode] = E1
+    np.testing.assert_array_equal(res["1"], res["2"])
+    monkeypatch.delenv("PILOT_OT_EMD_MULTI")
+    np.testing.assert_array_equal(engine.emd_grid(P, M, mode="all"), res["1"])          # the default is one of the two
+
+
+def test_emd_four_pairs_per_wave_kernel_on_the_reference_cohort(monkeypatch):
+    """Every pair of the reference test's own cohort (Kidney_IgAN_G: 634 patients x 14 clusters, up to 101 augmentations per
+    pair) against the oracle's network simplex, and against the one-pair-per-wave kernel augmentation for augmentation."""
+    g = load_golden(GOLDEN_REAL)
+    P = g["proportions"]; M = g["cost"] / g["cost"].max()
+    E1, i1 = engine.emd_grid(P, M, return_info=True)
     assert np.abs(E1 - O.emd_grid(P, M, n_threads=16, fast="ns")).max() <= 1e-12
-    rows = np.arange(3, 40, 7)
-    np.testing.assert_array_equal(engine.emd_grid(P, M, row_begin=3, row_step=7, mode="upper"),
-                                  np.where(np.arange(40)[None, :] >= rows[:, None], E0[rows], 0.0))
+    assert np.array_equal(E1, E1.T) and np.abs(np.diag(E1)).max() == 0.0
+    monkeypatch.setenv("PILOT_OT_EMD_MULTI", "0")
+    E0, i0 = engine.emd_grid(P, M, return_info=True)
+    iu = np.triu_indices(P.shape[0])
+    np.testing.assert_array_equal(i1["n_aug"][iu], i0["n_aug"][iu])
+    assert np.abs(E1 - E0).max() <= 1e-14
 
 
 def test_emd_modes_and_symmetry():
@@ -68,9 +100,9 @@ def test_emd_modes_and_symmetry():
         engine.emd_grid(P, M, row_begin=1, mode="mirror")
 
 
-@pytest.mark.parametrize("K", [1, 2, 17, 32, 33, 64, 65, 100, 128, 129, 192, 193, 256])
+@pytest.mark.parametrize("K", [1, 2, 9, 16, 17, 32, 33, 64, 65, 100, 128, 129, 192, 193, 256])
 def test_emd_every_k_regime(K):
-    """K <= 64: one row/column per lane (labels with the column potential up to K = 32, without it beyond: emd_ul); K > 64:
+    """K <= 16: four pairs per wave (emd_multi_kernels.hpp); K <= 64: one row/column per lane (labels with the column potential up to K = 32, without it beyond: emd_ul); K > 64:
     two (flow support masks of 2 x 64 bits per row); K > 128: three / four, cost matrix read from global memory, lazy
     restarts, row loops without bounds tests."""
     P, M = make_problem(12, K, 6, seed=200 + K, cells_per_patient=500)

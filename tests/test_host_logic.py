@@ -112,13 +112,22 @@ def test_a_wrong_embedding_key_fails_in_the_extraction_step():
     assert ad.uns == {}
 
 
-def test_return_sil_ari_is_refused_before_any_device_work():
+def test_return_sil_ari_is_refused_before_any_device_work(monkeypatch):
     """return_sil_ari=True (Trajectory.py:108-113) needs the Leiden clustering of the finished matrix (scanpy), a consumer
-    outside this engine's scope: the call is refused up front whatever is installed -- nothing
-    computed, nothing written to adata.uns, no GPU touched (this test runs on the CPU box)."""
+    outside this engine's scope.  Nothing of it is restated here: the reference's OWN Clustering is
+    used when pilotpy (and its scanpy / leidenalg stack) is importable, and otherwise the call is refused up front -- nothing
+    computed, nothing written to adata.uns, no GPU touched (this test runs on the CPU box, where pilotpy is not importable)."""
+    import sys, types
     g = load_golden("c1_20x10x10")
     ad, _ = golden_adata(g)
     with pytest.raises(NotImplementedError, match="Clustering"):
         tl.wasserstein_distance(ad, emb_matrix="X_pca", return_sil_ari=True)
     assert ad.uns == {}
     assert not hasattr(tl, "Clustering")
+    # with the reference importable the flag resolves to ITS function (looked up before any device work)
+    calls = []
+    fake = types.ModuleType("pilotpy.tools.Trajectory")
+    fake.Clustering = lambda EMD, annot, metric="cosine", res=0.01, steper=0.01: calls.append(1)
+    for name, mod in (("pilotpy", types.ModuleType("pilotpy")), ("pilotpy.tools", types.ModuleType("pilotpy.tools")), ("pilotpy.tools.Trajectory", fake)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    assert tl._reference_clustering() is fake.Clustering and not calls

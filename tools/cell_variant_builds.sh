@@ -2,11 +2,13 @@
 # experiment builds of the cell-level W2 kernel (GPU box): each argument is one set of extra -D flags
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R/pilot_amd/csrc
-cp ../libpilot_ot.so /tmp/libpilot_ot.keep.so
+KEEP=$(mktemp /tmp/libpilot_ot.keep.XXXXXX.so)
+cp ../libpilot_ot.so "$KEEP"
+# (put the installed library back on ANY exit: an interrupted run must not leave a diagnostic build behind)
+trap 'cp "$KEEP" "$R/pilot_amd/libpilot_ot.so"; rm -f "$KEEP"' EXIT
 timeout 300 python3 $R/tools/cell_w2_rate.py | sed 's/^/baseline: /' | sed -n 2p
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $v -c -o /tmp/pilot_ot_var.o pilot_ot.hip 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_var.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_inst_*.o -ldl
   timeout 300 python3 $R/tools/cell_w2_rate.py | sed "s/^/$v: /" | sed -n 2p
 done
-cp /tmp/libpilot_ot.keep.so ../libpilot_ot.so

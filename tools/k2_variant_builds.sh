@@ -5,7 +5,10 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R/pilot_amd/csrc
 PARTS=${K2_PARTS:-8 9}
-cp ../libpilot_ot.so /tmp/libpilot_ot.keep.so
+KEEP=$(mktemp /tmp/libpilot_ot.keep.XXXXXX.so)
+cp ../libpilot_ot.so "$KEEP"
+# (put the installed library back on ANY exit: an interrupted run must not leave a diagnostic build behind)
+trap 'cp "$KEEP" "$R/pilot_amd/libpilot_ot.so"; rm -f "$KEEP"' EXIT
 run() { for cfg in ${K2_CFGS:-c2 c3}; do timeout 120 python3 $R/bench.py --config $cfg --no-extras --no-cpu-baseline | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$1] $cfg: %.4f ms  kernel %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"; done; }
 run baseline
 for v in "$@"; do
@@ -25,4 +28,3 @@ for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so $host build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_wide.o $objs -ldl
   run "$v"
 done
-cp /tmp/libpilot_ot.keep.so ../libpilot_ot.so
