@@ -44,7 +44,7 @@ PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # same pipe, same dense rate for fp16 inputs
-PROFILE_ROUNDS = ("r04", "r03")  # newest first: the offline rocprofv3 measurements bench.py quotes next to its live ones
+PROFILE_ROUNDS = ("r05", "r04", "r03")  # newest first: the offline rocprofv3 measurements bench.py quotes next to its live ones
 
 
 def profile_file(name):
@@ -113,7 +113,8 @@ def main():
                     help="untimed calls before the warm-up steps that bring the GPU clocks up from idle (0 to disable; "
                          "default: 150 for grids up to the size of c3, 5 beyond -- about 0.2 s either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / reg_sweep / exact_emd / c4")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / reg_sweep / exact_emd / c4 / c5_cellw2")
+    ap.add_argument("--no-c5", action="store_true", help="skip the c5_cellw2 key of the default line (one 35 s pass over BASELINE config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work budget of the baseline sample")
     ap.add_argument("--force-comm", action="store_true",
                     help="testing on a 1-GPU box: run the one-process-per-GPU path (RCCL communicator, all-gather, max over "
@@ -309,7 +310,10 @@ def main():
             out["value_host_to_host"] = host_to_host(P, M, args.reg, run_prec)
             out["precision_ladder"] = precision_ladder(P, M, args.reg, args.config)
             out["reg_sweep"] = reg_sweep(P, M, K)
-            out["exact_emd"] = exact_emd_brief(L, P, M)
+            out["exact_emd"] = exact_emd_record(L, P, M, args.config, with_cpu=not args.no_cpu_baseline)
+            if args.config == "c3" and not args.no_c5:
+                c5 = bench_cellw2(args)       # BASELINE configs[4] (an extension): one pass over its 40 000 pairs, ~35 s
+                out["c5_cellw2"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "checks", "cpu_baseline")}
             if args.config in ("c2", "c3"):
                 out["e2e_tl_s"] = e2e_tl(cfg)
         if not args.no_cpu_baseline:
@@ -546,7 +550,12 @@ def reg_sweep(P, M, K, regs=(0.01, 0.1, 1.0), row_step=60):
         plan.sync()
         dt = (time.perf_counter() - t) / reps
         E, info = plan.fetch()
+        tc = time.perf_counter()
         Eo, io = O.sinkhorn_grid(P, M, reg, row_step=row_step, n_threads=host_cores(), return_info=True)
+        dt_cpu = time.perf_counter() - tc
+        tc = time.perf_counter()
+        O.sinkhorn_grid(P, M, reg, row_begin=0, row_end=1, n_threads=1)       # one row on one thread, like the reference's loop
+        dt_cpu1 = time.perf_counter() - tc
         Es, its, fl = E[::row_step], info["iters"][::row_step], info["flags"][::row_step]
         last = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((fl & _lib.FLAG_ABSORB_LAST) > 0)
         same = its == io["iters"]
@@ -563,13 +572,32 @@ def reg_sweep(P, M, K, regs=(0.01, 0.1, 1.0), row_step=60):
             "sample_absorb_on_last_oracle": int(((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0).sum()),
             "sample_absorb_on_last_gpu": int(((fl & _lib.FLAG_ABSORB_LAST) > 0).sum()),
             "sample_mean_updates_oracle": round(float(io["iters"].mean()), 2),
+            "cpu_pairs_per_s": round(Eo.size / dt_cpu, 1), "cpu_cores": host_cores(),
+            "cpu_pairs_per_s_one_thread": round(N / dt_cpu1, 1),
+            "cpu_what": "the fp64 oracle (POT's rule, kind \"port\") on the same sample, OpenMP over pairs on cpu_cores; one thread: row 0 (%d pairs)" % N,
         })
     plan.close()
     return {"precision": "auto", "sample": "rows 0,%d,.. x all columns" % row_step, "rows": rows}
 
 
-def exact_emd_brief(L, P, M, reps=3):
-    """The reference's DEFAULT mode (regularized='unreg', Trajectory.py:507-511) on the same cohort, device-resident."""
+def emd_instruction_accounting(config):
+    """Per-pair instruction counts and HBM traffic of the exact-OT kernel from the committed rocprofv3 PMC passes of this
+    workload (profiles/rNN/emd_instr.json, written by tools/make_emd_instr_json.py from tools/profile_pmc*.sh summaries)."""
+    path, rnd = profile_file("emd_instr.json")
+    if not path:
+        return None
+    try:
+        with open(path) as fh:
+            e = json.load(fh).get(config)
+    except (OSError, ValueError):
+        return None
+    if e:
+        e = dict(e, source="profiles/%s/emd_instr.json" % rnd)
+    return e
+
+
+def time_emd_grid(L, P, M, reps=5, ramp_s=0.2):
+    """(seconds per matrix, E, n_aug) of pilot_ot_emd_grid_dev on a resident cohort: symmetric cost -> j >= i solved, mirrored."""
     from pilot_amd import _lib, engine
     N = P.shape[0]
     plan = engine.DevicePlan(P, M)
@@ -577,16 +605,107 @@ def exact_emd_brief(L, P, M, reps=3):
     def run():
         _lib.check(L.pilot_ot_emd_grid_dev(plan.plan, plan.dP, plan.dM, sym, 0, N, 1, plan.dE, plan.dIt, None))
     t = time.perf_counter()
-    while time.perf_counter() - t < 0.2:
+    while time.perf_counter() - t < ramp_s:
         run(); plan.sync()
     t = time.perf_counter()
     for _ in range(reps):
         run()
     plan.sync()
     dt = (time.perf_counter() - t) / reps
+    E = np.empty((N, N)); n_aug = np.empty((N, N), dtype=np.int32)
+    _lib.check(L.pilot_ot_memcpy_d2h(E.ctypes.data, plan.dE, 8 * N * N))
+    _lib.check(L.pilot_ot_memcpy_d2h(n_aug.ctypes.data, plan.dIt, 4 * N * N))
     plan.close()
-    return {"ms_per_matrix": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1), "dtype": "f64",
-            "what": "pilot_ot_emd_grid_dev, all N^2 ordered pairs (symmetric cost: j >= i solved, mirrored)"}
+    return dt, E, n_aug
+
+
+def emd_cpu_legs(P, M, E, budget_s):
+    """Network simplex (oracle/pilot_oracle.c::pilot_oracle_emd2_ns, kind "port": the algorithm family of POT's LEMON solver)
+    on one thread over a bounded row sample, and on every core over the whole grid when that fits ~10 s (then also the parity
+    check of EVERY pair the launch produced)."""
+    from oracle import oracle as O
+    N = P.shape[0]
+    t = time.perf_counter()
+    O.emd_grid(P, M, row_begin=0, row_end=1, n_threads=1, fast="ns")
+    per_row = time.perf_counter() - t
+    n_rows = int(max(1, min(N, budget_s / max(per_row, 1e-9))))
+    step = max(1, N // n_rows)
+    t = time.perf_counter()
+    Eo = O.emd_grid(P, M, row_step=step, n_threads=1, fast="ns")
+    dt1 = time.perf_counter() - t
+    one = {"value": round(Eo.size / dt1, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+           "sample": "rows 0,%d,.. x all columns (%d ordered pairs), one thread: a NETWORK SIMPLEX on the bipartite transportation graph "
+                     "(spanning-tree basis, block-search pricing), the algorithm family of POT's own solver (LEMON; not available on "
+                     "this box); max|gpu-oracle| = %.2e" % (step, Eo.size, float(np.abs(E[::step] - Eo).max()))}
+    ncpu = host_cores()
+    step2 = 1 if dt1 / Eo.size * N * N / ncpu <= 10.0 else max(1, step // 8)
+    t = time.perf_counter()
+    Eo2 = O.emd_grid(P, M, row_step=step2, n_threads=ncpu, fast="ns")
+    dt2 = time.perf_counter() - t
+    err2 = float(np.abs(E[::step2] - Eo2).max())
+    allc = {"value": round(Eo2.size / dt2, 1), "unit": "pairs/s", "cores": ncpu, "kind": "port",
+            "sample": "%d ordered pairs%s, network simplex, OpenMP over pairs; max|gpu-oracle| over them = %.2e"
+                      % (Eo2.size, " = EVERY pair of the launch" if step2 == 1 else "", err2)}
+    parity = {"pairs": int(Eo2.size), "whole_grid": step2 == 1, "max_abs_diff_vs_fp64_oracle": err2, "tolerance": 1e-12,
+              "what": "the launch's output against the oracle's network simplex (a different algorithm from the kernel's; the LP value "
+                      "is unique) on the pairs of cpu_baseline_all_cores"}
+    return one, allc, parity
+
+
+def real_cohort_record(L, with_cpu):
+    """The reference test's own cohort (test/test_pilot.py:9-23: Kidney_IgAN_G, 634 patients x 14 clusters) from the committed
+    fixture: proportions and cost as the reference's code produced them; both modes of the pair grid, device-resident."""
+    from pilot_amd import engine
+    path = os.path.join(ROOT, "tests", "golden", "kidney_igan_g_634x14x14.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path, allow_pickle=True)
+    P = np.ascontiguousarray(g["proportions"], dtype=np.float64)
+    M = np.ascontiguousarray(g["cost"] / g["cost"].max(), dtype=np.float64)
+    N, K = P.shape
+    dt, E, n_aug = time_emd_grid(L, P, M, reps=10)
+    rec = {"cohort": "Kidney_IgAN_G (tests/golden/kidney_igan_g_634x14x14.npz): %d patients x %d clusters" % (N, K),
+           "exact_emd_ms_per_matrix": round(1e3 * dt, 3), "exact_emd_pairs_per_s": round(N * N / dt, 1),
+           "mean_augmentations_per_solved_pair": round(float(n_aug[np.triu_indices(N)].mean()), 2)}
+    plan = engine.DevicePlan(P, M)
+    for _ in range(20):
+        plan.run(0.1, precision="auto")
+    plan.sync()
+    t = time.perf_counter()
+    for _ in range(20):
+        plan.run(0.1, precision="auto")
+    plan.sync()
+    rec["sinkhorn_reg0.1_ms_per_matrix"] = round(1e3 * (time.perf_counter() - t) / 20, 3)
+    plan.close()
+    if with_cpu:
+        one, allc, parity = emd_cpu_legs(P, M, E, 2.0)
+        rec["exact_emd_cpu_baseline"], rec["exact_emd_cpu_baseline_all_cores"], rec["exact_emd_parity"] = one, allc, parity
+    return rec
+
+
+def exact_emd_record(L, P, M, config, with_cpu=True, budget_s=4.0):
+    """The reference's DEFAULT mode (regularized='unreg', Trajectory.py:507-511) on the same cohort, device-resident: time,
+    CPU baselines (network simplex, one thread and all cores), whole-grid parity, the committed instruction accounting of
+    the kernel, and the reference test's own cohort."""
+    N, K = P.shape
+    dt, E, n_aug = time_emd_grid(L, P, M)
+    iu = np.triu_indices(N)
+    out = {"ms_per_matrix": round(1e3 * dt, 3), "pairs_per_s": round(N * N / dt, 1), "dtype": "f64",
+           "what": "pilot_ot_emd_grid_dev, all N^2 ordered pairs (symmetric cost: j >= i solved, mirrored); host-timed over 5 back-to-back launches",
+           "mean_augmentations_per_solved_pair": round(float(n_aug[iu].mean()), 2),
+           "roofline": {"bound": "hbm", "achieved": round(N * N * (2 * K * 8 + 8) / dt / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(N * N * (2 * K * 8 + 8) / dt / 1e9 / PEAK_HBM_GBS, 6),
+                        "note": "instruction-issue-bound augmenting-path search (no MFMA, branchy fp64): the streaming-model bytes of "
+                                "SURVEY 8(d) are what the north star names; what bounds it is in `instructions`"}}
+    acc = emd_instruction_accounting(config)
+    if acc:
+        out["instructions"] = acc
+    if with_cpu:
+        out["cpu_baseline"], out["cpu_baseline_all_cores"], out["parity"] = emd_cpu_legs(P, M, E, budget_s)
+    rc = real_cohort_record(L, with_cpu)
+    if rc:
+        out["real_cohort"] = rc
+    return out
 
 
 def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
@@ -735,6 +854,31 @@ def bench_cellw2(args, reg=0.1, D=30):
     conv = info["iters"] < 1000
     Dp = 32 * ((D + 31) // 32)
     sym = float(np.abs(W - W.T)[conv & conv.T].max())
+    # CPU baseline: the C / OpenMP fp64 oracle (kind "port": the extension has no reference implementation) on a few pairs of the
+    # SAME cohort, all cores inside a pair; also the parity check of those pairs
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ncpu = host_cores()
+        pairs = [(0, 1), (2, 3), (5, 4)][:max(1, min(3, Np // 2))]
+        t = time.perf_counter()
+        vals = [O.cell_w2_c(X[offs[i]:offs[i + 1]], X[offs[j]:offs[j + 1]], scale, reg, n_threads=ncpu, return_info=True) for i, j in pairs]
+        dtc = time.perf_counter() - t
+        errs = [abs(v - W[i, j]) for (v, inf), (i, j) in zip(vals, pairs) if inf["iters"] < 1000]
+        cpu = {"value": round(len(pairs) / dtc, 4), "unit": "pairs/s", "cores": ncpu, "kind": "port",
+               "sample": "%d ordered pairs %s of the same cohort by oracle/pilot_oracle.c::pilot_oracle_cell_w2 (fp64, POT sinkhorn_log control "
+                         "flow, OpenMP inside a pair on %d threads), %s updates; max|gpu-oracle| on its converged pairs = %s"
+                         % (len(pairs), pairs, ncpu, [inf["iters"] for _, inf in vals], ("%.2e" % max(errs)) if errs else "n/a")}
+    traffic, traffic_src = None, None
+    tpath, trnd = profile_file("cellw2_traffic.json")
+    if tpath:
+        try:
+            with open(tpath) as fh:
+                e = json.load(fh).get("%dx%dx%d" % (Np, nc, D))
+            if e:
+                traffic, traffic_src = e["traffic_bytes"], "profiles/%s/cellw2_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this launch, git %s)" % (trnd, e.get("git", "?"))
+        except (OSError, ValueError, KeyError):
+            pass
     return {
         "metric": "cell-level W2 patient-pairs/sec (full NxN matrix; extension, BASELINE config 5)", "value": round(Np * Np / dt, 2),
         "unit": "pairs/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * dt, 1), "higher_is_better": True,
@@ -746,7 +890,7 @@ def bench_cellw2(args, reg=0.1, D=30):
         "roofline": {"bound": "mfma", "kernel": "pilot::cell_w2_kernel<1, true, %s>" % ("true" if pieces == 2 else "false"),
                      "achieved": round(flop * terms * Dp / D / kern_s / 1e12, 1),
                      "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flop * terms * Dp / D / kern_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                     "traffic": None, "kernel_ms": round(co.last_kernel_ms, 1),
+                     "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(co.last_kernel_ms, 1),
                      "note": "achieved = 16-bit MFMA flop executed: %d piece products per term (%s), "
                              "D padded to %d; the algorithmic (f32-equivalent) dot-product rate is 2 n_p n_q D per pass = %.1f TFLOP/s "
                              "(the f32-input MFMA peak is %.1f)" % (terms, "2 fp16 pieces of both operands" if pieces == 2 else
@@ -755,7 +899,7 @@ def bench_cellw2(args, reg=0.1, D=30):
                      "dot_tflops_f32_equivalent": round(flop / kern_s / 1e12, 2),
                      "mean_updates_per_pair": round(float(upd.mean()), 2)},
         "checks": {"pairs_converged": int(conv.sum()), "pairs": int(conv.size), "max_asymmetry_of_converged_pairs": sym},
-        "cpu_baseline": None,
+        "cpu_baseline": cpu,
     }
 
 
@@ -793,6 +937,9 @@ def bench_emd(args, L, P, M, cfg):
                              "the streaming-model bytes are what the north star names",
                      "mean_augmentations_per_solved_pair": round(float(n_aug[np.triu_indices(N)].mean()), 2)},
     }
+    acc = emd_instruction_accounting(args.config)
+    if acc:
+        out["instructions"] = acc
     if not args.no_cpu_baseline:
         ncpu = host_cores()
         step = max(1, N // 4)
