@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
 for k in sorted(acc, key=lambda k: -sum(dur.get(k, [0]))):
     if not k.startswith("sinkhorn") and not k.startswith("emd") and not k.startswith("cell_w2"):
         continue
-    print("== %s   dispatches=%d  mean duration (profiled) = %.1f us" % (k, len(dur.get(k, [])), sum(dur[k]) / max(1, len(dur[k]))))
+    print("== %s   dispatches=%d  mean duration (profiled) = %.1f us   max %.1f us" % (k, len(dur.get(k, [])), sum(dur[k]) / max(1, len(dur[k])), max(dur.get(k, [0]))))
     for c in sorted(acc[k]):
         v = acc[k][c]
-        print("   %-28s mean %.6g   (n=%d)" % (c, sum(v) / len(v), len(v)))
+        print("   %-28s mean %.6g   (n=%d)   max %.6g" % (c, sum(v) / len(v), len(v), max(v)))
