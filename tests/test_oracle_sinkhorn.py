@@ -128,3 +128,22 @@ def test_golden_fixtures_record_what_produced_their_ot_numbers(capsys):
     with capsys.disabled():
         print("\ngolden fixtures, ot_source: %s" % sorted(set(sources.values())))
     assert all(s == "oracle-shim" or s.startswith("pot==") for s in sources.values()), sources
+
+
+def test_pin_with_pot_tool_runs_end_to_end_in_self_test_mode():
+    """tools/pin_with_pot.py is the one command that closes "parity unpinned" for anybody who has POT.  POT is not importable
+    here, so the tool's plumbing is exercised against the oracle itself (--self-test never prints PINNED) -- including its list of
+    c3 / reg 0.01 pairs whose tau-absorption lands on the last update, which the tool re-checks against the oracle's flags --
+    and without POT it must say UNPINNED and exit 2."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_with_pot.py"), "--self-test", "--per-class", "3", "--rows", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SELF-TEST passed" in r.stdout and "PINNED:" not in r.stdout
+    assert "'absorb-on-last'" in r.stdout and "'nan-revert': 36" in r.stdout      # (3 of the 12 sparse rows x 12 columns: all of them revert)
+    try:
+        import ot  # noqa: F401
+    except Exception:
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_with_pot.py")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 2 and "UNPINNED" in r.stdout
