@@ -1,3 +1,5 @@
+"""Beyond 128 cell types (200 patients, reg 0.1, host arrays in -> out): Sinkhorn at K = 128 / 130 / 192 / 256 / 300 (one wave per tile, eight
+waves per tile, POT-literal kernel) and the exact grid across the same steps; parity against the oracle on sampled rows."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
