@@ -38,6 +38,44 @@ def test_sharded_matrix_is_bit_identical_to_the_single_device_one(c2, devices, g
     np.testing.assert_array_equal(Xm, X)                 # upper triangle solved per shard, mirrored after the gather
 
 
+def _n_devices():
+    return int(_lib.load().pilot_ot_device_count())
+
+
+@pytest.mark.skipif("_n_devices() < 2", reason="needs at least two visible GPUs (the 1-GPU boxes of this pool skip it; the first multi-GPU node runs it)")
+@pytest.mark.parametrize("gather", ["rccl", "copy"])
+def test_real_devices_rccl_all_gather_bit_identical_to_one_device(c2, gather):
+    """More than one PHYSICAL device: ncclCommInitAll over distinct devices, one host thread per shard on its own device, the
+    grouped ncclAllGather over xGMI (or peer copies), the row interleave on every device.  Every device count the node offers up to
+    eight, every grid entry point (Sinkhorn with its per-pair outputs, exact OT, the resident MultiPlan with c3 and its timers,
+    tl.wasserstein_distance with n_devices): the assembled matrix must be the single-device matrix bit for bit, and RCCL must report
+    as many ranks as devices were asked for."""
+    P, M, E, info, X = c2
+    n = min(_n_devices(), 8)
+    for g in sorted({2, n, (n // 2) or 2}):
+        if g > n:
+            continue
+        devs = list(range(g))
+        Em, im = multi.sinkhorn_grid_multi(P, M, 0.1, devices=devs, gather=gather, precision="fp32", return_info=True)
+        np.testing.assert_array_equal(Em, E)
+        for k in ("iters", "flags", "err"):
+            np.testing.assert_array_equal(im[k], info[k])
+        np.testing.assert_array_equal(multi.emd_grid_multi(P, M, devices=devs, gather=gather), X)
+    P3, M3 = make_problem(**CONFIGS["c3"])
+    ref = engine.sinkhorn_grid(P3, M3, 0.1, precision="auto")
+    mp = multi.MultiPlan(P3, M3, devices=list(range(n)), gather=gather)
+    for _ in range(3):
+        mp.sinkhorn(0.1)
+    np.testing.assert_array_equal(mp.fetch(), ref)
+    grid_ms, gather_ms = mp.times_ms()
+    assert grid_ms.shape == (n,) and (grid_ms > 0).all()
+    ranks, user_ranks = mp.rccl_info()
+    assert (ranks, user_ranks) == (([n] * n, list(range(n))) if gather == "rccl" else ([0] * n, [-1] * n))
+    mp.emd()
+    np.testing.assert_array_equal(mp.fetch(), engine.emd_grid(P3, M3))
+    mp.close()
+
+
 def test_rccl_with_repeated_devices_is_refused():
     P, M = make_problem(**CONFIGS["c1"])
     with pytest.raises(ValueError, match="distinct"):

@@ -1,5 +1,13 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Exact OT: would a better start than the diagonal save augmentations? (VERDICT r04 #1b; numpy prototype of the kernels' algorithm, CPU)
+
+Potentials carried from pair (i, j) to (i, j + 1): dual-feasible for any pair, and the previous optimal support is a set of tight
+arcs, so a greedy flow on it keeps complementary slackness -- against the fresh start (row minima + min(a_i, b_i) on the diagonal).
+A greedy row-minimum start is not on the table: with the zero-diagonal costs of this path the only tight arcs under the initial
+potentials ARE the diagonal.  Result (profiles/r05/emd_start_probe.txt): the reference test's cohort -20 % augmentations / -14 %
+steps, the c3 shape +16 % steps -- below the 30 % that would pay for the dependency between consecutive pairs: not built."""
+import os, sys, numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from conftest import GOLDEN_REAL, load_golden
 from oracle import oracle as O
 INF = float("inf")
