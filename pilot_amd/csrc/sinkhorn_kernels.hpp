@@ -1058,7 +1058,7 @@ constexpr int GREG_MAX = 64;
 #define PILOT_AREG_MAX_RT 4
 #endif
 #ifndef PILOT_SPLIT_OCC2_MAX_RT
-#define PILOT_SPLIT_OCC2_MAX_RT 6
+#define PILOT_SPLIT_OCC2_MAX_RT 4
 #endif
 #ifndef PILOT_SPLIT_OCC2_MAX_RT_TRACK
 #define PILOT_SPLIT_OCC2_MAX_RT_TRACK 4      // (K = 80 / 96 at reg 0.01: 160 -> 134 ms, 189 -> 146 ms with one wave and no spills; RT = 4: 32.5 -> 47.5 ms)
