@@ -240,7 +240,8 @@ struct pilot_ot_plan {
     int *flags_ws;     // per-pair flags when the caller passes none
     size_t flags_ws_n;
     int *emd_counter;  // 1: dynamic pair queue of the exact-EMD kernel
-    double *f_slab;    // exact-EMD flow values: one K*K block per resident wave
+    double *f_slab;    // exact-EMD flow values: one K*K block per resident wave (per 16-lane group of a wave for K <= 16); allocated by the
+    size_t f_slab_bytes;  // first exact-mode call that needs it -- a Sinkhorn-only plan never pays for it (164 MB at K = 50)
     double *emdg_slab; // K > 256: flow + label slab per resident workgroup of emd_generic_kernel, then K row minima (lazy)
     int emdg_wgs;
     double *kws;       // generic Sinkhorn kernel: K' and its transpose per workgroup (allocated on first use)
@@ -433,7 +434,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (!pl) return fail(PILOT_OT_EINVAL, "out of host memory");
     pl->N = N; pl->K = K; pl->max_cost = 1.0;
     pl->img = nullptr; pl->p_slot = nullptr; pl->track_list = nullptr; pl->track_count = nullptr;
-    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->emdg_slab = nullptr; pl->emdg_wgs = 0; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
+    pl->emd_counter = nullptr; pl->f_slab = nullptr; pl->f_slab_bytes = 0; pl->emdg_slab = nullptr; pl->emdg_wgs = 0; pl->n_cu = 256; pl->kws = nullptr; pl->generic_wgs = 0; pl->nan_list = nullptr; pl->nan_list_n = 0;
     pl->wide_rec = nullptr; pl->wide_rec_n = 0;
     pl->order_list = nullptr; pl->order_bucket = nullptr; pl->order_hist = nullptr;
     pl->flags_ws = nullptr; pl->flags_ws_n = 0;
@@ -472,10 +473,6 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     if (e == hipSuccess) pl->nan_list_n = (size_t)N * N;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->flags_ws), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) pl->flags_ws_n = (size_t)N * N;
-    if (e == hipSuccess && K <= EMD_MAX_K)
-        e = hipMalloc(reinterpret_cast<void **>(&pl->f_slab),
-                      sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)) *
-                          (K <= EMD_MULTI_MAX_K ? 4 : 1));   // (K <= 16: a slab per 16-lane GROUP of a wave)
     if (e != hipSuccess) {
         pilot_ot_plan_destroy(pl);
         return fail(PILOT_OT_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
@@ -1228,7 +1225,18 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.P = d_P; p.M = d_M; p.N = N; p.K = K;
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
     p.upper_only = mode != PILOT_OT_EMD_ALL;
-    p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = pl->f_slab; p.queue = pl->emd_counter;
+    p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = nullptr; p.queue = pl->emd_counter;
+    // the flow slab of the wave-per-pair kernels: grown on demand (the first call of a plan in a mode that needs it)
+    auto need_slab = [&](size_t bytes) -> int {
+        if (pl->f_slab_bytes < bytes) {
+            if (pl->f_slab) HIP_TRY(hipFree(pl->f_slab));
+            pl->f_slab = nullptr; pl->f_slab_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->f_slab), bytes));
+            pl->f_slab_bytes = bytes;
+        }
+        p.f_slab = pl->f_slab;
+        return PILOT_OT_OK;
+    };
     HIP_TRY(hipMemsetAsync(pl->emd_counter, 0, sizeof(int) * pilot::EMD_NQ * pilot::EMD_Q_STRIDE, s));
     const long total = (long)n_rows * N;
     if (K > EMD_MAX_K) {
@@ -1254,8 +1262,11 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         hipLaunchKernelGGL(pilot::emd_generic_kernel, dim3((unsigned)wgs), dim3(pilot::EMDG_WG), lds, s, p, rowmin);
     } else if (K <= EMD_MULTI_MAX_K && emd_multi_mode(K) != 0) {
         // four pairs per wavefront
-        if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
         const pilot::EmdMultiGeom m = pilot::emd_multi_geom(K, emd_multi_mode(K) != 2);
+        if (!m.flds) {      // (flow values in the global slab: a K x K block per 16-lane group of every resident wave)
+            const int rc = need_slab(sizeof(double) * (size_t)K * K * 4 * m.waves * m.wgs_per_cu * pl->n_cu);
+            if (rc != PILOT_OT_OK) return rc;
+        }
         const long groups = (total + (64 / m.G) - 1) / (64 / m.G);
         long wgs = (groups + m.waves - 1) / m.waves;
         const long cap = (long)pl->n_cu * m.wgs_per_cu;
@@ -1264,7 +1275,10 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * m.waves), m.lds, s, p);
     } else {
-        if (!pl->f_slab) return fail(PILOT_OT_ENOTSUP, "exact OT: no flow slab for K=%d", K);
+        {
+            const int rc = need_slab(sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K)));
+            if (rc != PILOT_OT_OK) return rc;
+        }
         const size_t lds = pilot::emd_lds_bytes(K);
         if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the LDS layout", K);
         const int waves = pilot::emd_waves(emd_nk(K));
@@ -1448,6 +1462,31 @@ template <typename T>
 int centroid_medians_impl(const void *X, const void *dXdev, long long C, int D, const int *cell_code, int K, double *centroids) {
     using U = typename pilot::OrderedKey<T>::U;
     using State = pilot::SelectState<U>;
+    // small cohorts: one launch, the selection in LDS (small_medians_kernel) -- when every type fits its key buffer and the
+    // K x D workgroups reading all C codes is a small amount of traffic (PILOT_OT_NO_SMALL_MEDIANS=1: the general path, tests)
+    if (C > 0 && (double)C * K * D <= 3.2e7 && !getenv("PILOT_OT_NO_SMALL_MEDIANS")) {
+        std::vector<unsigned int> n_k((size_t)K, 0u);
+        for (long long c = 0; c < C; ++c) { const int k = cell_code[c]; if (k >= 0 && k < K) ++n_k[(size_t)k]; }
+        unsigned int n_max = 0;
+        for (unsigned int v : n_k) n_max = v > n_max ? v : n_max;
+        if (n_max <= (unsigned int)pilot::SMALL_MEDIANS_CAP) {
+            DevBuf dX(0), dc(1), dout(8);
+            hipError_t e = dXdev ? hipSuccess : dX.alloc(sizeof(T) * (size_t)C * D);
+            if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
+            if (e == hipSuccess) e = dout.alloc(sizeof(double) * (size_t)K * D);
+            if (e == hipSuccess && !dXdev) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+            const size_t lds = sizeof(U) * (size_t)(n_max ? n_max : 1);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::small_medians_kernel<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(U) * pilot::SMALL_MEDIANS_CAP)));
+            hipLaunchKernelGGL(pilot::small_medians_kernel<T>, dim3((unsigned)(K * D)), dim3(256), lds, nullptr,
+                               static_cast<const T *>(dXdev ? dXdev : dX.p), D, dc.as<int>(), (long)C, K, dout.as<double>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(centroids, dout.p, sizeof(double) * (size_t)K * D, hipMemcpyDeviceToHost));
+            return PILOT_OT_OK;
+        }
+    }
     const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;      // dimensions per histogram launch
     const size_t lds = sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
     DevBuf dX(0), dc(1), dn(2), doffs(3), dcur(4), dperm(5), dst(6), dh(7), dout(8);

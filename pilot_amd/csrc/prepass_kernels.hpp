@@ -193,4 +193,68 @@ __global__ void select_finish_kernel(const unsigned int *__restrict__ n_k, int K
     centroids[idx] = double(m);
 }
 
+// SMALL cohorts (the reference test's own: 24 227 cells, 14 clusters, 14 features): the general path above is sixteen launches,
+// three memsets and two staging copies -- 1.1 ms for a few hundred microseconds' worth of data, a quarter of the whole
+// tl.wasserstein_distance call (profiles/r05/e2e_tl_wasserstein_distance_kidney.txt).  Here ONE launch does it: workgroup (k, d)
+// gathers the order-preserving keys of cell type k's values of dimension d into LDS (every workgroup reads all C codes: the host
+// takes this path only while C x K x D is small) and radix-selects the two middle elements there, 8 bits per pass, both
+// queries at once.  Same keys, same ranks, same final arithmetic as select_*_kernel: the same bits.
+constexpr int SMALL_MEDIANS_CAP = 8192;                 // cells of one type the LDS key buffer holds
+template <typename T>
+__global__ void __launch_bounds__(256) small_medians_kernel(const T *__restrict__ X, int D, const int *__restrict__ cell_code, long C, int K,
+                                                            double *__restrict__ centroids /* K x D */) {
+    using OK = OrderedKey<T>;
+    using U = typename OK::U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char small_medians_smem[];
+    U *keys = reinterpret_cast<U *>(small_medians_smem);
+    __shared__ unsigned int cnt, hist[2][256], rnk[2];
+    __shared__ U pref[2];
+    const int k = (int)blockIdx.x / D, d = (int)blockIdx.x % D;
+    if (threadIdx.x == 0) cnt = 0u;
+    __syncthreads();
+    for (long c = threadIdx.x; c < C; c += blockDim.x)
+        if (cell_code[c] == k) {
+            const unsigned int pos = atomicAdd(&cnt, 1u);
+            if (pos < (unsigned int)SMALL_MEDIANS_CAP) keys[pos] = OK::enc(X[(size_t)c * D + d]);
+        }
+    __syncthreads();
+    const unsigned int n = cnt;
+    if (n == 0u || n > (unsigned int)SMALL_MEDIANS_CAP) {       // an empty slice: NaN like pandas (beyond the cap: the host never sends such a cohort here)
+        if (threadIdx.x == 0) centroids[(size_t)k * D + d] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    if (threadIdx.x == 0) { pref[0] = pref[1] = U(0); rnk[0] = (n - 1u) / 2u; rnk[1] = n / 2u; }
+    for (int shift = OK::BITS - 8; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) (&hist[0][0])[i] = 0u;
+        __syncthreads();
+        const U himask = (shift + 8 >= OK::BITS) ? U(0) : (~U(0) << (shift + 8));
+        const U p0 = pref[0], p1 = pref[1];
+        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) {
+            const U key = keys[i];
+            const unsigned int digit = (unsigned int)(key >> shift) & 255u;
+            if ((key & himask) == p0) atomicAdd(&hist[0][digit], 1u);
+            if ((key & himask) == p1) atomicAdd(&hist[1][digit], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int q = threadIdx.x;
+            unsigned int rank = rnk[q], run = 0u;
+            int digit = 255;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned int c = hist[q][b];
+                if (rank < run + c) { digit = b; break; }
+                run += c;
+            }
+            pref[q] |= (U(digit) << shift);
+            rnk[q] = rank - run;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const T lo = OK::dec(pref[0]), hi = OK::dec(pref[1]);
+        const T m = (n & 1u) ? lo : T((lo + hi) * T(0.5));
+        centroids[(size_t)k * D + d] = double(m);
+    }
+}
+
 }  // namespace pilot

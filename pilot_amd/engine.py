@@ -122,7 +122,13 @@ def proportions_and_first_rows(cell_code, sample_code, n_samples, n_types, regul
 
 class EmbeddingUpload:
     """The C x D embedding on its way to the device: the copy runs on a helper thread (ctypes releases the GIL) while the
-    caller factorises the label columns; :meth:`medians` joins it and runs the device radix select."""
+    caller factorises the label columns; :meth:`medians` joins it and runs the device radix select.
+
+    A SMALL embedding (below ``SMALL_BYTES``: the reference test's own cohort is 1.3 MB) is not worth a thread, a device
+    allocation and the ``hipFree`` that synchronises the device at the end -- 0.4 ms of a 2.8 ms call: it goes up inside
+    :meth:`medians`, through the calling thread's buffer pool (``pilot_ot_centroid_medians`` on the host array)."""
+
+    SMALL_BYTES = 4 << 20
 
     def __init__(self, X):
         import threading
@@ -141,6 +147,9 @@ class EmbeddingUpload:
         dev = ctypes.c_int(0)
         _lib.check(self.L.pilot_ot_get_device(ctypes.byref(dev)))
         self.device = dev.value
+        self.thread = None
+        if self.X.nbytes < self.SMALL_BYTES:
+            return
 
         def work():
             try:
@@ -154,6 +163,8 @@ class EmbeddingUpload:
         self.thread.start()
 
     def medians(self, cell_code, n_types):
+        if self.thread is None:
+            return centroid_medians(self.X, cell_code, n_types)
         self.thread.join()
         if self.err is not None:
             raise self.err
@@ -165,7 +176,8 @@ class EmbeddingUpload:
         return out
 
     def close(self):
-        self.thread.join()
+        if self.thread is not None:
+            self.thread.join()
         if self.h:
             self.L.pilot_ot_embedding_destroy(self.h)
             self.h = ctypes.c_void_p()

@@ -353,10 +353,12 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     X = data.to_numpy()
     upload = engine.EmbeddingUpload(X)
     own = np.empty_like(X)
-    n_copy = 4 if X.size >= (1 << 22) else 1
-    bounds = np.linspace(0, X.shape[0], n_copy + 1).astype(np.int64)
+    n_copy = 4 if X.size >= (1 << 22) else (1 if X.nbytes >= (4 << 20) else 0)
+    bounds = np.linspace(0, X.shape[0], max(n_copy, 1) + 1).astype(np.int64)
     copiers = [threading.Thread(target=np.copyto, args=(own[a:b], X[a:b]), name="pilot_amd_data_copy")
-               for a, b in zip(bounds[:-1], bounds[1:])]
+               for a, b in zip(bounds[:-1], bounds[1:])] if n_copy else []
+    if not n_copy:
+        np.copyto(own, X)          # (a small embedding: a thread costs more than the copy)
     for t in copiers:
         t.start()
     dev = {}

@@ -293,6 +293,36 @@ def test_centroid_medians_exact(dtype, C, D, K):
             np.testing.assert_array_equal(got[k], np.median(rows, axis=0).astype(np.float64))   # median in X's dtype
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_small_cohort_medians_in_one_launch_give_the_general_path_s_bits(dtype, monkeypatch):
+    """Small cohorts (C x K x D <= 3.2e7 and no cell type beyond 8192 cells) select their medians in ONE launch, in LDS
+    (small_medians_kernel); the general path (PILOT_OT_NO_SMALL_MEDIANS=1) is sixteen launches.  Same keys, ranks and final
+    arithmetic: the same bits, with ties, signed zeros, infinities, an empty type, one-cell types, an even / odd split -- and a
+    cohort with one type beyond the cap must take the general path by itself."""
+    rng = np.random.default_rng(5)
+    for C, D, K in ((24227, 14, 14), (5000, 3, 40), (9, 2, 4)):
+        X = (rng.standard_normal((C, D)) * 3).astype(dtype)
+        X[rng.random((C, D)) < 0.1] = 0.0
+        X[rng.random((C, D)) < 0.03] *= -0.0
+        X[rng.random((C, D)) < 0.01] = np.inf
+        cc = rng.integers(0, K - 1, C).astype(np.int32)             # type K - 1 stays empty
+        cc[:3] = [0, 1, 1]
+        fast = engine.centroid_medians(X, cc, K)
+        monkeypatch.setenv("PILOT_OT_NO_SMALL_MEDIANS", "1")
+        slow = engine.centroid_medians(X, cc, K)
+        monkeypatch.delenv("PILOT_OT_NO_SMALL_MEDIANS")
+        np.testing.assert_array_equal(fast, slow)
+        assert np.isnan(fast[K - 1]).all()
+        for k in range(K - 1):
+            np.testing.assert_array_equal(fast[k], np.median(X[cc == k], axis=0).astype(np.float64))
+    C, D, K = 20000, 2, 2                                             # 12 000 cells of one type: beyond the LDS key buffer
+    X = rng.standard_normal((C, D)).astype(dtype)
+    cc = (np.arange(C) >= 12000).astype(np.int32)
+    got = engine.centroid_medians(X, cc, K)
+    for k in range(K):
+        np.testing.assert_array_equal(got[k], np.median(X[cc == k], axis=0).astype(np.float64))
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_centroid_medians_match_the_reference_pandas_medians(name):
     g = load_golden(name)

@@ -67,6 +67,11 @@ def test_wasserstein_distance_from_concurrent_threads_and_short_lived_callers():
     for k in range(8):                                      # warm: code objects, runtime pools
         t = threading.Thread(target=short, args=(k,)); t.start(); t.join()
     _lib.check(_lib.load().pilot_ot_shutdown())
+    # (the shutdown above also releases what the MAIN thread held from earlier tests; when that hands a whole chunk back to the
+    # HIP runtime's sub-allocator, the next caller makes the runtime reserve a fresh one -- 120 MB seen -- that outlives a
+    # shutdown: one more caller + shutdown puts the measurement on both sides of the same allocator state)
+    t = threading.Thread(target=short, args=(8,)); t.start(); t.join()
+    _lib.check(_lib.load().pilot_ot_shutdown())
     m1 = free_mem()
     for k in range(24):
         t = threading.Thread(target=short, args=(k,)); t.start(); t.join()
