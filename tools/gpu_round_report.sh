@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything the round commits under profiles/: usage tools/gpu_round_report.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/report_$TAG
 mkdir -p $O
@@ -31,7 +31,9 @@ python tools/big_k_probe.py > $O/big_k_probe.txt 2>&1
 python tools/mid_reg_probe.py > $O/mid_reg_probe.txt 2>&1
 python tools/sinkhorn_full_grid_check.py 2>&1 | grep -v "^make" > $O/sinkhorn_full_grid_check.txt
 python tools/emd_full_grid_check.py c2 c3 c4 2>&1 | grep -v "^make" > $O/emd_full_grid_check.txt
-for p in 2 4 12 real 30 50 64 100 160 256; do python tools/emd_point.py $p; done > $O/emd_points.txt 2>&1
+for p in 2 4 8 12 real 14 16 17 30 50 64 65 100 128 129 160 256; do python tools/emd_point.py $p; done > $O/emd_points.txt 2>&1
+python tools/emd_multi_probe.py 2 4 8 12 real 14 15 16 > $O/emd_multi_probe.txt 2>&1
+python tools/e2e_profile.py real > $O/e2e_tl_wasserstein_distance_kidney.txt 2>&1
 python tools/emd_point.py 100 2000 >> $O/emd_points.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
@@ -52,20 +54,14 @@ cp $O/stats_k80/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_k80.csv 2>/dev/nu
 cp $O/stats_k96/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_k96.csv 2>/dev/null
 bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc --no-extras > /dev/null 2>&1
 cp $O/pmc/summary.txt $O/rocprofv3_pmc_summary_bench_c3.txt
-bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_emd --mode emd > /dev/null 2>&1
-cp $O/pmc_emd/summary.txt $O/rocprofv3_pmc_summary_emd_c3.txt
+# exact-OT kernels (c3, the reference test's cohort, the K = 64/65 and 128/129 steps) and the cell-level kernel's traffic:
+# rocprofv3_pmc_summary_emd_*.txt, emd_instr.json, cellw2_traffic.json
+bash tools/emd_round_profiles.sh gpurun_out/report_$TAG > /dev/null 2>&1
 BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k80 80 > /dev/null 2>&1
 cp $O/pmc_k80/summary.txt $O/rocprofv3_pmc_summary_k80.txt
 BENCH_PY=tools/k_point.py bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_k96 96 > /dev/null 2>&1
 cp $O/pmc_k96/summary.txt $O/rocprofv3_pmc_summary_k96.txt
-bash tools/profile_pmc_scalar.sh gpurun_out/report_$TAG/pmc_emd_sca --mode emd > /dev/null 2>&1
-cp $O/pmc_emd_sca/summary.txt $O/rocprofv3_pmc_scalar_emd_c3.txt
-rm -rf $O/pmc_emd_sca
 bash tools/emd_prof_builds.sh c3 > $O/emd_prof_c3.txt 2>&1
-PILOT_OT_EMD_LDS_FLOW=1 bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc_emd_lf --mode emd > /dev/null 2>&1
-cp $O/pmc_emd_lf/summary.txt $O/rocprofv3_pmc_summary_emd_c3_lds_flow.txt
-rm -rf $O/pmc_emd_lf
-for p in 4 12 real 30 50 60; do PILOT_OT_EMD_LDS_FLOW=1 python tools/emd_point.py $p; done > $O/emd_points_lds_flow.txt 2>&1
 python tools/make_traffic_json.py $O > $O/traffic.json
 # the other rungs of the precision ladder: kernel-trace average + the PMC passes, merged into traffic.json
 for prec in fp32 bf16x3 fp64; do
@@ -76,5 +72,8 @@ for prec in fp32 bf16x3 fp64; do
   TRAFFIC_SUFFIX=_$prec python tools/make_traffic_json.py $O > $O/traffic.json.new && mv $O/traffic.json.new $O/traffic.json
   rm -rf $O/stats_$prec $O/pmc_$prec
 done
-rm -rf $O/stats $O/stats_emd $O/stats_emd_c4 $O/stats_cellw2 $O/stats_cons $O/stats_k80 $O/stats_k96 $O/pmc $O/pmc_emd $O/pmc_k80 $O/pmc_k96
+rm -rf $O/stats $O/stats_emd $O/stats_emd_c4 $O/stats_cellw2 $O/stats_cons $O/stats_k80 $O/stats_k96 $O/pmc $O/pmc_k80 $O/pmc_k96
+# fuzz campaigns of the round (random shapes / options / degenerate inputs against the oracle, scipy and scikit-learn)
+{ for f in "fuzz_emd.py 150 51" "fuzz_sinkhorn.py 80 52" "fuzz_prepass.py 60 53" "fuzz_consumers.py 60 54" "fuzz_multi.py 40 55" "fuzz_cellw2.py 20 56"; do
+    echo "== tools/$f"; timeout 900 python tools/$f 2>&1 | tail -3; done; } > $O/fuzz_campaigns.txt 2>&1
 cat $O/pytest_gpu.txt $O/smoke.txt; cut -c1-700 $O/bench_c3_reg0.1_n1.json; head -6 $O/rocprofv3_kernel_stats_bench_c3.csv; cat $O/traffic.json
