@@ -70,6 +70,21 @@ def test_emd_four_pairs_per_wave_kernel_against_the_one_pair_kernel(K, monkeypat
     np.testing.assert_array_equal(engine.emd_grid(P, M, mode="all"), res["1"])          # the default is one of the two
 
 
+@pytest.mark.parametrize("K", [2, 5, 9, 13, 16])
+def test_emd_whole_grids_at_small_k_against_the_network_simplex(K):
+    """tools/emd_multi_probe.py at test size: EVERY pair of a 300-patient grid (45 150 solved pairs: two hundred pairs per 16-lane
+    group, so every group refills, finishes and idles at the end of the queue many times) against the oracle's network simplex --
+    a different algorithm; symmetric, zero diagonal, no guard tripped; a round-robin row shard in `upper` mode gives the same bits."""
+    P, M = make_problem(300, K, 8, seed=K, cells_per_patient=200)
+    E, info = engine.emd_grid(P, M, return_info=True)
+    assert (info["n_aug"][np.triu_indices(300)] >= 0).all()
+    assert np.abs(E - O.emd_grid(P, M, n_threads=16, fast="ns")).max() <= 1e-12
+    assert np.array_equal(E, E.T) and np.abs(np.diag(E)).max() == 0.0
+    rows = np.arange(1, 300, 4)
+    np.testing.assert_array_equal(engine.emd_grid(P, M, row_begin=1, row_step=4, mode="upper"),
+                                  np.where(np.arange(300)[None, :] >= rows[:, None], E[rows], 0.0))
+
+
 def test_emd_four_pairs_per_wave_kernel_on_the_reference_cohort(monkeypatch):
     """Every pair of the reference test's own cohort (Kidney_IgAN_G: 634 patients x 14 clusters, up to 101 augmentations per
     pair) against the oracle's network simplex, and against the one-pair-per-wave kernel augmentation for augmentation."""
