@@ -26,6 +26,33 @@ __device__ inline void mfma_block_seq(f32x4_t (&c)[4], f16x8_t x, f16x8_t y) {  
 #pragma unroll
         for (int i = 0; i < 6; ++i) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c[j], 0, 0, 0);
 }
+using f32x16_t = float __attribute__((ext_vector_type(16)));
+// the same flop as two mfma_block calls on HALF the instructions: 24 x v_mfma_f32_32x32x16_f16, four independent chains
+__device__ inline void mfma_block32(f32x16_t (&c)[4], f16x8_t x, f16x8_t y) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c[j], 0, 0, 0);
+}
+// mode 6 / 7 (round 5): ONE wave does the work two waves do in mode 3 -- 24 32x32x16 MFMAs (= 48 16x16x32) and 176 VALU per iteration
+// (7: the VALU in two halves around the MFMAs)
+__global__ void k32(float *out, const float *in, int iters, int mode) {
+    float a0 = in[threadIdx.x % 64], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float b = in[64 + threadIdx.x % 64];
+    f16x8_t x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)in[i]; y[i] = (_Float16)in[8 + i]; }
+    f32x16_t c[4];
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) c[j][e] = 0.f;
+    for (int i = 0; i < iters; ++i) {
+        if (mode == 7) valu_block(a0, a1, a2, a3, a4, a5, a6, a7, b);
+        mfma_block32(c, x, y);
+        valu_block(a0, a1, a2, a3, a4, a5, a6, a7, b);
+        if (mode != 7) valu_block(a0, a1, a2, a3, a4, a5, a6, a7, b);
+    }
+    float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) s += c[j][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 // mode 0: VALU only; 1: MFMA only; 2: even waves VALU, odd waves (by wave / 4: the SIMD partner) MFMA; 3: alternate in every wave
 __global__ void k(float *out, const float *in, int iters, int mode) {
     float a0 = in[threadIdx.x % 64], a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
@@ -67,6 +94,19 @@ int main() {
                 hipEventElapsedTime(&ms, e0, e1);
             }
             printf("%-50s %d waves/SIMD: %8.1f ns per iteration per wave  (%.1f ns per SIMD per wave-iteration)\n", names[mode], threads / 256, ms * 1e6 / iters, ms * 1e6 / iters / (threads / 256));
+        }
+    printf("\nround 5: the work of TWO mode-3 waves (48 16x16x32 MFMAs + 176 VALU) in ONE wave with 24 32x32x16 MFMAs\n");
+    for (int mode = 6; mode <= 7; ++mode)
+        for (int threads = 256; threads <= 512; threads *= 2) {
+            float ms = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(k32, dim3(256), dim3(threads), 0, 0, d_out, d_in, iters, mode);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("%-50s %d waves/SIMD: %8.1f ns per iteration per wave  (%.1f ns per SIMD per 48-MFMA16-equivalent + 176 VALU)\n",
+                   mode == 6 ? "24 MFMA 32x32x16 then 176 VALU" : "88 VALU, 24 MFMA 32x32x16, 88 VALU", threads / 256, ms * 1e6 / iters, ms * 1e6 / iters / (threads / 256));
         }
     return 0;
 }
