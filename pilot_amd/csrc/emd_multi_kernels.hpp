@@ -2,24 +2,25 @@
 // Replaces the ot.emd2 loop of pilotpy/tools/Trajectory.py:507-511 (the reference's DEFAULT mode) where real cohorts live:
 // the reference test's own cohort has 14 clusters (test/test_pilot.py:9-23), PILOT's tutorials 10 - 30 cell types.
 //
-// emd_grid_kernel (emd_kernels.hpp) gives a pair a whole wavefront: at K = 14 that is 14 of 64 lanes, and the wave-uniform
-// bookkeeping of a search (queue, path walk, masks) runs once per pair on the scalar unit.  Here a wavefront is cut into
-// 64 / G GROUPS of G lanes (G = 16: four pairs per wave, K <= 16; G = 32: two pairs, K <= 32) and each group solves a pair
-// of its own with the same algorithm -- successive shortest augmenting paths from every row with supply left, node
-// potentials, every column tied at the smallest label scanned in one step, several augmentations per search while the tree
-// is valid, diagonal warm start, initial labels of a search cached while the source set stands -- and the same fp64
-// arithmetic for labels and potentials (labels kept plus the column potential, clamped to the previous step's label).
+// emd_grid_kernel (emd_kernels.hpp) gives a pair a whole wavefront: at K = 14 that is 14 of 64 lanes.  Here a wavefront is cut
+// into 64 / G GROUPS of G lanes and each group solves a pair of its own with the same algorithm -- successive shortest
+// augmenting paths from every row with supply left, node potentials, every column tied at the smallest label scanned in one
+// step, several augmentations per search while the tree is valid, diagonal warm start, initial labels of a search cached while
+// the source set stands -- and the same fp64 arithmetic for labels and potentials (labels kept plus the column potential,
+// clamped to the previous step's label): a pair takes the same augmentations and comes out equal to rounding.
+// G = 16 (four pairs per wave, K <= 16) is what is instantiated; G = 32 (two pairs, K <= 32) compiles and measured slower than one
+// pair per wave at every K (profiles/r05/ab_experiments.md #1).
 //   * lane c of a group owns row c and column c of its pair: supply, demand, potentials, label, predecessor links in registers;
-//   * what is wave-uniform in the one-pair kernel is GROUP-uniform here and lives replicated in the group's lanes: a group's
-//     bit masks are fields of a wave ballot, its minimum is a four-stage DPP butterfly inside the 16-lane row
-//     (quad_perm, row_half_mirror, row_mirror; v_permlane16_swap joins two rows for G = 32), a value of lane i of the group is
-//     fetched with ds_bpermute;
-//   * control flow is plain SIMT with group-uniform conditions: the groups of a wave run their steps in lockstep, a group's
-//     inner loops (rows to relax, targets, path hops) cost the wave the longest of its groups, and a group that starts a new
-//     search or a new pair does so at the top of the step loop while the others go on;
+//   * a group's minimum is a four-stage DPP butterfly inside the 16-lane row (quad_perm, row_half_mirror, row_mirror;
+//     v_permlane16_swap joins two rows for G = 32), a value of lane i of the group is fetched with ds_bpermute;
+//   * lane = node number for all groups at once, so the node sets of a search are 64-bit WAVE masks on the scalar unit and the
+//     control flow is one loop with wave-uniform branches and group-uniform predicates (see emd_multi_kernel below): the groups
+//     run their steps in lockstep, and a group that starts a new search or a new pair does so at the top of the loop while the
+//     others go on;
+//   * an augmentation walks nothing: labels carry the bit mask of their tree path (see below);
 //   * a group draws its pairs one by one from the sharded device-wide queue of emd_grid_kernel, so a pair's bits do not depend
 //     on its slot mates, its wave or the row subset of the call;
-//   * flow values: K x K doubles per group in LDS (G = 16) or in the L2-resident global slab (G = 32), zero outside the support,
+//   * flow values: K x K doubles per group in LDS (up to K = 15) or in the L2-resident global slab, zero outside the support,
 //     put back to zero through the support masks when a pair is done; the support itself is a bit mask per row in registers.
 #pragma once
 #include <type_traits>
