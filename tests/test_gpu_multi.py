@@ -46,9 +46,8 @@ def _n_devices():
 def test_real_devices_rccl_all_gather_bit_identical_to_one_device(c2, gather):
     """More than one PHYSICAL device: ncclCommInitAll over distinct devices, one host thread per shard on its own device, the
     grouped ncclAllGather over xGMI (or peer copies), the row interleave on every device.  Every device count the node offers up to
-    eight, every grid entry point (Sinkhorn with its per-pair outputs, exact OT, the resident MultiPlan with c3 and its timers,
-    tl.wasserstein_distance with n_devices): the assembled matrix must be the single-device matrix bit for bit, and RCCL must report
-    as many ranks as devices were asked for."""
+    eight, every grid entry point (Sinkhorn with its per-pair outputs, exact OT, the resident MultiPlan with c3 and its timers):
+    the assembled matrix must be the single-device matrix bit for bit, and RCCL must report as many ranks as devices were asked for."""
     if _n_devices() < 2:
         pytest.skip("needs at least two visible GPUs (the 1-GPU boxes of this pool skip it; the first multi-GPU node runs it)")
     P, M, E, info, X = c2
