@@ -118,6 +118,18 @@ int pilot_ot_memcpy_h2d(void *dst, const void *src, unsigned long long bytes);
 int pilot_ot_memcpy_d2h(void *dst, const void *src, unsigned long long bytes);
 int pilot_ot_stream_sync(void *stream);
 
+/* ---- label columns -> codes (host only, no device work) -------------------------------------- */
+/* Numbers the n labels of one column in order of first appearance: what annot.cell_type.unique() /
+ * annot.sampleID.unique() plus one boolean mask per label amount to (Trajectory.py:402-425).
+ * ids: the labels as fixed-width integers: id_bytes = 1, 2, 4 -- signed, negative = missing (the codes of a pandas
+ *      Categorical, what AnnData stores for obs labels); id_bytes = 8 -- opaque 64-bit identities, 0 = missing (the object
+ *      pointers of an object column: a cohort's 1.8 M labels are a few hundred distinct Python objects).
+ * codes: n int32 out, -1 for missing; first_rows[j]: row where code j first appears (max_uniques entries);
+ * *n_uniques: how many codes.  More than max_uniques distinct labels -> PILOT_OT_ENOTSUP.
+ * n_threads >= 1 host threads share the pass (slices side by side, their first-appearance lists merged in order). */
+int pilot_ot_label_codes(const void *ids, int id_bytes, long long n, int max_uniques, int n_threads, int *codes,
+                         long long *first_rows, int *n_uniques);
+
 /* ---- pre-pass: replaces the pandas loops of Cluster_Representations and cost_matrix ---------- */
 /* cell_code / sample_code: per cell, index of its cell type / sample in FIRST-APPEARANCE order
  * (what Series.unique() yields, Trajectory.py:402,412); negative codes (missing values) are skipped.
@@ -143,6 +155,11 @@ typedef struct pilot_ot_embedding pilot_ot_embedding;
 int pilot_ot_embedding_upload(const void *X, int dtype, long long n_cells, int D, pilot_ot_embedding **emb);
 int pilot_ot_embedding_destroy(pilot_ot_embedding *emb);
 int pilot_ot_centroid_medians_dev(pilot_ot_embedding *emb, const int *cell_code, int K, double *centroids);
+/* The whole device pre-pass of wasserstein_distance from ONE upload of the two code columns (emb->C entries each):
+ * proportions P (N x K), first rows (nullable) and centroids (K x D) as the three calls above give them, bit for bit --
+ * Cluster_Representations (Trajectory.py:377-436), return_real_labels (:617-642), the medians of cost_matrix (:462-466). */
+int pilot_ot_prepass_dev(pilot_ot_embedding *emb, const int *cell_code, const int *sample_code, long long n_total, int N, int K,
+                         double regulizer, int normalization, double *P, long long *first_row, double *centroids);
 
 /* ---- cost matrix: replaces scipy pdist+squareform at Trajectory.py:468-469 ------------------ */
 /* centroids: K x D row-major (per-cell-type medians, Trajectory.py:465-466).  cost: K x K,

@@ -1387,6 +1387,137 @@ int current_cu_count() {
 }
 }  // namespace
 
+namespace {
+// ---- the device pre-pass, carved out of ONE pooled workspace (slot 1 of the calling thread's pool) ----------------------
+// head (cleared by one memset): counts N*K | first_row N | n_k K | cursor K | n_items 1 | global histograms K*D*2*256
+// then: prior K | P N*K | segment starts K | select items | select state | centroids K*D | codes | grouped keys
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+struct PrepassWs {
+    // what the caller asks for
+    bool want_counts = false, want_medians = false;
+    long long C = 0; int N = 0, K = 0, D = 0, n_cu = 256; size_t key_bytes = 4;
+    int n_code_cols = 1;
+    // derived
+    long R = 0, max_items = 0;
+    size_t o_counts = 0, o_first = 0, o_nk = 0, o_cursor = 0, o_nitems = 0, o_hist = 0, clear_bytes = 0, o_prior = 0, o_P = 0, o_offs = 0,
+           o_items = 0, o_st = 0, o_out = 0, o_code = 0, o_y = 0, total = 0;
+    void carve() {
+        size_t o = 0;
+        auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+        o_counts = take(want_counts ? sizeof(unsigned int) * (size_t)N * K : 0);
+        o_first = take(want_counts ? sizeof(unsigned int) * (size_t)N : 0);
+        o_nk = take(sizeof(unsigned int) * K);
+        o_cursor = take(sizeof(unsigned int) * K);
+        o_nitems = take(sizeof(unsigned int));
+        if (want_medians) {
+            const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;
+            // rows per select item: about 64 K keys a block, fewer while that leaves CUs without a block; a multiple of 4
+            R = 65536 / Dw_max;
+            const long R_fill = (long)(C / (2LL * n_cu));
+            if (R > R_fill) R = R_fill;
+            if (R < 64) R = 64;
+            R = (R + 3) & ~3L;
+            max_items = (long)(C / R) + K + 1;
+            o_hist = take(sizeof(unsigned int) * (size_t)K * D * 2 * 256);
+        } else {
+            o_hist = o;
+        }
+        clear_bytes = o;
+        o_prior = take(want_counts ? sizeof(double) * (size_t)K : 0);
+        o_P = take(want_counts ? sizeof(double) * (size_t)N * K : 0);
+        o_offs = take(sizeof(unsigned int) * K);
+        o_items = take(want_medians ? sizeof(pilot::SelectItem) * (size_t)max_items : 0);
+        o_st = take(want_medians ? (key_bytes + 8) * (size_t)K * D * 2 : 0);
+        o_out = take(want_medians ? sizeof(double) * (size_t)K * D : 0);
+        o_code = take(sizeof(int) * (size_t)C * n_code_cols);
+        o_y = take(want_medians ? key_bytes * ((size_t)C + 4 * (size_t)K) * D : 0);
+        total = o;
+    }
+};
+
+// counts + first rows + n_k from device-resident codes, then the proportions: three launches
+void launch_counts(const PrepassWs &ws, unsigned char *w, const int *d_cell, const int *d_sample, long long n_total, double regulizer,
+                   int normalization, bool want_first) {
+    const long nchunks = (long)((ws.C + pilot::COUNT_CHUNK - 1) / pilot::COUNT_CHUNK);
+    long grid = 4L * ws.n_cu;
+    if (grid > nchunks) grid = nchunks;
+    if (grid < 1) grid = 1;
+    unsigned int *counts = reinterpret_cast<unsigned int *>(w + ws.o_counts);
+    const size_t lds = sizeof(unsigned int) * ((size_t)pilot::COUNT_LDS_BINS + pilot::COUNT_LDS_ROWS + ws.K + 16);
+    hipLaunchKernelGGL(pilot::count_kernel, dim3((unsigned)grid), dim3(256), lds, nullptr, d_cell, d_sample, (long)ws.C, ws.N, ws.K, counts,
+                       reinterpret_cast<unsigned int *>(w + ws.o_nk), want_first ? reinterpret_cast<unsigned int *>(w + ws.o_first) : nullptr);
+    hipLaunchKernelGGL(pilot::prior_kernel, dim3((unsigned)((ws.K + 3) / 4)), dim3(256), 0, nullptr, counts, ws.N, ws.K, (long)n_total, regulizer,
+                       reinterpret_cast<double *>(w + ws.o_prior));
+    hipLaunchKernelGGL(pilot::proportions_kernel, dim3((unsigned)((ws.N + 3) / 4)), dim3(256), 0, nullptr, counts, ws.N, ws.K,
+                       reinterpret_cast<const double *>(w + ws.o_prior), normalization, reinterpret_cast<double *>(w + ws.o_P));
+}
+
+// the general median path (prepass_kernels.hpp): [count,] prep, group the rows by type, BITS/8 x (histogram, pick)
+template <typename T>
+int launch_medians(const PrepassWs &ws, unsigned char *w, const T *dXp, const int *d_cell, bool have_nk) {
+    using U = typename pilot::OrderedKey<T>::U;
+    using State = pilot::SelectState<U>;
+    static_assert(sizeof(State) <= sizeof(U) + 8, "select state larger than its carve");
+    const int K = ws.K, D = ws.D;
+    const long long C = ws.C;
+    unsigned int *d_nk = reinterpret_cast<unsigned int *>(w + ws.o_nk), *d_cursor = reinterpret_cast<unsigned int *>(w + ws.o_cursor),
+                 *d_nitems = reinterpret_cast<unsigned int *>(w + ws.o_nitems), *d_hist = reinterpret_cast<unsigned int *>(w + ws.o_hist),
+                 *d_offs = reinterpret_cast<unsigned int *>(w + ws.o_offs);
+    pilot::SelectItem *d_items = reinterpret_cast<pilot::SelectItem *>(w + ws.o_items);
+    State *d_st = reinterpret_cast<State *>(w + ws.o_st);
+    double *d_out = reinterpret_cast<double *>(w + ws.o_out);
+    U *d_y = reinterpret_cast<U *>(w + ws.o_y);
+    const long nb = (long)((C + pilot::GROUP_ROWS_PER_BLOCK - 1) / pilot::GROUP_ROWS_PER_BLOCK);
+    if (!have_nk) {
+        long g = 2L * ws.n_cu;
+        if (g > nb) g = nb;
+        hipLaunchKernelGGL(pilot::type_count_kernel, dim3((unsigned)g), dim3(256), sizeof(unsigned int) * K, nullptr, d_cell, (long)C, K, d_nk);
+    }
+    hipLaunchKernelGGL(pilot::median_prep_kernel, dim3(1), dim3(256), sizeof(unsigned int) * (2 * (size_t)K + 2 + 257), nullptr, d_nk, K,
+                       (unsigned int)ws.R, d_offs, d_nitems, d_items);
+    hipLaunchKernelGGL(pilot::group_rows_kernel<T>, dim3((unsigned)nb), dim3(256),
+                       sizeof(unsigned int) * (2 * (size_t)K + pilot::GROUP_ROWS_PER_BLOCK), nullptr, dXp, D, d_cell, (long)C, K, d_offs, d_cursor, d_y);
+    const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;      // dimensions per histogram launch
+    const size_t lds = sizeof(U) * 2 * (size_t)Dw_max + sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::select_hist_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned pick_blocks = (unsigned)(((size_t)K * D * 64 + 255) / 256);
+    for (int shift = pilot::OrderedKey<T>::BITS - 8; shift >= 0; shift -= 8) {
+        for (int dbeg = 0; dbeg < D; dbeg += Dw_max) {           // any D: the dimensions in windows that fit the LDS histograms
+            const int Dw = D - dbeg < Dw_max ? D - dbeg : Dw_max;
+            hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)ws.max_items), dim3(pilot::SELECT_THREADS),
+                               sizeof(U) * 2 * (size_t)Dw + sizeof(unsigned int) * (size_t)Dw * 2 * 256, nullptr, d_y, D, dbeg, Dw,
+                               d_nitems, d_items, shift, d_st, d_hist);
+        }
+        hipLaunchKernelGGL(pilot::select_pick_kernel<T>, dim3(pick_blocks), dim3(256), 0, nullptr, d_nk, K, D, shift, d_st, d_hist, d_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return PILOT_OT_OK;
+}
+
+// small cohorts: one launch, the selection in LDS (small_medians_kernel) -- when every type fits its key buffer and the
+// K x D workgroups reading all C codes is a small amount of traffic (PILOT_OT_NO_SMALL_MEDIANS=1: the general path, tests)
+bool small_medians_fit(long long C, int D, const int *cell_code, int K, unsigned int *n_max_out) {
+    if (!(C > 0 && (double)C * K * D <= 3.2e7) || getenv("PILOT_OT_NO_SMALL_MEDIANS")) return false;
+    std::vector<unsigned int> n_k((size_t)K, 0u);
+    for (long long c = 0; c < C; ++c) { const int k = cell_code[c]; if (k >= 0 && k < K) ++n_k[(size_t)k]; }
+    unsigned int n_max = 0;
+    for (unsigned int v : n_k) n_max = v > n_max ? v : n_max;
+    *n_max_out = n_max;
+    return n_max <= (unsigned int)pilot::SMALL_MEDIANS_CAP;
+}
+template <typename T>
+int launch_small_medians(const T *dXp, long long C, int D, const int *d_cell, int K, unsigned int n_max, double *d_out) {
+    using U = typename pilot::OrderedKey<T>::U;
+    const size_t lds = sizeof(U) * (size_t)(n_max ? n_max : 1);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::small_medians_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(U) * pilot::SMALL_MEDIANS_CAP)));
+    hipLaunchKernelGGL(pilot::small_medians_kernel<T>, dim3((unsigned)(K * D)), dim3(256), lds, nullptr, dXp, D, d_cell, (long)C, K, d_out);
+    HIP_TRY(hipGetLastError());
+    return PILOT_OT_OK;
+}
+}  // namespace
+
 PILOT_API int pilot_ot_proportions(const int *cell_code, const int *sample_code, long long n_cells, long long n_total,
                                    int N, int K, double regulizer, int normalization, double *P) {
     return pilot_ot_proportions_ex(cell_code, sample_code, n_cells, n_total, N, K, regulizer, normalization, P, nullptr);
@@ -1399,34 +1530,30 @@ PILOT_API int pilot_ot_proportions_ex(const int *cell_code, const int *sample_co
     if (N <= 0 || K <= 0 || n_cells < 0 || n_total < 2)
         return fail(PILOT_OT_EINVAL, "N=%d K=%d n_cells=%lld n_total=%lld out of range", N, K, n_cells, n_total);
     if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
-    DevBuf dc(0), ds(1), dcnt(2), dP(3), dfirst(4);
-    hipError_t e = dc.alloc(sizeof(int) * (size_t)n_cells);
-    if (e == hipSuccess) e = ds.alloc(sizeof(int) * (size_t)n_cells);
-    if (e == hipSuccess) e = dcnt.alloc(sizeof(unsigned int) * (size_t)N * K);
-    if (e == hipSuccess && first_row) e = dfirst.alloc(sizeof(unsigned int) * (size_t)N);
-    if (e == hipSuccess && first_row) e = hipMemset(dfirst.p, 0xff, sizeof(unsigned int) * (size_t)N);
-    if (e == hipSuccess) e = dP.alloc(sizeof(double) * (size_t)N * K);
-    if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(ds.p, sample_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(dcnt.p, 0, sizeof(unsigned int) * (size_t)N * K);
+    PrepassWs ws;
+    ws.want_counts = true; ws.C = n_cells; ws.N = N; ws.K = K; ws.n_cu = current_cu_count(); ws.n_code_cols = 2;
+    ws.carve();
+    DevBuf buf(1);
+    hipError_t e = buf.alloc(ws.total);
+    unsigned char *w = buf.as<unsigned char>();
+    int *d_cell = reinterpret_cast<int *>(w + ws.o_code), *d_sample = d_cell + n_cells;
+    if (e == hipSuccess) e = hipMemcpy(d_cell, cell_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sample, sample_code, sizeof(int) * (size_t)n_cells, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(w, 0, ws.clear_bytes, nullptr);
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
-    const int n_cu = current_cu_count();
-    hipLaunchKernelGGL(pilot::count_kernel, dim3(grid_for(n_cells, 256, n_cu)), dim3(256), 0, nullptr, dc.as<int>(),
-                       ds.as<int>(), (long)n_cells, K, dcnt.as<unsigned int>(), first_row ? dfirst.as<unsigned int>() : nullptr);
-    hipLaunchKernelGGL(pilot::proportions_kernel, dim3(1), dim3(256), sizeof(double) * (K + 1), nullptr,
-                       dcnt.as<unsigned int>(), N, K, (long)n_total, regulizer, normalization, dP.as<double>());
+    launch_counts(ws, w, d_cell, d_sample, n_total, regulizer, normalization, first_row != nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(P, dP.p, sizeof(double) * (size_t)N * K, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(P, w + ws.o_P, sizeof(double) * (size_t)N * K, hipMemcpyDeviceToHost));
     if (first_row) {
         std::vector<unsigned int> fr((size_t)N);
-        HIP_TRY(hipMemcpy(fr.data(), dfirst.p, sizeof(unsigned int) * (size_t)N, hipMemcpyDeviceToHost));
-        for (int n = 0; n < N; ++n) first_row[n] = fr[(size_t)n] == 0xffffffffu ? -1 : (long long)fr[(size_t)n];
+        HIP_TRY(hipMemcpy(fr.data(), w + ws.o_first, sizeof(unsigned int) * (size_t)N, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) first_row[n] = fr[(size_t)n] == 0u ? -1 : (long long)(0xffffffffu - fr[(size_t)n]);
     }
     return PILOT_OT_OK;
 }
 
 // the embedding resident on the device: uploaded once (from a helper thread of the host language, beside its own work on
-// the label columns), read by pilot_ot_centroid_medians_dev
+// the label columns), read by pilot_ot_centroid_medians_dev / pilot_ot_prepass_dev
 struct pilot_ot_embedding {
     void *dX = nullptr;
     int dtype = 0, D = 0, device = 0;
@@ -1460,82 +1587,67 @@ namespace {
 // dXdev (nullable): the embedding already on the device; else X is copied in
 template <typename T>
 int centroid_medians_impl(const void *X, const void *dXdev, long long C, int D, const int *cell_code, int K, double *centroids) {
-    using U = typename pilot::OrderedKey<T>::U;
-    using State = pilot::SelectState<U>;
-    // small cohorts: one launch, the selection in LDS (small_medians_kernel) -- when every type fits its key buffer and the
-    // K x D workgroups reading all C codes is a small amount of traffic (PILOT_OT_NO_SMALL_MEDIANS=1: the general path, tests)
-    if (C > 0 && (double)C * K * D <= 3.2e7 && !getenv("PILOT_OT_NO_SMALL_MEDIANS")) {
-        std::vector<unsigned int> n_k((size_t)K, 0u);
-        for (long long c = 0; c < C; ++c) { const int k = cell_code[c]; if (k >= 0 && k < K) ++n_k[(size_t)k]; }
-        unsigned int n_max = 0;
-        for (unsigned int v : n_k) n_max = v > n_max ? v : n_max;
-        if (n_max <= (unsigned int)pilot::SMALL_MEDIANS_CAP) {
-            DevBuf dX(0), dc(1), dout(8);
-            hipError_t e = dXdev ? hipSuccess : dX.alloc(sizeof(T) * (size_t)C * D);
-            if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
-            if (e == hipSuccess) e = dout.alloc(sizeof(double) * (size_t)K * D);
-            if (e == hipSuccess && !dXdev) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
-            if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
-            const size_t lds = sizeof(U) * (size_t)(n_max ? n_max : 1);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::small_medians_kernel<T>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(U) * pilot::SMALL_MEDIANS_CAP)));
-            hipLaunchKernelGGL(pilot::small_medians_kernel<T>, dim3((unsigned)(K * D)), dim3(256), lds, nullptr,
-                               static_cast<const T *>(dXdev ? dXdev : dX.p), D, dc.as<int>(), (long)C, K, dout.as<double>());
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpy(centroids, dout.p, sizeof(double) * (size_t)K * D, hipMemcpyDeviceToHost));
-            return PILOT_OT_OK;
-        }
-    }
-    const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;      // dimensions per histogram launch
-    const size_t lds = sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
-    DevBuf dX(0), dc(1), dn(2), doffs(3), dcur(4), dperm(5), dst(6), dh(7), dout(8);
+    unsigned int n_max = 0;
+    const bool small = small_medians_fit(C, D, cell_code, K, &n_max);
+    PrepassWs ws;
+    ws.want_medians = !small; ws.C = C; ws.K = K; ws.D = D; ws.n_cu = current_cu_count(); ws.key_bytes = sizeof(T);
+    ws.carve();
+    DevBuf dX(0), buf(1);
     hipError_t e = dXdev ? hipSuccess : dX.alloc(sizeof(T) * (size_t)C * D);
-    if (e == hipSuccess) e = dc.alloc(sizeof(int) * (size_t)C);
-    if (e == hipSuccess) e = dn.alloc(sizeof(unsigned int) * K);
-    if (e == hipSuccess) e = doffs.alloc(sizeof(unsigned int) * (K + 1));
-    if (e == hipSuccess) e = dcur.alloc(sizeof(unsigned int) * K);
-    if (e == hipSuccess) e = dperm.alloc(sizeof(unsigned int) * (size_t)C);
-    if (e == hipSuccess) e = dst.alloc(sizeof(State) * (size_t)K * D * 2);
-    if (e == hipSuccess) e = dh.alloc(sizeof(unsigned int) * (size_t)K * D * 2 * 256);
-    if (e == hipSuccess) e = dout.alloc(sizeof(double) * (size_t)K * D);
-    if (e == hipSuccess && !dXdev) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
-    const T *dXp = static_cast<const T *>(dXdev ? dXdev : dX.p);
-    if (e == hipSuccess) e = hipMemcpy(dc.p, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(dn.p, 0, sizeof(unsigned int) * K);
-    if (e == hipSuccess) e = hipMemset(dcur.p, 0, sizeof(unsigned int) * K);
-    if (e == hipSuccess) e = hipMemset(dh.p, 0, sizeof(unsigned int) * (size_t)K * D * 2 * 256);
+    if (e == hipSuccess) e = buf.alloc(ws.total + al256(sizeof(double) * (size_t)K * D));
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
-    const int n_cu = current_cu_count();
-    const int gc = grid_for(C, 256, n_cu);
-    hipLaunchKernelGGL(pilot::type_count_kernel, dim3(gc), dim3(256), 0, nullptr, dc.as<int>(), (long)C, K, dn.as<unsigned int>());
-    hipLaunchKernelGGL(pilot::type_offsets_kernel, dim3(1), dim3(64), 0, nullptr, dn.as<unsigned int>(), K, doffs.as<unsigned int>());
-    hipLaunchKernelGGL(pilot::type_scatter_kernel, dim3(gc), dim3(256), 0, nullptr, dc.as<int>(), (long)C, K,
-                       doffs.as<unsigned int>(), dcur.as<unsigned int>(), dperm.as<unsigned int>());
-    const int nq = K * D * 2;
-    hipLaunchKernelGGL(pilot::select_init_kernel<T>, dim3((nq + 255) / 256), dim3(256), 0, nullptr, dn.as<unsigned int>(), K, D,
-                       dst.as<State>());
-    // enough workgroups per cell type to fill the chip, at most one per ~2048 rows
-    long splits = (2L * n_cu + K - 1) / K;
-    const long max_splits = (C / K) / 2048 + 1;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::select_hist_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int shift = pilot::OrderedKey<T>::BITS - 8; shift >= 0; shift -= 8) {
-        for (int dbeg = 0; dbeg < D; dbeg += Dw_max) {           // any D: the dimensions in windows that fit the LDS histograms
-            const int Dw = D - dbeg < Dw_max ? D - dbeg : Dw_max;
-            hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)splits, (unsigned)K), dim3(256),
-                               sizeof(unsigned int) * (size_t)Dw * 2 * 256, nullptr, dXp, D, dbeg, Dw,
-                               dperm.as<unsigned int>(), doffs.as<unsigned int>(), shift, dst.as<State>(), dh.as<unsigned int>());
-        }
-        hipLaunchKernelGGL(pilot::select_pick_kernel<T>, dim3((nq + 255) / 256), dim3(256), 0, nullptr, K, D, shift,
-                           dst.as<State>(), dh.as<unsigned int>());
-    }
-    hipLaunchKernelGGL(pilot::select_finish_kernel<T>, dim3((K * D + 255) / 256), dim3(256), 0, nullptr, dn.as<unsigned int>(), K, D,
-                       dst.as<State>(), dout.as<double>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(centroids, dout.p, sizeof(double) * (size_t)K * D, hipMemcpyDeviceToHost));
+    unsigned char *w = buf.as<unsigned char>();
+    int *d_cell = reinterpret_cast<int *>(w + ws.o_code);
+    double *d_out = small ? reinterpret_cast<double *>(w + ws.total) : reinterpret_cast<double *>(w + ws.o_out);
+    if (!dXdev) e = hipMemcpy(dX.p, X, sizeof(T) * (size_t)C * D, hipMemcpyHostToDevice);
+    const T *dXp = static_cast<const T *>(dXdev ? dXdev : dX.p);
+    if (e == hipSuccess) e = hipMemcpy(d_cell, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !small) e = hipMemsetAsync(w, 0, ws.clear_bytes, nullptr);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    const int rc = small ? launch_small_medians<T>(dXp, C, D, d_cell, K, n_max, d_out) : launch_medians<T>(ws, w, dXp, d_cell, false);
+    if (rc != PILOT_OT_OK) return rc;
+    HIP_TRY(hipMemcpy(centroids, d_out, sizeof(double) * (size_t)K * D, hipMemcpyDeviceToHost));
+    return PILOT_OT_OK;
+}
+
+// the whole pre-pass from one upload of the two code columns
+template <typename T>
+int prepass_impl(const pilot_ot_embedding *emb, const int *cell_code, const int *sample_code, long long n_total, int N, int K,
+                 double regulizer, int normalization, double *P, long long *first_row, double *centroids) {
+    const long long C = emb->C;
+    const int D = emb->D;
+    unsigned int n_max = 0;
+    const bool small = small_medians_fit(C, D, cell_code, K, &n_max);
+    PrepassWs ws;
+    ws.want_counts = true; ws.want_medians = !small; ws.C = C; ws.N = N; ws.K = K; ws.D = D; ws.n_cu = current_cu_count();
+    ws.key_bytes = sizeof(T); ws.n_code_cols = 2;
+    ws.carve();
+    DevBuf buf(1);
+    // results leave in one copy: P | centroids | first rows, packed behind the workspace
+    const size_t r_P = sizeof(double) * (size_t)N * K, r_cen = sizeof(double) * (size_t)K * D, r_first = sizeof(unsigned int) * (size_t)N;
+    hipError_t e = buf.alloc(ws.total + al256(r_P + r_cen + r_first));
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    unsigned char *w = buf.as<unsigned char>(), *res = w + ws.total;
+    int *d_cell = reinterpret_cast<int *>(w + ws.o_code), *d_sample = d_cell + C;
+    e = hipMemcpy(d_cell, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sample, sample_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(w, 0, ws.clear_bytes, nullptr);
+    if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    launch_counts(ws, w, d_cell, d_sample, n_total, regulizer, normalization, true);
+    const T *dXp = static_cast<const T *>(emb->dX);
+    double *d_cen = reinterpret_cast<double *>(res + r_P);
+    int rc = small ? launch_small_medians<T>(dXp, C, D, d_cell, K, n_max, d_cen) : launch_medians<T>(ws, w, dXp, d_cell, true);
+    if (rc != PILOT_OT_OK) return rc;
+    hipError_t he = hipMemcpyAsync(res, w + ws.o_P, r_P, hipMemcpyDeviceToDevice, nullptr);
+    if (he == hipSuccess && !small) he = hipMemcpyAsync(d_cen, w + ws.o_out, r_cen, hipMemcpyDeviceToDevice, nullptr);
+    if (he == hipSuccess) he = hipMemcpyAsync(res + r_P + r_cen, w + ws.o_first, r_first, hipMemcpyDeviceToDevice, nullptr);
+    std::vector<unsigned char> host(r_P + r_cen + r_first);
+    if (he == hipSuccess) he = hipMemcpy(host.data(), res, host.size(), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) return fail(PILOT_OT_EHIP, "pre-pass results: %s", hipGetErrorString(he));
+    memcpy(P, host.data(), r_P);
+    memcpy(centroids, host.data() + r_P, r_cen);
+    const unsigned int *fr = reinterpret_cast<const unsigned int *>(host.data() + r_P + r_cen);
+    if (first_row) for (int n = 0; n < N; ++n) first_row[n] = fr[n] == 0u ? -1 : (long long)(0xffffffffu - fr[n]);
     return PILOT_OT_OK;
 }
 }  // namespace
@@ -1544,7 +1656,8 @@ PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_ce
                                         double *centroids) {
     if (!X || !cell_code || !centroids) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (n_cells <= 0 || D <= 0 || K <= 0) return fail(PILOT_OT_EINVAL, "n_cells=%lld D=%d K=%d must be positive", n_cells, D, K);
-    if (n_cells > 0xffffffffLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", n_cells);
+    if (n_cells > 0xfffffffeLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", n_cells);
+    if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
     if (dtype == PILOT_OT_F32) return centroid_medians_impl<float>(X, nullptr, n_cells, D, cell_code, K, centroids);
     if (dtype == PILOT_OT_F64) return centroid_medians_impl<double>(X, nullptr, n_cells, D, cell_code, K, centroids);
     return fail(PILOT_OT_EINVAL, "unknown dtype id %d", dtype);
@@ -1553,12 +1666,26 @@ PILOT_API int pilot_ot_centroid_medians(const void *X, int dtype, long long n_ce
 PILOT_API int pilot_ot_centroid_medians_dev(pilot_ot_embedding *e, const int *cell_code, int K, double *centroids) {
     if (!e || !cell_code || !centroids) return fail(PILOT_OT_EINVAL, "NULL pointer");
     if (K <= 0) return fail(PILOT_OT_EINVAL, "K=%d must be positive", K);
-    if (e->C > 0xffffffffLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", e->C);
+    if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
+    if (e->C > 0xfffffffeLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", e->C);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != e->device) return fail(PILOT_OT_EINVAL, "the embedding lives on device %d, the current device is %d", e->device, dev);
     if (e->dtype == PILOT_OT_F32) return centroid_medians_impl<float>(nullptr, e->dX, e->C, e->D, cell_code, K, centroids);
     return centroid_medians_impl<double>(nullptr, e->dX, e->C, e->D, cell_code, K, centroids);
+}
+
+PILOT_API int pilot_ot_prepass_dev(pilot_ot_embedding *e, const int *cell_code, const int *sample_code, long long n_total, int N, int K,
+                                   double regulizer, int normalization, double *P, long long *first_row, double *centroids) {
+    if (!e || !cell_code || !sample_code || !P || !centroids) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    if (N <= 0 || K <= 0 || n_total < 2) return fail(PILOT_OT_EINVAL, "N=%d K=%d n_total=%lld out of range", N, K, n_total);
+    if (K > 4096) return fail(PILOT_OT_ENOTSUP, "K=%d > 4096 cell types", K);
+    if (e->C > 0xfffffffeLL) return fail(PILOT_OT_ENOTSUP, "n_cells=%lld exceeds the 32-bit row index", e->C);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != e->device) return fail(PILOT_OT_EINVAL, "the embedding lives on device %d, the current device is %d", e->device, dev);
+    if (e->dtype == PILOT_OT_F32) return prepass_impl<float>(e, cell_code, sample_code, n_total, N, K, regulizer, normalization, P, first_row, centroids);
+    return prepass_impl<double>(e, cell_code, sample_code, n_total, N, K, regulizer, normalization, P, first_row, centroids);
 }
 
 // ------------------------------------------------------------------------------------------------

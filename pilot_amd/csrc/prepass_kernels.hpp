@@ -12,44 +12,117 @@
 namespace pilot {
 
 // ---- proportions --------------------------------------------------------------------------------------------
-// first_row (nullable, N entries preset to 0xffffffff): smallest row number of every sample -- the row whose status value
-// return_real_labels reports (Trajectory.py:617-642).  The plain read in front of the atomic keeps all but the first few
-// cells of a sample off the atomic unit.
-__global__ void count_kernel(const int *__restrict__ cell_code, const int *__restrict__ sample_code, long C, int K,
-                             unsigned int *__restrict__ counts /* N*K */, unsigned int *__restrict__ first_row) {
-    for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
-        const int k = cell_code[c], s = sample_code[c];
-        if (k >= 0 && s >= 0) atomicAdd(&counts[(size_t)s * K + k], 1u);
-        if (first_row && s >= 0 && (unsigned int)c < __builtin_nontemporal_load(&first_row[s])) atomicMin(&first_row[s], (unsigned int)c);
+// One pass over the two code columns: counts[s][k] (cells with both labels), n_k[k] (cells with a type label: what the
+// median pass groups), first_row[s] (nullable: smallest row number c of every sample -- the row whose status value
+// return_real_labels reports, Trajectory.py:617-642 -- kept as 0xffffffff - c under atomicMax, so that 0 = "no cell" and one
+// memset clears every output of the pass).
+// A cohort is stored sample after sample, so the 2048 cells a block takes at a time belong to one or two samples: 3.6 M
+// global atomics on a handful of hot addresses (round 5: 1.2 ms for 14 MB of codes) become LDS atomics on a window of
+// sample rows [s_min, s_max] of the block's chunk plus one global add per non-empty bin; a chunk whose samples span more
+// rows than the window holds falls back to global atomics, bin for bin the same integers.
+constexpr int COUNT_CHUNK = 2048;        // cells per block and step
+constexpr int COUNT_LDS_BINS = 8192;     // (sample window) x K counters in LDS
+constexpr int COUNT_LDS_ROWS = 1024;     // widest sample window
+__global__ void __launch_bounds__(256) count_kernel(const int *__restrict__ cell_code, const int *__restrict__ sample_code, long C, int N, int K,
+                                                    unsigned int *__restrict__ counts /* N*K */, unsigned int *__restrict__ n_k /* K, nullable */,
+                                                    unsigned int *__restrict__ first_row) {
+    extern __shared__ unsigned int ck_sm[];                  // bins[COUNT_LDS_BINS] | first[COUNT_LDS_ROWS] | nk[K] | red[16]
+    unsigned int *bins = ck_sm, *first = bins + COUNT_LDS_BINS, *nk = first + COUNT_LDS_ROWS;
+    int *red = reinterpret_cast<int *>(nk + K);
+    constexpr int PER = COUNT_CHUNK / 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < K; k += 256) nk[k] = 0u;
+    const long nchunks = (C + COUNT_CHUNK - 1) / COUNT_CHUNK;
+    for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const long c0 = ch * COUNT_CHUNK;
+        int kk[PER], ss[PER];
+        int smin = 0x7fffffff, smax = -1;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const long c = c0 + i * 256 + threadIdx.x;
+            kk[i] = -1; ss[i] = -1;
+            if (c < C) { kk[i] = cell_code[c]; ss[i] = sample_code[c]; }
+            if (kk[i] >= K) kk[i] = -1;
+            if (ss[i] >= N) ss[i] = -1;
+            if (ss[i] >= 0) { smin = ss[i] < smin ? ss[i] : smin; smax = ss[i] > smax ? ss[i] : smax; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(smin, o, 64), b = __shfl_xor(smax, o, 64);
+            smin = a < smin ? a : smin; smax = b > smax ? b : smax;
+        }
+        __syncthreads();                                     // (the previous chunk's flush has read bins / first / red)
+        if (lane == 0) { red[wave] = smin; red[4 + wave] = smax; }
+        __syncthreads();
+        smin = min(min(red[0], red[1]), min(red[2], red[3]));
+        smax = max(max(red[4], red[5]), max(red[6], red[7]));
+        const int rows = smax >= smin ? smax - smin + 1 : 0;
+        const bool in_lds = rows <= COUNT_LDS_ROWS && (long)rows * K <= COUNT_LDS_BINS;
+        if (in_lds) {
+            for (int i = threadIdx.x; i < rows * K; i += 256) bins[i] = 0u;
+            for (int i = threadIdx.x; i < rows; i += 256) first[i] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int k = kk[i], sidx = ss[i];
+            const unsigned int c = 0xffffffffu - (unsigned int)(c0 + i * 256 + threadIdx.x);
+            if (k >= 0) atomicAdd(&nk[k], 1u);
+            if (in_lds) {
+                if (k >= 0 && sidx >= 0) atomicAdd(&bins[(sidx - smin) * K + k], 1u);
+                if (first_row && sidx >= 0) atomicMax(&first[sidx - smin], c);
+            } else {
+                if (k >= 0 && sidx >= 0) atomicAdd(&counts[(size_t)sidx * K + k], 1u);
+                if (first_row && sidx >= 0 && c > __builtin_nontemporal_load(&first_row[sidx])) atomicMax(&first_row[sidx], c);
+            }
+        }
+        __syncthreads();
+        if (in_lds) {
+            for (int i = threadIdx.x; i < rows * K; i += 256) if (bins[i]) atomicAdd(&counts[(size_t)smin * K + i], bins[i]);
+            if (first_row)
+                for (int i = threadIdx.x; i < rows; i += 256) if (first[i]) atomicMax(&first_row[smin + i], first[i]);
+        }
+    }
+    __syncthreads();
+    if (n_k) for (int k = threadIdx.x; k < K; k += 256) if (nk[k]) atomicAdd(&n_k[k], nk[k]);
+}
+
+// every fp64 operation in the order the reference performs it (Trajectory.py:405-430).  Two launches: the priors
+// (a wave per cell type sums its column of the counts: integers, exact in any order), then a wave per sample.
+__global__ void __launch_bounds__(256) prior_kernel(const unsigned int *__restrict__ counts, int N, int K, long n_total, double regulizer,
+                                                    double *__restrict__ prior /* K */) {
+    const int lane = threadIdx.x & 63, k = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
+    if (k >= K) return;
+    unsigned long long nk = 0;
+    for (int n = lane; n < N; n += 64) nk += counts[(size_t)n * K + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nk += __shfl_xor(nk, o, 64);
+    if (lane == 0) {
+        const double pr = double(nk) / double(n_total - 1);          // :407   n_k / (C - 1)
+        prior[k] = pr * regulizer;                                    // :409
     }
 }
 
-// one workgroup; every fp64 operation in the order the reference performs it (Trajectory.py:405-430)
-__global__ void proportions_kernel(const unsigned int *__restrict__ counts, int N, int K, long n_total,
-                                   double regulizer, int normalization, double *__restrict__ P) {
-    extern __shared__ double sh[];       // prior[K], then sum_prior
-    double *prior = sh;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        unsigned long long nk = 0;
-        for (int n = 0; n < N; ++n) nk += counts[(size_t)n * K + k];
-        double pr = double(nk) / double(n_total - 1);      // :407   n_k / (C - 1)
-        prior[k] = pr * regulizer;                          // :409
-    }
-    __syncthreads();
+__global__ void __launch_bounds__(256) proportions_kernel(const unsigned int *__restrict__ counts, int N, int K,
+                                                          const double *__restrict__ prior, int normalization, double *__restrict__ P) {
+    __shared__ double sum_prior_sh;
     if (threadIdx.x == 0) {
-        double s = 0.0;                                     // Python sum(prior): int 0 + p0 + p1 + ...
+        double s = 0.0;                                     // Python sum(prior): ((0 + p0) + p1) + ... in this order
         for (int k = 0; k < K; ++k) s += prior[k];
-        sh[K] = s;
+        sum_prior_sh = s;
     }
     __syncthreads();
-    const double sum_prior = sh[K];
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        double rs = 0.0;                                    // sum(counts[n]): integers, exact in any order
-        for (int k = 0; k < K; ++k) rs += double(counts[(size_t)n * K + k]);
-        for (int k = 0; k < K; ++k) {
-            const double c = double(counts[(size_t)n * K + k]);
-            P[(size_t)n * K + k] = normalization ? (c + prior[k]) / (rs + sum_prior) : c;   // :430
-        }
+    const int lane = threadIdx.x & 63, n = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
+    if (n >= N) return;
+    const double sum_prior = sum_prior_sh;
+    unsigned long long r = 0;                               // sum(counts[n]): integers, exact in any order
+    for (int k = lane; k < K; k += 64) r += counts[(size_t)n * K + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+    const double rs = double(r);
+    for (int k = lane; k < K; k += 64) {
+        const double c = double(counts[(size_t)n * K + k]);
+        P[(size_t)n * K + k] = normalization ? (c + prior[k]) / (rs + sum_prior) : c;   // :430
     }
 }
 
@@ -80,117 +153,273 @@ template <> struct OrderedKey<double> {
     }
 };
 
-// cells grouped by type: perm[offset[k] + i] = index of the i-th cell of type k (order inside a type is irrelevant)
-__global__ void type_count_kernel(const int *__restrict__ cell_code, long C, int K, unsigned int *__restrict__ n_k) {
-    for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
+// ---- general path: rows grouped by type, then an 8-bit radix select over contiguous memory -----------------------------------
+// Round 5's general path gathered one 120-byte row per wave and step through a permutation (30 of 64 lanes busy, every load
+// behind the load of its index) and took 20.5 ms for 1.8 M x 30 floats: 0.5 % of the HBM roof.  Now:
+//   1. type_count_kernel      n_k (a block counts its cells in LDS, then K global adds);
+//   2. median_prep_kernel     one block: segment starts (every type starts on a row that is a multiple of 4, so a block's
+//                             first element is 16-byte aligned) and the work list of (type, row chunk) items for the select
+//                             passes;
+//   3. group_rows_kernel      ONE read of the embedding, ONE write of its order-preserving keys with the rows of a type
+//                             contiguous (a block ranks its 1024 cells per type in LDS, reserves a run per type with one
+//                             global add, and copies its rows; reads fully coalesced, writes in whole rows);
+//   4. select_hist_kernel  x BITS/8: a block streams one contiguous chunk of rows of ONE type with 16-byte loads, lane = 4
+//                             consecutive elements, i.e. every lane busy whatever D is; the 256-bin histograms of all D dimensions sit in
+//                             LDS, so the lanes of a wave spread over D histograms (2 - 3 lanes on a bin, not 64);
+//      select_pick_kernel     a wave per (type, dimension): the digit that holds the wanted rank; the last one writes the
+//                             medians.
+// HBM traffic per call: C*D*s read + written once, then BITS/8 reads of C*D*s -- the model DESIGN.md prices the pass against.
+constexpr int GROUP_ROWS_PER_BLOCK = 1024;
+constexpr int SELECT_MAX_DIMS = 64;                      // dimensions per histogram window (LDS: 2 x 64 x 256 counters = 128 KB)
+constexpr int SELECT_THREADS = 512;                      // select_hist_kernel: two such blocks per CU at D = 30 (62 KB of LDS each)
+
+__global__ void __launch_bounds__(256) type_count_kernel(const int *__restrict__ cell_code, long C, int K, unsigned int *__restrict__ n_k) {
+    extern __shared__ unsigned int tc_bins[];            // K
+    for (int k = threadIdx.x; k < K; k += blockDim.x) tc_bins[k] = 0u;
+    __syncthreads();
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
         const int k = cell_code[c];
-        if (k >= 0 && k < K) atomicAdd(&n_k[k], 1u);
+        if (k >= 0 && k < K) atomicAdd(&tc_bins[k], 1u);
     }
-}
-__global__ void type_offsets_kernel(const unsigned int *__restrict__ n_k, int K, unsigned int *__restrict__ offs /* K+1 */) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned int run = 0;
-        for (int k = 0; k < K; ++k) { offs[k] = run; run += n_k[k]; }
-        offs[K] = run;
-    }
-}
-__global__ void type_scatter_kernel(const int *__restrict__ cell_code, long C, int K, const unsigned int *__restrict__ offs,
-                                    unsigned int *__restrict__ cursor, unsigned int *__restrict__ perm) {
-    for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < C; c += (long)gridDim.x * blockDim.x) {
-        const int k = cell_code[c];
-        if (k >= 0 && k < K) perm[offs[k] + atomicAdd(&cursor[k], 1u)] = (unsigned int)c;
-    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) if (tc_bins[k]) atomicAdd(&n_k[k], tc_bins[k]);
 }
 
 // Radix-select state per (type k, dimension d, query q): q = 0 -> rank floor((n-1)/2), q = 1 -> rank floor(n/2)
 // (the two middle elements; equal ranks when n is odd).  prefix = key bits fixed so far, rank = rank of the
 // wanted element among the keys that share the prefix.
 template <typename U> struct SelectState { U prefix; unsigned int rank; };
+struct SelectItem { unsigned int k, r0, r1; };          // rows [r0, r1) of the grouped array, all of type k
 
-template <typename T>
-__global__ void select_init_kernel(const unsigned int *__restrict__ n_k, int K, int D,
-                                   SelectState<typename OrderedKey<T>::U> *__restrict__ st) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= K * D * 2) return;
-    const int q = idx & 1, k = idx / (2 * D);
-    const unsigned int n = n_k[k];
-    st[idx].prefix = 0;
-    st[idx].rank = n ? (q == 0 ? (n - 1) / 2 : n / 2) : 0;
+// exclusive scan of v[0..n) in LDS by one 256-thread block; returns the total (tmp: 257 words of LDS)
+__device__ inline unsigned int block_exclusive_scan(unsigned int *v, int n, unsigned int *tmp) {
+    const int per = (n + 255) / 256, a = (int)threadIdx.x * per, b = a + per < n ? a + per : n;
+    unsigned int s = 0;
+    for (int i = a; i < b; ++i) s += v[i];
+    tmp[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int i = 0; i < 256; ++i) { const unsigned int x = tmp[i]; tmp[i] = run; run += x; }
+        tmp[256] = run;
+    }
+    __syncthreads();
+    unsigned int run = tmp[threadIdx.x];
+    for (int i = a; i < b; ++i) { const unsigned int x = v[i]; v[i] = run; run += x; }
+    __syncthreads();
+    return tmp[256];
 }
 
-// one radix pass (8 bits at `shift`): histogram of the digit over the keys matching each query's prefix.
-// grid = (splits, K); every workgroup sweeps a slice of the rows of type k, the dimensions [dbeg, dbeg + Dw) at once
-// (the LDS histograms hold Dw <= SELECT_MAX_DIMS dimensions; wider embeddings take several launches per pass).
-constexpr int SELECT_MAX_DIMS = 64;
+__global__ void __launch_bounds__(256) median_prep_kernel(const unsigned int *__restrict__ n_k, int K, unsigned int R,
+                                                          unsigned int *__restrict__ offs /* K */, unsigned int *__restrict__ n_items,
+                                                          SelectItem *__restrict__ items) {
+    extern __shared__ unsigned int mp_sm[];              // start[K + 1] | chunk[K + 1] | tmp[257]
+    unsigned int *start = mp_sm, *chunk = mp_sm + (K + 1), *tmp = chunk + (K + 1);
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const unsigned int n = n_k[k];
+        start[k] = (n + 3u) & ~3u;                       // rows reserved: the next type starts on a multiple of 4 again
+        chunk[k] = (n + R - 1u) / R;
+    }
+    __syncthreads();
+    block_exclusive_scan(start, K, tmp);
+    const unsigned int total = block_exclusive_scan(chunk, K, tmp);
+    if (threadIdx.x == 0) *n_items = total;
+    for (int k = threadIdx.x; k < K; k += 256) offs[k] = start[k];
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < total; i += 256) {
+        int lo = 0, hi = K;                               // the last k with chunk[k] <= i (empty types share a value: take the last)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk[mid] <= i) lo = mid; else hi = mid; }
+        const unsigned int n = n_k[lo], r0 = start[lo] + (i - chunk[lo]) * R;
+        const unsigned int end = start[lo] + n;
+        items[i] = SelectItem{(unsigned int)lo, r0, r0 + R < end ? r0 + R : end};
+    }
+}
+
 template <typename T>
-__global__ void select_hist_kernel(const T *__restrict__ X, int D, int dbeg, int Dw, const unsigned int *__restrict__ perm,
-                                   const unsigned int *__restrict__ offs, int shift,
-                                   const SelectState<typename OrderedKey<T>::U> *__restrict__ st,
-                                   unsigned int *__restrict__ hist /* K * D * 2 * 256 */) {
+__global__ void __launch_bounds__(256) group_rows_kernel(const T *__restrict__ X, int D, const int *__restrict__ cell_code, long C, int K,
+                                                         const unsigned int *__restrict__ offs, unsigned int *__restrict__ cursor /* K, zeroed */,
+                                                         typename OrderedKey<T>::U *__restrict__ Y) {
+    using OK = OrderedKey<T>;
+    extern __shared__ unsigned int gr_sm[];              // cnt[K] | base[K] | dest[GROUP_ROWS_PER_BLOCK]
+    unsigned int *cnt = gr_sm, *base = gr_sm + K, *dest = base + K;
+    constexpr int PER = GROUP_ROWS_PER_BLOCK / 256;
+    for (int k = threadIdx.x; k < K; k += 256) cnt[k] = 0u;
+    __syncthreads();
+    const long c0 = (long)blockIdx.x * GROUP_ROWS_PER_BLOCK;
+    const int rows = (int)(C - c0 < GROUP_ROWS_PER_BLOCK ? C - c0 : GROUP_ROWS_PER_BLOCK);
+    int kk[PER];
+    unsigned int lr[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int r = i * 256 + (int)threadIdx.x;
+        kk[i] = -1;
+        if (r < rows) { const int k = cell_code[c0 + r]; if (k >= 0 && k < K) { kk[i] = k; lr[i] = atomicAdd(&cnt[k], 1u); } }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) if (cnt[k]) base[k] = offs[k] + atomicAdd(&cursor[k], cnt[k]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) dest[i * 256 + (int)threadIdx.x] = kk[i] >= 0 ? base[kk[i]] + lr[i] : 0xffffffffu;
+    __syncthreads();
+    // the block's rows are one contiguous piece of X: element e = r * D + d, no division in the loop; four loads in flight
+    const T *src = X + (size_t)c0 * D;
+    const unsigned int total = (unsigned int)rows * (unsigned int)D;
+    unsigned int r = threadIdx.x / (unsigned int)D, d = threadIdx.x % (unsigned int)D;
+    const unsigned int dr = 256u / (unsigned int)D, dd = 256u % (unsigned int)D;
+    constexpr int UNR = 4;
+    for (unsigned int e = threadIdx.x; e < total; e += 256u * UNR) {
+        T v[UNR];
+        unsigned int rr[UNR], dv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned int idx = e + 256u * u;
+            v[u] = idx < total ? __builtin_nontemporal_load(&src[idx]) : T(0);
+            rr[u] = idx < total ? r : 0u; dv[u] = d;
+            r += dr; d += dd;
+            if (d >= (unsigned int)D) { d -= (unsigned int)D; ++r; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned int row = dest[rr[u]];
+            if (e + 256u * u < total && row != 0xffffffffu) Y[(size_t)row * D + dv[u]] = OK::enc(v[u]);
+        }
+    }
+}
+
+// one radix pass (8 bits at `shift`) over the dimension window [dbeg, dbeg + Dw): item = one chunk of rows of one type.
+// VEC keys per 16-byte load when the window is the whole row (the chunk is then one contiguous, 16-byte aligned range).
+template <typename T>
+__global__ void __launch_bounds__(SELECT_THREADS) select_hist_kernel(const typename OrderedKey<T>::U *__restrict__ Y, int D, int dbeg, int Dw,
+                                                          const unsigned int *__restrict__ n_items, const SelectItem *__restrict__ items,
+                                                          int shift, const SelectState<typename OrderedKey<T>::U> *__restrict__ st,
+                                                          unsigned int *__restrict__ hist /* K * D * 2 * 256 */) {
     using OK = OrderedKey<T>;
     using U = typename OK::U;
-    extern __shared__ unsigned int lh[];                   // Dw * 2 * 256
-    const int k = blockIdx.y;
-    const unsigned int beg = offs[k], end = offs[k + 1];
+    constexpr int VEC = 16 / (int)sizeof(U);
+    if (blockIdx.x >= *n_items) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
+    U *pre = reinterpret_cast<U *>(sh_raw);                                 // [2][Dw] prefixes of the two queries
+    unsigned int *lh = reinterpret_cast<unsigned int *>(pre + 2 * Dw);      // [2][Dw][256]
+    const SelectItem it = items[blockIdx.x];
+    const int k = (int)it.k;
     const int nbins = Dw * 2 * 256;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i] = 0;
+    for (int i = threadIdx.x; i < nbins; i += SELECT_THREADS) lh[i] = 0u;
+    const bool first = shift + 8 >= OK::BITS;                               // (no state yet: nothing is fixed, every key counts)
+    for (int i = threadIdx.x; i < 2 * Dw; i += SELECT_THREADS) pre[i] = first ? U(0) : st[((size_t)k * D + dbeg + (i % Dw)) * 2 + (i / Dw)].prefix;
     __syncthreads();
     const U himask = (shift + 8 >= OK::BITS) ? U(0) : (~U(0) << (shift + 8));
-    // a wave handles one row at a time: lane d (< D) takes dimension d -> the row is one coalesced read
-    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, nwaves = blockDim.x / 64;
-    const unsigned int per = (end - beg + gridDim.x - 1) / gridDim.x;
-    const unsigned int r0 = beg + blockIdx.x * per, r1 = (r0 + per < end) ? r0 + per : end;
-    for (int d0 = 0; d0 < Dw; d0 += 64) {
-        const int dl = d0 + lane, d = dbeg + dl;
-        U p0 = 0, p1 = 0;
-        if (dl < Dw) { p0 = st[(k * D + d) * 2 + 0].prefix; p1 = st[(k * D + d) * 2 + 1].prefix; }
-        for (unsigned int r = r0 + wave; r < r1; r += nwaves) {
-            const size_t row = perm[r];
-            if (dl < Dw) {
-                const U key = OK::enc(X[row * D + d]);
-                const unsigned int digit = (unsigned int)(key >> shift) & 255u;
-                if ((key & himask) == p0) atomicAdd(&lh[((dl * 2 + 0) << 8) + digit], 1u);
-                if ((key & himask) == p1) atomicAdd(&lh[((dl * 2 + 1) << 8) + digit], 1u);
+    const unsigned int uDw = (unsigned int)Dw;
+    auto tally = [&](U key, unsigned int dl) {
+        const unsigned int digit = (unsigned int)(key >> shift) & 255u;
+        const U hi = key & himask, p0 = pre[dl], p1 = pre[uDw + dl];
+        if (hi == p0) atomicAdd(&lh[(dl << 8) + digit], 1u);
+        else if (hi == p1) atomicAdd(&lh[((uDw + dl) << 8) + digit], 1u);   // (the second histogram only where the queries parted)
+    };
+    if (Dw == D) {
+        const U *src = Y + (size_t)it.r0 * D;
+        const size_t total = (size_t)(it.r1 - it.r0) * D, nvec = total / VEC;
+        using V = __attribute__((ext_vector_type(VEC))) U;
+        const V *src4 = reinterpret_cast<const V *>(src);
+        unsigned int dl = (unsigned int)(((size_t)threadIdx.x * VEC) % uDw);
+        const unsigned int step = ((unsigned int)SELECT_THREADS * VEC) % uDw;
+        size_t v = threadIdx.x;
+        constexpr int UNR = 4;
+        for (; v + (size_t)(UNR - 1) * SELECT_THREADS < nvec; v += (size_t)UNR * SELECT_THREADS) {
+            V x[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) x[u] = __builtin_nontemporal_load(&src4[v + (size_t)u * SELECT_THREADS]);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                unsigned int d2 = dl;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { tally(x[u][j], d2); d2 = d2 + 1u == uDw ? 0u : d2 + 1u; }
+                dl += step; if (dl >= uDw) dl -= uDw;
             }
+        }
+        for (; v < nvec; v += SELECT_THREADS) {
+            const V x = __builtin_nontemporal_load(&src4[v]);
+            unsigned int d2 = dl;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { tally(x[j], d2); d2 = d2 + 1u == uDw ? 0u : d2 + 1u; }
+            dl += step; if (dl >= uDw) dl -= uDw;
+        }
+        for (size_t e = nvec * VEC + threadIdx.x; e < total; e += SELECT_THREADS) tally(src[e], (unsigned int)(e % uDw));
+    } else {
+        // a window of a wide row: element (r, dl) at Y[(r0 + r) * D + dbeg + dl]
+        const unsigned int rows = it.r1 - it.r0;
+        unsigned int r = threadIdx.x / uDw, dl = threadIdx.x % uDw;
+        const unsigned int dr = (unsigned int)SELECT_THREADS / uDw, dd = (unsigned int)SELECT_THREADS % uDw;
+        while (r < rows) {
+            tally(Y[(size_t)(it.r0 + r) * D + dbeg + dl], dl);
+            r += dr; dl += dd;
+            if (dl >= uDw) { dl -= uDw; ++r; }
         }
     }
     __syncthreads();
-    unsigned int *gh = hist + ((size_t)k * D + dbeg) * 2 * 256;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) if (lh[i]) atomicAdd(&gh[i], lh[i]);
-}
-
-// pick the digit that contains the wanted rank; fix it in the prefix; re-zero the histogram for the next pass
-template <typename T>
-__global__ void select_pick_kernel(int K, int D, int shift, SelectState<typename OrderedKey<T>::U> *__restrict__ st,
-                                   unsigned int *__restrict__ hist) {
-    using U = typename OrderedKey<T>::U;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (k, d, q)
-    if (idx >= K * D * 2) return;
-    unsigned int *h = hist + (size_t)idx * 256;
-    unsigned int rank = st[idx].rank, run = 0;
-    int digit = 255;
-    for (int b = 0; b < 256; ++b) {
-        const unsigned int c = h[b];
-        if (rank < run + c) { digit = b; break; }
-        run += c;
+    unsigned int *gh0 = hist + (((size_t)k * D + dbeg) * 2) * 256;          // [d][q][256] in global memory
+    for (int i = threadIdx.x; i < nbins; i += SELECT_THREADS) {
+        const unsigned int c = lh[i];
+        if (c) {
+            const int q = i / (Dw * 256), dl = (i >> 8) % Dw;
+            atomicAdd(&gh0[((size_t)dl * 2 + q) * 256 + (i & 255)], c);
+        }
     }
-    for (int b = 0; b < 256; ++b) h[b] = 0;
-    st[idx].prefix |= (U(digit) << shift);
-    st[idx].rank = rank - run;
 }
 
-// median = mean of the two middle elements, computed in the data's own dtype like numpy/pandas, then widened
+// a wave per (type, dimension): pick the digit that contains the wanted rank of both queries, fix it in the prefix,
+// re-zero the histograms for the next pass; on the last pass write the median = mean of the two middle elements,
+// computed in the data's own dtype like numpy/pandas, then widened.
 template <typename T>
-__global__ void select_finish_kernel(const unsigned int *__restrict__ n_k, int K, int D,
-                                     const SelectState<typename OrderedKey<T>::U> *__restrict__ st,
-                                     double *__restrict__ centroids /* K x D */) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (k, d)
+__global__ void __launch_bounds__(256) select_pick_kernel(const unsigned int *__restrict__ n_k, int K, int D, int shift,
+                                                          SelectState<typename OrderedKey<T>::U> *__restrict__ st,
+                                                          unsigned int *__restrict__ hist, double *__restrict__ centroids /* K x D, last pass only */) {
+    using OK = OrderedKey<T>;
+    using U = typename OK::U;
+    const int lane = threadIdx.x & 63, idx = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // (k, d)
     if (idx >= K * D) return;
-    const int k = idx / D;
-    if (n_k[k] == 0) { centroids[idx] = __longlong_as_double(0x7ff8000000000000ll); return; }   // NaN, like an empty slice
-    const T lo = OrderedKey<T>::dec(st[idx * 2 + 0].prefix), hi = OrderedKey<T>::dec(st[idx * 2 + 1].prefix);
-    const T m = (n_k[k] & 1u) ? lo : T((lo + hi) * T(0.5));
-    centroids[idx] = double(m);
+    SelectState<U> *s = st + (size_t)idx * 2;
+    const bool first = shift + 8 >= OK::BITS;
+    const unsigned int n_all = n_k[idx / D];
+    const U p0 = first ? U(0) : s[0].prefix, p1 = first ? U(0) : s[1].prefix;
+    const bool parted = p0 != p1;
+    U pref[2] = {p0, p1};
+    unsigned int rank[2] = {first ? (n_all ? (n_all - 1u) / 2u : 0u) : s[0].rank, first ? n_all / 2u : s[1].rank};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        unsigned int *h = hist + ((size_t)idx * 2 + ((q == 1 && parted) ? 1 : 0)) * 256;
+        unsigned int c[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = h[lane * 4 + j]; sum += c[j]; }
+        unsigned int incl = sum;                                   // inclusive scan over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+        const unsigned long long has = __ballot(rank[q] < incl);
+        int digit = 255; unsigned int below = 0;
+        if (has) {
+            const int L = __builtin_ctzll(has);
+            unsigned int run = __shfl(incl - sum, L, 64);
+            const unsigned int c0 = __shfl(c[0], L, 64), c1 = __shfl(c[1], L, 64), c2 = __shfl(c[2], L, 64);
+            int j = 0;
+            if (rank[q] >= run + c0) { run += c0; j = 1; if (rank[q] >= run + c1) { run += c1; j = 2; if (rank[q] >= run + c2) { run += c2; j = 3; } } }
+            digit = L * 4 + j; below = run;
+        } else {
+            below = __shfl(incl, 63, 64);                          // (an empty type: nothing matches; the value is never used)
+        }
+        pref[q] |= U((unsigned int)digit) << shift;
+        rank[q] -= has ? below : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // every lane has read both histograms: zero them for the next pass
+    unsigned int *h = hist + (size_t)idx * 2 * 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[lane + 64 * j] = 0u;
+    if (lane < 2) { s[lane].prefix = pref[lane]; s[lane].rank = rank[lane]; }
+    if (shift == 0 && lane == 0) {
+        if (n_all == 0u) { centroids[idx] = __longlong_as_double(0x7ff8000000000000ll); return; }   // NaN, like an empty slice
+        const T lo = OK::dec(pref[0]), hi = OK::dec(pref[1]);
+        const T m = (n_all & 1u) ? lo : T((lo + hi) * T(0.5));
+        centroids[idx] = double(m);
+    }
 }
 
 // SMALL cohorts (the reference test's own: 24 227 cells, 14 clusters, 14 features): the general path above is sixteen launches,

@@ -93,36 +93,42 @@ def _annot_frame(obs, clusters_col, sample_col, status):
 def _first_appearance_codes(series):
     """(codes, uniques) with uniques in first-appearance order, as ``Series.unique()`` gives; missing values get -1.
 
-    Two shortcuts around hashing millions of Python objects (what ``pd.factorize`` does on an object column, ~25 ms per
-    1.8 M cells and column):
+    ``pd.factorize`` on an object column hashes millions of Python objects (~25 ms per 1.8 M cells and column) and holds the
+    interpreter lock.  Two shortcuts, both one native pass of ``libpilot_ot.so`` (``engine.label_codes``, int32 codes out,
+    no lock held -- ``wasserstein_distance`` runs its two columns side by side):
 
     * categorical columns (what AnnData gives for ``obs`` labels): the integer codes are there already, only their
       numbering is changed to first appearance;
     * object columns: the labels of 1.8 M cells are a few hundred distinct Python objects repeated (AnnData / pandas /
-      numpy fancy indexing copy POINTERS), so the column is factorised by object identity -- a hash of 8-byte integers --
-      and only the distinct objects are then factorised by value (equal strings at different addresses merge there).
+      numpy fancy indexing copy POINTERS), so the column is numbered by object identity and only the distinct objects
+      are then factorised by value (equal strings at different addresses merge there).
     """
     if isinstance(series.dtype, pd.CategoricalDtype):
-        cat = series.cat
-        raw = cat.codes.to_numpy()
+        values = series.array
+        raw = values.codes                                            # int8 / int16 / int32 (int64 beyond 2^31 categories)
+        if raw.dtype.itemsize <= 4:
+            codes, first = engine.label_codes(raw, max_uniques=len(values.categories) + 1)
+            return codes, np.asarray(values.categories[raw[first]])
         seen = pd.unique(raw[raw >= 0]) if (raw < 0).any() else pd.unique(raw)       # category numbers, first appearance
-        remap = np.full(len(cat.categories) + 1, -1, dtype=np.int64)                 # (slot -1 serves the missing code)
+        remap = np.full(len(values.categories) + 1, -1, dtype=np.int64)              # (slot -1 serves the missing code)
         remap[seen] = np.arange(len(seen))
-        return remap[raw], np.asarray(cat.categories[seen])
+        return remap[raw], np.asarray(values.categories[seen])
     arr = series.to_numpy()
     if arr.dtype == object and arr.ndim == 1 and arr.strides == (arr.itemsize,) and arr.size:
         ptrs = np.ctypeslib.as_array((ctypes.c_size_t * arr.size).from_address(arr.ctypes.data))      # (arr stays alive here)
-        pcodes, puniq = pd.factorize(ptrs, sort=False)
         # (ADVICE r03) the shortcut only pays while the labels are few shared objects: a column built row by row holds one
-        # str object per cell (as many pointers as cells: the Python-level loop below would take seconds at 1.8 M cells), and a
-        # NULL slot cannot be turned back into an object -- both go the plain way
-        if len(puniq) > max(4096, arr.size // 8) or (puniq == 0).any():
+        # str object per cell (as many pointers as cells) -- such a column goes the plain way
+        got = engine.label_codes(ptrs.view(np.uint64), max_uniques=max(4096, arr.size // 8))
+        if got is None:
             codes, uniques = pd.factorize(series, sort=False, use_na_sentinel=True)
             return codes, np.asarray(uniques)
-        objs = np.empty(len(puniq), dtype=object)
-        objs[:] = [ctypes.cast(int(a), ctypes.py_object).value for a in puniq]
+        pcodes, first = got
+        objs = arr[first]                                              # the distinct objects, in order of first appearance
         vcodes, uniques = pd.factorize(objs, sort=False, use_na_sentinel=True)
-        return vcodes[pcodes], np.asarray(uniques)
+        if len(uniques) == len(objs) and np.array_equal(vcodes, np.arange(len(objs))):
+            return pcodes, np.asarray(uniques)                         # every object its own value: the identity codes stand
+        lut = np.append(vcodes, -1).astype(np.int32)                   # (slot -1 serves the missing code)
+        return lut[pcodes], np.asarray(uniques)
     codes, uniques = pd.factorize(series, sort=False, use_na_sentinel=True)
     return codes, np.asarray(uniques)
 
@@ -244,6 +250,40 @@ def _labels_from_codes(scodes, n_samples, cond):
     return [cond[r] for r in first_row]
 
 
+def _values_at(series, rows):
+    """``[series.iloc[r] for r in rows]`` as ``Series.unique()[0]`` hands the values out, without materialising a
+    categorical column (1.8 M Python references for a few hundred lookups)."""
+    if isinstance(series.dtype, pd.CategoricalDtype):
+        values = series.array
+        codes = values.codes[np.asarray(rows, dtype=np.int64)]
+        cats = values.categories
+        return [cats[c] if c >= 0 else np.nan for c in codes]
+    values = series.to_numpy()
+    return [values[int(r)] for r in rows]
+
+
+_libc = None
+
+
+def _empty_like_huge(X):
+    """``np.empty_like(X)`` whose pages the kernel may back with 2 MB huge pages (``madvise(MADV_HUGEPAGE)`` where transparent
+    huge pages are in ``madvise`` mode): the private copy of a 216 MB embedding is 52 000 first-touch page faults otherwise,
+    which is most of what the copy costs."""
+    global _libc
+    huge = 2 << 20
+    if X.nbytes < 8 * huge or not X.flags.c_contiguous:
+        return np.empty_like(X)
+    try:
+        if _libc is None:
+            _libc = ctypes.CDLL(None, use_errno=True)
+        raw = np.empty(X.nbytes + huge, dtype=np.uint8)
+        off = (-raw.ctypes.data) % huge
+        _libc.madvise(ctypes.c_void_p(raw.ctypes.data + off), ctypes.c_size_t((X.nbytes // huge) * huge), 14)       # MADV_HUGEPAGE; advisory
+        return raw[off:off + X.nbytes].view(X.dtype).reshape(X.shape)
+    except Exception:
+        return np.empty_like(X)
+
+
 class _DeviceWorker:
     """ONE long-lived helper thread that runs the device chain of ``wasserstein_distance`` (the library caches its
     workspace per calling thread: a fresh thread per call would rebuild it every time)."""
@@ -348,12 +388,12 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     else:
         var_names = list(adata.var_names)
         data = pd.DataFrame(adata[:, var_names].X, columns=var_names)
-    # While the label columns are selected and factorised on this thread (GIL-bound object work), helper threads move bytes:
-    # the embedding to the device (H2D) and into the private copy that adata.uns['data'] holds, like the reference's.
+    # While the label columns are numbered (native passes, side by side), helper threads move bytes: the embedding to the device
+    # (H2D) and into the private copy that adata.uns['data'] holds, like the reference's.
     X = data.to_numpy()
     upload = engine.EmbeddingUpload(X)
-    own = np.empty_like(X)
-    n_copy = 4 if X.size >= (1 << 22) else (1 if X.nbytes >= (4 << 20) else 0)
+    own = _empty_like_huge(X)
+    n_copy = min(8, max(1, (os.cpu_count() or 2) - 2)) if X.size >= (1 << 22) else (1 if X.nbytes >= (4 << 20) else 0)
     bounds = np.linspace(0, X.shape[0], max(n_copy, 1) + 1).astype(np.int64)
     copiers = [threading.Thread(target=np.copyto, args=(own[a:b], X[a:b]), name="pilot_amd_data_copy")
                for a, b in zip(bounds[:-1], bounds[1:])] if n_copy else []
@@ -364,21 +404,39 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     dev = {}
 
     def device_chain(ccodes, scodes, n_samples, n_types):
-        # runs with the GIL released almost throughout (ctypes calls): proportions + first rows, medians, pdist, pair grid
+        # runs with the GIL released almost throughout (ctypes calls): proportions + first rows + medians, pdist, pair grid
         try:
-            dev["P"], dev["first"] = engine.proportions_and_first_rows(ccodes, scodes, n_samples, n_types, regulizer=regulizer,
-                                                                       normalization=normalization, n_total=len(ccodes))
-            cost = engine.pdist_square(upload.medians(ccodes, n_types), metric=metric)
+            dev["P"], dev["first"], centroids = upload.prepass(ccodes, scodes, n_samples, n_types, regulizer=regulizer,
+                                                               normalization=normalization, n_total=len(ccodes))
+            cost = engine.pdist_square(centroids, metric=metric)
             dev["cost"] = cost
             dev["EMD"] = _pair_grid(dev["P"], cost / cost.max(), regularized, reg, engine_options) if n_samples else np.zeros((0, 0))
         except BaseException as e:          # re-raised on the calling thread
             dev["error"] = e
     chain = None
     try:
-        # the two label columns are factorised ONCE (first-appearance order, Trajectory.py:402,412), straight from adata.obs,
-        # and shared by the three steps that the reference runs as separate pandas scans ...
-        ccodes, cells = _first_appearance_codes(adata.obs[clusters_col])
-        scodes, samples = _first_appearance_codes(adata.obs[sample_col])
+        # the two label columns are numbered ONCE (first-appearance order, Trajectory.py:402,412), straight from adata.obs,
+        # and shared by the three steps that the reference runs as separate pandas scans; the cell-type column on a helper
+        # thread beside the sample column on this one when the columns are long enough to pay for the thread ...
+        side = {}
+        if len(adata.obs) >= (1 << 17):
+            def number_types():
+                try:
+                    side["cells"] = _first_appearance_codes(adata.obs[clusters_col])
+                except BaseException as e:
+                    side["error"] = e
+            helper = threading.Thread(target=number_types, name="pilot_amd_label_codes")
+            helper.start()
+            try:
+                scodes, samples = _first_appearance_codes(adata.obs[sample_col])
+            finally:
+                helper.join()
+            if "error" in side:
+                raise side["error"]
+            ccodes, cells = side["cells"]
+        else:
+            ccodes, cells = _first_appearance_codes(adata.obs[clusters_col])
+            scodes, samples = _first_appearance_codes(adata.obs[sample_col])
         chain = _device_worker().submit(upload.device, device_chain, ccodes, scodes, len(samples), len(cells))
         # ... and while the device works, this thread does the GIL-bound part: the annotation frame (a copy of three object
         # columns of adata.obs, Trajectory.py:257-262)
@@ -406,8 +464,7 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
     # first status value of every sample (return_real_labels, :617-642): the first row of a sample came out of the
     # device pass over the codes
     # (the values as ``Series.unique()[0]`` hands them out; ``.iloc`` per sample on a categorical column was 3 - 6 ms at 634 samples)
-    status_values = annot["status"].to_numpy()
-    real_labels = [status_values[int(r)] for r in first_rows]
+    real_labels = _values_at(annot["status"], first_rows)
     if reference_clustering is not None:      # Trajectory.py:108-113: the reference's Clustering on the finished matrix, the silhouette on the device
         _predicted, ARI, real_labels = reference_clustering(EMD / EMD.max(), annot, metric=metric, res=res, steper=steper)
         adata.uns["real_labels"] = real_labels

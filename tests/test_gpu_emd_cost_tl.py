@@ -291,6 +291,65 @@ def test_proportions_kernel_large_and_ragged():
     np.testing.assert_array_equal(P, want)
 
 
+@pytest.mark.parametrize("layout", ["sample_major", "shuffled", "few_wide"])
+def test_count_kernel_lds_window_and_global_fallback(layout):
+    """count_kernel tallies a block's 2048 cells in an LDS window of sample rows when (rows x K) fits 8192 counters and
+    falls back to global atomics when it does not: sample-major cohorts (the window path), a shuffled one with 700 samples
+    (every chunk spans all samples: the fallback), and few samples x many types (window limited by K).  Same integers either
+    way; the first row of every sample comes out of the same pass."""
+    rng = np.random.default_rng(11)
+    if layout == "sample_major":
+        C, N, K = 250_000, 83, 50
+        sc = np.sort(rng.integers(0, N, C)).astype(np.int32)
+    elif layout == "shuffled":
+        C, N, K = 250_000, 700, 50
+        sc = rng.integers(0, N, C).astype(np.int32)
+    else:
+        C, N, K = 120_000, 5, 3000
+        sc = np.sort(rng.integers(0, N, C)).astype(np.int32)
+    cc = rng.integers(0, K, C).astype(np.int32)
+    cc[rng.random(C) < 0.01] = -1
+    sc[rng.random(C) < 0.005] = -1
+    P, first = engine.proportions_and_first_rows(cc, sc, N, K, regulizer=0.2, n_total=C)
+    ok = (cc >= 0) & (sc >= 0)
+    counts = np.bincount(sc[ok].astype(np.int64) * K + cc[ok], minlength=N * K).reshape(N, K).astype(np.float64)
+    prior = counts.sum(0) / (C - 1) * 0.2
+    want = np.stack([(counts[n] + prior) / (sum(counts[n]) + sum(prior)) for n in range(N)])
+    np.testing.assert_array_equal(P, want)
+    want_first = np.full(N, -1, dtype=np.int64)
+    idx = np.flatnonzero(sc >= 0)
+    want_first[sc[idx][::-1]] = idx[::-1]
+    np.testing.assert_array_equal(first, want_first)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("C,D,K,N", [(300_000, 30, 50, 100), (20_000, 14, 14, 600), (70_000, 70, 3, 9)])
+def test_prepass_in_one_call_gives_the_three_calls_bits(dtype, C, D, K, N):
+    """pilot_ot_prepass_dev: proportions, first rows and medians from ONE upload of the two code columns -- the general
+    median path (grouped rows + radix select), the one-launch small-cohort path and a windowed D > 64, against the separate
+    entry points and numpy."""
+    rng = np.random.default_rng(C + D)
+    X = (rng.standard_normal((C, D)) * 4).astype(dtype)
+    X[rng.random((C, D)) < 0.05] = 0.0
+    cc = rng.integers(0, K, C).astype(np.int32)
+    sc = np.sort(rng.integers(0, N, C)).astype(np.int32)
+    cc[rng.random(C) < 0.01] = -1
+    X = np.concatenate([X, X[:1]])[:C]                      # (a private, contiguous array)
+    up = engine.EmbeddingUpload(X)
+    up.SMALL_BYTES = 0
+    try:
+        P, first, cen = up.prepass(cc, sc, N, K, regulizer=0.2, n_total=C)
+        cen2 = up.medians(cc, K)
+    finally:
+        up.close()
+    P2, first2 = engine.proportions_and_first_rows(cc, sc, N, K, regulizer=0.2, n_total=C)
+    np.testing.assert_array_equal(P, P2)
+    np.testing.assert_array_equal(first, first2)
+    np.testing.assert_array_equal(cen, cen2)
+    for k in range(K):
+        np.testing.assert_array_equal(cen[k], np.median(X[cc == k], axis=0).astype(np.float64))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("C,D,K", [(1, 1, 1), (7, 3, 2), (1000, 30, 50), (4097, 65, 3), (3000, 150, 4), (500, 400, 2), (200_000, 30, 50)])
 def test_centroid_medians_exact(dtype, C, D, K):

@@ -6,7 +6,7 @@ import pytest
 
 from conftest import GOLDEN_CASES, GOLDEN_OPTION_CASES, GOLDEN_REAL, golden_adata, load_golden, load_golden_pack
 from oracle import oracle as O
-from pilot_amd import tl
+from pilot_amd import engine, tl
 
 
 def _annot(g):
@@ -162,3 +162,27 @@ def test_result_frames_are_the_objects_the_reference_builds():
         assert dis is E and cost.index.name == "cell_types"
     empty = tl._emd_frame(np.zeros((0, 0)), [])
     assert empty.shape == (0, 0) and empty.index.name == "sampleID"
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32, np.uint64])
+@pytest.mark.parametrize("n,n_threads", [(0, 1), (1, 1), (1000, 1), (200_000, 3)])
+def test_label_codes_native_pass_is_pandas_factorize(dtype, n, n_threads):
+    """engine.label_codes (host pass of libpilot_ot.so, no device): codes in first-appearance order, -1 for missing, the row
+    of every first appearance -- pd.factorize on the same labels; slices on several threads merge to the same numbering;
+    a column with more distinct labels than the caller allows is refused (None)."""
+    rng = np.random.default_rng(n + n_threads)
+    hi = 100 if dtype == np.int8 else 5000
+    ids = rng.integers(0, hi, n).astype(dtype)
+    if dtype == np.uint64:
+        ids = ids * np.uint64(64) + np.uint64(0x7F0000000000)
+    missing = rng.random(n) < 0.02
+    ids[missing] = 0 if dtype == np.uint64 else -1
+    codes, first = engine.label_codes(ids, n_threads=n_threads)
+    ser = pd.Series(ids.astype(np.float64))
+    ser[missing] = np.nan
+    want, uniques = pd.factorize(ser, sort=False, use_na_sentinel=True)
+    assert codes.dtype == np.int32 and first.dtype == np.int64
+    np.testing.assert_array_equal(codes, want)
+    np.testing.assert_array_equal(ids[first].astype(np.float64), uniques)
+    if n >= 1000:
+        assert engine.label_codes(ids, max_uniques=10, n_threads=n_threads) is None

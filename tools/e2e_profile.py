@@ -46,13 +46,28 @@ def stamp(name, fn, reps=5):
     print("  %-58s %.5f s" % (name, best)); return r
 if REAL:
     stamp("data frame (adata[:, var_names].X)", lambda: pd.DataFrame(ad[:, list(ad.var_names)].X, columns=list(ad.var_names)))
+print("  host: %d cores, transparent huge pages: %s" % (os.cpu_count(), open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip()
+                                                      if os.path.exists("/sys/kernel/mm/transparent_hugepage/enabled") else "n/a"))
 annot = stamp("annot frame (obs[[3 columns]])", lambda: tl._annot_frame(ad.obs, cell_col, "sampleID", "status"))
-cc = stamp("factorise cell_type", lambda: tl._first_appearance_codes(annot["cell_type"]))
-sc = stamp("factorise sampleID", lambda: tl._first_appearance_codes(annot["sampleID"]))
+cc = stamp("number cell_type (native pass)", lambda: tl._first_appearance_codes(annot["cell_type"]))
+sc = stamp("number sampleID (native pass)", lambda: tl._first_appearance_codes(annot["sampleID"]))
+if not REAL:
+    for col in ("cell_type", "sampleID"):
+        cat = annot[col].astype("category")
+        stamp("number %s, categorical" % col, lambda: tl._first_appearance_codes(cat))
 up = stamp("embedding upload (H2D, here on this thread)", lambda: (lambda u: (u.thread.join() if u.thread else None, u)[1])(engine.EmbeddingUpload(X)), reps=1)
-stamp("private copy of the embedding, 4 threads", lambda: tl.np.copyto(np.empty_like(X), X))
+def private_copy(n_threads, huge):
+    import threading
+    own = tl._empty_like_huge(X) if huge else np.empty_like(X)
+    b = np.linspace(0, X.shape[0], n_threads + 1).astype(np.int64)
+    th = [threading.Thread(target=np.copyto, args=(own[i:j], X[i:j])) for i, j in zip(b[:-1], b[1:])]
+    [t.start() for t in th]; [t.join() for t in th]
+for nt in (1, 4, 8):
+    stamp("private copy of the embedding, %d threads" % nt, lambda: private_copy(nt, False))
+    stamp("private copy of the embedding, %d threads, madvise(HUGEPAGE)" % nt, lambda: private_copy(nt, True))
 pr = stamp("proportions + first rows (device)", lambda: engine.proportions_and_first_rows(cc[0], sc[0], len(sc[1]), len(cc[1])))
 cen = stamp("medians (device, embedding resident)", lambda: up.medians(cc[0], len(cc[1])))
+stamp("pre-pass in one call (proportions + first rows + medians)", lambda: up.prepass(cc[0], sc[0], len(sc[1]), len(cc[1])))
 M = stamp("pdist (device)", lambda: engine.pdist_square(cen))
 E = stamp("sinkhorn grid (host arrays in / out)", lambda: engine.sinkhorn_grid(pr[0], M / M.max(), 0.1))
 stamp("exact grid (host arrays in / out)", lambda: engine.emd_grid(pr[0], M / M.max()))
