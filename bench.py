@@ -44,7 +44,7 @@ PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # same pipe, same dense rate for fp16 inputs
-PROFILE_ROUNDS = ("r05", "r04", "r03")  # newest first: the offline rocprofv3 measurements bench.py quotes next to its live ones
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")  # newest first: the offline rocprofv3 measurements bench.py quotes next to its live ones
 
 
 def profile_file(name):
@@ -315,7 +315,10 @@ def main():
                 c5 = bench_cellw2(args)       # BASELINE configs[4] (an extension): one pass over its 40 000 pairs, ~35 s
                 out["c5_cellw2"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "checks", "cpu_baseline")}
             if args.config in ("c2", "c3"):
-                out["e2e_tl_s"] = e2e_tl(cfg)
+                from pilot_amd.synthetic import make_cells
+                cohort = make_cells(cfg["n_patients"], cfg["n_types"], cfg["n_dims"], cfg["seed"], cfg["cells_per_patient"])
+                out["e2e_tl_s"] = e2e_tl(cohort)
+                out["prepass"] = prepass_record(L, cohort, with_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             cb, cb_eq, cb_all, upd = cpu_baseline(P, M, args.reg, args.cpu_seconds, E, iters)
             out["cpu_baseline"], out["cpu_baseline_equal_updates"], out["cpu_baseline_all_cores"] = cb, cb_eq, cb_all
@@ -428,24 +431,89 @@ def attach_offline_profile(roofline, config, reg, prec):
 
 
 # ---- extras ---------------------------------------------------------------------------------------------------------
-def e2e_tl(cfg, reps=3):
+def e2e_tl(ad, reps=3):
     """What a user of the reference calls: tl.wasserstein_distance(adata) on the cell-level cohort of this config (cells x PCA
-    dims + three obs columns, object dtype like the reference's tutorials) -> adata.uns, wall time, both modes (best of 3
-    after one warm-up call).  Host pandas work + H2D of the embedding + every device kernel + frames."""
+    dims + three obs columns, object dtype like the reference's tutorials, then categorical like AnnData stores them) ->
+    adata.uns, wall time, both modes (best of 3 after one warm-up call).  Host label work + H2D of the embedding + every
+    device kernel + frames."""
     from pilot_amd import tl
-    from pilot_amd.synthetic import make_cells
     os.environ.setdefault("PILOT_AMD_NO_RESULTS_DIR", "1")
-    ad = make_cells(cfg["n_patients"], cfg["n_types"], cfg["n_dims"], cfg["seed"], cfg["cells_per_patient"])
-    out = {"cells": int(ad.X.shape[0]), "what": "tl.wasserstein_distance(adata, ...) end to end, best of %d" % reps}
-    for mode, key in (("reg", "sinkhorn_reg0.1"), ("unreg", "exact_emd")):
-        best = float("inf")
-        for r in range(reps + 1):
-            ad.uns = {}
+    out = {"cells": int(ad.X.shape[0]), "what": "tl.wasserstein_distance(adata, ...) end to end, best of %d; obs label columns of object dtype "
+                                               "(the `_categorical` keys: the same columns as pandas Categoricals, what AnnData stores)" % reps}
+    obs_object = ad.obs
+    for suffix, obs in (("", obs_object), ("_categorical", obs_object.astype("category"))):
+        ad.obs = obs
+        for mode, key in (("reg", "sinkhorn_reg0.1"), ("unreg", "exact_emd")):
+            best = float("inf")
+            for r in range(reps + 1):
+                ad.uns = {}
+                t = time.perf_counter()
+                tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized=mode, reg=0.1)
+                if r:
+                    best = min(best, time.perf_counter() - t)
+            out[key + suffix] = round(best, 4)
+    ad.obs = obs_object
+    ad.uns = {}
+    return out
+
+
+def prepass_record(L, ad, with_cpu=True, reps=10):
+    """The device pre-pass of tl.wasserstein_distance on the cell-level cohort (Cluster_Representations,
+    Trajectory.py:400-430, and the per-type medians of cost_matrix, :462-466): (sample, type) histogram + proportions + first rows +
+    K x D medians from one upload of the two code columns, the embedding resident in HBM.  `ms` = wall clock of the C-ABI call
+    (code columns H2D and results D2H inside), `device_ms` = HIP events around its kernels; the roofline prices the kernels
+    against HBM on the bytes the algorithm moves: the codes, one read + one write of the embedding (rows grouped by type, as
+    order-preserving keys), then one read per 8-bit radix digit."""
+    import ctypes
+    import pandas as pd
+    from pilot_amd import _lib, engine, tl
+    X = ad.obsm["X_pca"]
+    C, D = X.shape
+    ccodes, cells = tl._first_appearance_codes(ad.obs["cell_types"])
+    scodes, samples = tl._first_appearance_codes(ad.obs["sampleID"])
+    K, N = len(cells), len(samples)
+    up = engine.EmbeddingUpload(X)
+    wall, dev = [], []
+    try:
+        for r in range(reps + 2):
             t = time.perf_counter()
-            tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized=mode, reg=0.1)
-            if r:
-                best = min(best, time.perf_counter() - t)
-        out[key] = round(best, 4)
+            P, first, cen = up.prepass(ccodes, scodes, N, K, regulizer=0.2, n_total=C)
+            dt = time.perf_counter() - t
+            ms = ctypes.c_float(0.0)
+            _lib.check(L.pilot_ot_prepass_device_ms(ctypes.byref(ms)))
+            if r >= 2:
+                wall.append(dt * 1e3); dev.append(float(ms.value))
+    finally:
+        up.close()
+    s = X.itemsize
+    sweeps = 2 + s                                            # group: read + write; one read per 8-bit digit of an s-byte key
+    model = C * D * s * sweeps + C * 4 * 3                    # + the code columns: both read by the count pass, one by the grouping
+    dev_ms = float(np.median(dev))
+    traffic, traffic_src = None, None
+    tf, rnd = profile_file("prepass_traffic.json")
+    if tf:
+        t = json.load(open(tf))
+        if t.get("cells") == C and t.get("dims") == D:
+            traffic, traffic_src = t.get("hbm_bytes_per_call"), "profiles/%s/prepass_traffic.json (%s)" % (rnd, t.get("how", "rocprofv3 --pmc"))
+    out = {"what": "proportions + first rows + per-type medians on the device, %d cells x %d dims (%s), %d types, %d samples" % (C, D, X.dtype, K, N),
+           "ms": round(float(np.median(wall)), 4), "device_ms": round(dev_ms, 4),
+           "roofline": {"bound": "hbm", "achieved": round(model / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(model / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(model),
+                        "model": "codes (12 B/cell) + embedding x (1 read + 1 write + %d digit passes)" % s,
+                        "frac_one_read": round(C * D * s / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "traffic": traffic, "traffic_source": traffic_src}}
+    if with_cpu:
+        # the reference's own lines on the same array: cost_matrix's median loop (Trajectory.py:462-466) -- pandas, one thread
+        data = pd.DataFrame(X, columns=["PCA_%d" % (i + 1) for i in range(D)])
+        annot = ad.obs[["cell_types", "sampleID", "status"]]
+        annot.columns = ["cell_type", "sampleID", "status"]
+        t = time.perf_counter()
+        ref = [list(data[annot[annot.columns[0]] == i].median(axis=0)) for i in annot[annot.columns[0]].unique()]
+        cpu_s = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": round(cpu_s * 1e3, 1), "unit": "ms", "cores": 1, "kind": "reference",
+                               "sample": "the reference's own median loop (Trajectory.py:462-466, pandas boolean mask + DataFrame.median per "
+                                         "cell type) on the same %d x %d array, whole; medians only (its proportions loop is not timed)" % (C, D)}
+        out["parity"] = {"medians_bit_exact_vs_pandas": bool(np.array_equal(np.asarray(ref, dtype=np.float64), cen, equal_nan=True))}
     return out
 
 

@@ -160,6 +160,9 @@ int pilot_ot_centroid_medians_dev(pilot_ot_embedding *emb, const int *cell_code,
  * Cluster_Representations (Trajectory.py:377-436), return_real_labels (:617-642), the medians of cost_matrix (:462-466). */
 int pilot_ot_prepass_dev(pilot_ot_embedding *emb, const int *cell_code, const int *sample_code, long long n_total, int N, int K,
                          double regulizer, int normalization, double *P, long long *first_row, double *centroids);
+/* Device time (HIP events on the launch stream, first kernel to last; transfers excluded) of the calling thread's last
+ * pilot_ot_prepass_dev / pilot_ot_centroid_medians(_dev) call -- what bench.py's `prepass.roofline` is computed from. */
+int pilot_ot_prepass_device_ms(float *ms);
 
 /* ---- cost matrix: replaces scipy pdist+squareform at Trajectory.py:468-469 ------------------ */
 /* centroids: K x D row-major (per-cell-type medians, Trajectory.py:465-466).  cost: K x K,

@@ -1062,7 +1062,19 @@ struct HostCtx {
 // pilot_ot_shutdown() releases the caches of EVERY thread (it must not run concurrently with other calls), and the caches
 // of a thread that has exited are released by the next thread that creates its own -- never from a thread-exit or
 // process-exit hook, where the HIP runtime may already be gone.
-struct ThreadCtx { HostCtx host; WsPool ws; bool orphan = false; };
+// device time of the calling thread's last pre-pass (pilot_ot_prepass_device_ms): two events on the launch stream
+struct PrepassClock {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool valid = false;
+    void release() { for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; } valid = false; }
+    void start() {
+        valid = false;
+        if (!ev[0] && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)) { release(); return; }
+        (void)hipEventRecord(ev[0], nullptr);
+    }
+    void stop() { if (ev[1]) valid = hipEventRecord(ev[1], nullptr) == hipSuccess; }
+};
+struct ThreadCtx { HostCtx host; WsPool ws; PrepassClock clock; bool orphan = false; };
 std::mutex g_tctx_mutex;
 std::vector<ThreadCtx *> g_tctx_all;
 struct TctxOwner {
@@ -1081,6 +1093,7 @@ ThreadCtx &tctx() {
             if (g_tctx_all[i]->orphan) {
                 g_tctx_all[i]->host.release();
                 g_tctx_all[i]->ws.release();
+                g_tctx_all[i]->clock.release();
                 delete g_tctx_all[i];
                 g_tctx_all.erase(g_tctx_all.begin() + (long)i);
             } else {
@@ -1094,6 +1107,7 @@ ThreadCtx &tctx() {
 }
 #define g_host (tctx().host)
 #define g_ws (tctx().ws)
+#define g_clock (tctx().clock)
 hipError_t ws_get(int slot, size_t bytes, void **out) { return g_ws.get(slot, bytes, out); }
 }  // namespace
 namespace pilot {
@@ -1171,7 +1185,7 @@ int host_fetch(const Fetch *f, int n) {
 PILOT_API int pilot_ot_shutdown(void) {
     {
         std::lock_guard<std::mutex> l(g_tctx_mutex);
-        for (ThreadCtx *c : g_tctx_all) { c->host.release(); c->ws.release(); }
+        for (ThreadCtx *c : g_tctx_all) { c->host.release(); c->ws.release(); c->clock.release(); }
     }
     pilot::abi_multi_release();
     return PILOT_OT_OK;
@@ -1410,13 +1424,10 @@ struct PrepassWs {
         o_cursor = take(sizeof(unsigned int) * K);
         o_nitems = take(sizeof(unsigned int));
         if (want_medians) {
-            const int Dw_max = D < pilot::SELECT_MAX_DIMS ? D : pilot::SELECT_MAX_DIMS;
-            // rows per select item: about 64 K keys a block, fewer while that leaves CUs without a block; a multiple of 4
-            R = 65536 / Dw_max;
-            const long R_fill = (long)(C / (2LL * n_cu));
-            if (R > R_fill) R = R_fill;
-            if (R < 64) R = 64;
-            R = (R + 3) & ~3L;
+            // rows per select item (the unit the passes are balanced in; a block takes a run of items): 256, more only to
+            // keep the list below 64 K items; a multiple of 4
+            R = 256;
+            if (C / R > 65536) R = (long)(((C / 65536) + 3) & ~3LL);
             max_items = (long)(C / R) + K + 1;
             o_hist = take(sizeof(unsigned int) * (size_t)K * D * 2 * 256);
         } else {
@@ -1481,11 +1492,16 @@ int launch_medians(const PrepassWs &ws, unsigned char *w, const T *dXp, const in
     const size_t lds = sizeof(U) * 2 * (size_t)Dw_max + sizeof(unsigned int) * (size_t)Dw_max * 2 * 256;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::select_hist_kernel<T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // as many histogram blocks as the chip holds at once (LDS-bound), each with an equal run of the work list
+    long hist_grid = (long)ws.n_cu * (long)((160 * 1024) / (lds + 256) < (size_t)(2048 / pilot::SELECT_THREADS) ? (160 * 1024) / (lds + 256)
+                                                                                                                 : (size_t)(2048 / pilot::SELECT_THREADS));
+    if (hist_grid > ws.max_items) hist_grid = ws.max_items;
+    if (hist_grid < 1) hist_grid = 1;
     const unsigned pick_blocks = (unsigned)(((size_t)K * D * 64 + 255) / 256);
     for (int shift = pilot::OrderedKey<T>::BITS - 8; shift >= 0; shift -= 8) {
         for (int dbeg = 0; dbeg < D; dbeg += Dw_max) {           // any D: the dimensions in windows that fit the LDS histograms
             const int Dw = D - dbeg < Dw_max ? D - dbeg : Dw_max;
-            hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)ws.max_items), dim3(pilot::SELECT_THREADS),
+            hipLaunchKernelGGL(pilot::select_hist_kernel<T>, dim3((unsigned)hist_grid), dim3(pilot::SELECT_THREADS),
                                sizeof(U) * 2 * (size_t)Dw + sizeof(unsigned int) * (size_t)Dw * 2 * 256, nullptr, d_y, D, dbeg, Dw,
                                d_nitems, d_items, shift, d_st, d_hist);
         }
@@ -1604,7 +1620,9 @@ int centroid_medians_impl(const void *X, const void *dXdev, long long C, int D, 
     if (e == hipSuccess) e = hipMemcpy(d_cell, cell_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
     if (e == hipSuccess && !small) e = hipMemsetAsync(w, 0, ws.clear_bytes, nullptr);
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    g_clock.start();
     const int rc = small ? launch_small_medians<T>(dXp, C, D, d_cell, K, n_max, d_out) : launch_medians<T>(ws, w, dXp, d_cell, false);
+    g_clock.stop();
     if (rc != PILOT_OT_OK) return rc;
     HIP_TRY(hipMemcpy(centroids, d_out, sizeof(double) * (size_t)K * D, hipMemcpyDeviceToHost));
     return PILOT_OT_OK;
@@ -1633,10 +1651,12 @@ int prepass_impl(const pilot_ot_embedding *emb, const int *cell_code, const int 
     if (e == hipSuccess) e = hipMemcpy(d_sample, sample_code, sizeof(int) * (size_t)C, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemsetAsync(w, 0, ws.clear_bytes, nullptr);
     if (e != hipSuccess) return fail(PILOT_OT_EHIP, "device staging failed: %s", hipGetErrorString(e));
+    g_clock.start();
     launch_counts(ws, w, d_cell, d_sample, n_total, regulizer, normalization, true);
     const T *dXp = static_cast<const T *>(emb->dX);
     double *d_cen = reinterpret_cast<double *>(res + r_P);
     int rc = small ? launch_small_medians<T>(dXp, C, D, d_cell, K, n_max, d_cen) : launch_medians<T>(ws, w, dXp, d_cell, true);
+    g_clock.stop();
     if (rc != PILOT_OT_OK) return rc;
     hipError_t he = hipMemcpyAsync(res, w + ws.o_P, r_P, hipMemcpyDeviceToDevice, nullptr);
     if (he == hipSuccess && !small) he = hipMemcpyAsync(d_cen, w + ws.o_out, r_cen, hipMemcpyDeviceToDevice, nullptr);
@@ -1673,6 +1693,15 @@ PILOT_API int pilot_ot_centroid_medians_dev(pilot_ot_embedding *e, const int *ce
     if (dev != e->device) return fail(PILOT_OT_EINVAL, "the embedding lives on device %d, the current device is %d", e->device, dev);
     if (e->dtype == PILOT_OT_F32) return centroid_medians_impl<float>(nullptr, e->dX, e->C, e->D, cell_code, K, centroids);
     return centroid_medians_impl<double>(nullptr, e->dX, e->C, e->D, cell_code, K, centroids);
+}
+
+PILOT_API int pilot_ot_prepass_device_ms(float *ms) {
+    if (!ms) return fail(PILOT_OT_EINVAL, "NULL pointer");
+    PrepassClock &c = g_clock;
+    if (!c.valid) return fail(PILOT_OT_EINVAL, "no pre-pass has run on this thread");
+    HIP_TRY(hipEventSynchronize(c.ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms, c.ev[0], c.ev[1]));
+    return PILOT_OT_OK;
 }
 
 PILOT_API int pilot_ot_prepass_dev(pilot_ot_embedding *e, const int *cell_code, const int *sample_code, long long n_total, int N, int K,

@@ -163,15 +163,20 @@ template <> struct OrderedKey<double> {
 //   3. group_rows_kernel      ONE read of the embedding, ONE write of its order-preserving keys with the rows of a type
 //                             contiguous (a block ranks its 1024 cells per type in LDS, reserves a run per type with one
 //                             global add, and copies its rows; reads fully coalesced, writes in whole rows);
-//   4. select_hist_kernel  x BITS/8: a block streams one contiguous chunk of rows of ONE type with 16-byte loads, lane = 4
-//                             consecutive elements, i.e. every lane busy whatever D is; the 256-bin histograms of all D dimensions sit in
-//                             LDS, so the lanes of a wave spread over D histograms (2 - 3 lanes on a bin, not 64);
+//   4. select_hist_kernel  x BITS/8: a block streams contiguous rows of ONE type with 16-byte loads, lane = 4 consecutive
+//                             elements, i.e. every lane busy whatever D is; the 256-bin histograms of all D dimensions sit in
+//                             LDS, so the lanes of a wave spread over D histograms (2 - 3 lanes on a bin, not 64); the chip
+//                             holds every block at once and each takes an equal share of the rows;
 //      select_pick_kernel     a wave per (type, dimension): the digit that holds the wanted rank; the last one writes the
 //                             medians.
 // HBM traffic per call: C*D*s read + written once, then BITS/8 reads of C*D*s -- the model DESIGN.md prices the pass against.
+// Tuning, measured on 1.8 M x 30 floats (tools/prepass_variants.sh, profiles/r06/prepass_variants.txt): group_rows 1024 rows a
+// block 154 us (512: 165, 256: 187 -- more blocks queue on the cursor adds; 2048: 200, 4096: 278 -- too few waves in flight);
+// select_hist 1024 threads a block 48.8 us (512: 51.6 here, 67.9 with one block per 64 K keys instead of equal runs of the work
+// list; 256: 107), plain loads (non-temporal: +3 us), four 16-byte loads in flight per lane (2: 49.4, 8: 72).
 constexpr int GROUP_ROWS_PER_BLOCK = 1024;
 constexpr int SELECT_MAX_DIMS = 64;                      // dimensions per histogram window (LDS: 2 x 64 x 256 counters = 128 KB)
-constexpr int SELECT_THREADS = 512;                      // select_hist_kernel: two such blocks per CU at D = 30 (62 KB of LDS each)
+constexpr int SELECT_THREADS = 1024;                     // select_hist_kernel: two such blocks per CU at D = 30 (62 KB of LDS each)
 
 __global__ void __launch_bounds__(256) type_count_kernel(const int *__restrict__ cell_code, long C, int K, unsigned int *__restrict__ n_k) {
     extern __shared__ unsigned int tc_bins[];            // K
@@ -286,8 +291,11 @@ __global__ void __launch_bounds__(256) group_rows_kernel(const T *__restrict__ X
     }
 }
 
-// one radix pass (8 bits at `shift`) over the dimension window [dbeg, dbeg + Dw): item = one chunk of rows of one type.
-// VEC keys per 16-byte load when the window is the whole row (the chunk is then one contiguous, 16-byte aligned range).
+// one radix pass (8 bits at `shift`) over the dimension window [dbeg, dbeg + Dw).  The work list is cut into gridDim.x
+// equal runs of items; consecutive items of one type are adjacent rows, so a block streams ONE contiguous range per type
+// it meets (usually one or two) and flushes its LDS histograms when the type changes.
+// VEC keys per 16-byte load when the window is the whole row (a range then starts 16-byte aligned: segment starts and
+// item lengths are multiples of 4 rows).
 template <typename T>
 __global__ void __launch_bounds__(SELECT_THREADS) select_hist_kernel(const typename OrderedKey<T>::U *__restrict__ Y, int D, int dbeg, int Dw,
                                                           const unsigned int *__restrict__ n_items, const SelectItem *__restrict__ items,
@@ -296,73 +304,85 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_hist_kernel(const typen
     using OK = OrderedKey<T>;
     using U = typename OK::U;
     constexpr int VEC = 16 / (int)sizeof(U);
-    if (blockIdx.x >= *n_items) return;
+    const unsigned int total_items = *n_items;
+    const unsigned int i0 = (unsigned int)(((unsigned long long)blockIdx.x * total_items) / gridDim.x),
+                       i1 = (unsigned int)(((unsigned long long)(blockIdx.x + 1) * total_items) / gridDim.x);
+    if (i0 >= i1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
     U *pre = reinterpret_cast<U *>(sh_raw);                                 // [2][Dw] prefixes of the two queries
     unsigned int *lh = reinterpret_cast<unsigned int *>(pre + 2 * Dw);      // [2][Dw][256]
-    const SelectItem it = items[blockIdx.x];
-    const int k = (int)it.k;
     const int nbins = Dw * 2 * 256;
-    for (int i = threadIdx.x; i < nbins; i += SELECT_THREADS) lh[i] = 0u;
     const bool first = shift + 8 >= OK::BITS;                               // (no state yet: nothing is fixed, every key counts)
-    for (int i = threadIdx.x; i < 2 * Dw; i += SELECT_THREADS) pre[i] = first ? U(0) : st[((size_t)k * D + dbeg + (i % Dw)) * 2 + (i / Dw)].prefix;
-    __syncthreads();
-    const U himask = (shift + 8 >= OK::BITS) ? U(0) : (~U(0) << (shift + 8));
+    const U himask = first ? U(0) : (~U(0) << (shift + 8));
     const unsigned int uDw = (unsigned int)Dw;
+    for (int i = threadIdx.x; i < nbins; i += SELECT_THREADS) lh[i] = 0u;
     auto tally = [&](U key, unsigned int dl) {
         const unsigned int digit = (unsigned int)(key >> shift) & 255u;
         const U hi = key & himask, p0 = pre[dl], p1 = pre[uDw + dl];
         if (hi == p0) atomicAdd(&lh[(dl << 8) + digit], 1u);
         else if (hi == p1) atomicAdd(&lh[((uDw + dl) << 8) + digit], 1u);   // (the second histogram only where the queries parted)
     };
-    if (Dw == D) {
-        const U *src = Y + (size_t)it.r0 * D;
-        const size_t total = (size_t)(it.r1 - it.r0) * D, nvec = total / VEC;
-        using V = __attribute__((ext_vector_type(VEC))) U;
-        const V *src4 = reinterpret_cast<const V *>(src);
-        unsigned int dl = (unsigned int)(((size_t)threadIdx.x * VEC) % uDw);
-        const unsigned int step = ((unsigned int)SELECT_THREADS * VEC) % uDw;
-        size_t v = threadIdx.x;
-        constexpr int UNR = 4;
-        for (; v + (size_t)(UNR - 1) * SELECT_THREADS < nvec; v += (size_t)UNR * SELECT_THREADS) {
-            V x[UNR];
+    unsigned int i = i0;
+    while (i < i1) {
+        // the run of items of one type: rows [r0, r1)
+        const SelectItem head = items[i];
+        const int k = (int)head.k;
+        unsigned int r1 = head.r1;
+        for (++i; i < i1; ++i) { const SelectItem nx = items[i]; if ((int)nx.k != k) break; r1 = nx.r1; }
+        const unsigned int r0 = head.r0;
+        for (int j = threadIdx.x; j < 2 * Dw; j += SELECT_THREADS) pre[j] = first ? U(0) : st[((size_t)k * D + dbeg + (j % Dw)) * 2 + (j / Dw)].prefix;
+        __syncthreads();
+        if (Dw == D) {
+            const U *src = Y + (size_t)r0 * D;
+            const size_t total = (size_t)(r1 - r0) * D, nvec = total / VEC;
+            using V = __attribute__((ext_vector_type(VEC))) U;
+            const V *src4 = reinterpret_cast<const V *>(src);
+            unsigned int dl = (unsigned int)(((size_t)threadIdx.x * VEC) % uDw);
+            const unsigned int step = ((unsigned int)SELECT_THREADS * VEC) % uDw;
+            size_t v = threadIdx.x;
+            constexpr int UNR = 4;
+            for (; v + (size_t)(UNR - 1) * SELECT_THREADS < nvec; v += (size_t)UNR * SELECT_THREADS) {
+                V x[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) x[u] = __builtin_nontemporal_load(&src4[v + (size_t)u * SELECT_THREADS]);
+                for (int u = 0; u < UNR; ++u) x[u] = src4[v + (size_t)u * SELECT_THREADS];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
+                for (int u = 0; u < UNR; ++u) {
+                    unsigned int d2 = dl;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { tally(x[u][j], d2); d2 = d2 + 1u == uDw ? 0u : d2 + 1u; }
+                    dl += step; if (dl >= uDw) dl -= uDw;
+                }
+            }
+            for (; v < nvec; v += SELECT_THREADS) {
+                const V x = src4[v];
                 unsigned int d2 = dl;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { tally(x[u][j], d2); d2 = d2 + 1u == uDw ? 0u : d2 + 1u; }
+                for (int j = 0; j < VEC; ++j) { tally(x[j], d2); d2 = d2 + 1u == uDw ? 0u : d2 + 1u; }
                 dl += step; if (dl >= uDw) dl -= uDw;
             }
+            for (size_t e = nvec * VEC + threadIdx.x; e < total; e += SELECT_THREADS) tally(src[e], (unsigned int)(e % uDw));
+        } else {
+            // a window of a wide row: element (r, dl) at Y[(r0 + r) * D + dbeg + dl]
+            const unsigned int rows = r1 - r0;
+            unsigned int r = threadIdx.x / uDw, dl = threadIdx.x % uDw;
+            const unsigned int dr = (unsigned int)SELECT_THREADS / uDw, dd = (unsigned int)SELECT_THREADS % uDw;
+            while (r < rows) {
+                tally(Y[(size_t)(r0 + r) * D + dbeg + dl], dl);
+                r += dr; dl += dd;
+                if (dl >= uDw) { dl -= uDw; ++r; }
+            }
         }
-        for (; v < nvec; v += SELECT_THREADS) {
-            const V x = __builtin_nontemporal_load(&src4[v]);
-            unsigned int d2 = dl;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) { tally(x[j], d2); d2 = d2 + 1u == uDw ? 0u : d2 + 1u; }
-            dl += step; if (dl >= uDw) dl -= uDw;
+        __syncthreads();
+        unsigned int *gh0 = hist + (((size_t)k * D + dbeg) * 2) * 256;      // [d][q][256] in global memory
+        for (int j = threadIdx.x; j < nbins; j += SELECT_THREADS) {
+            const unsigned int c = lh[j];
+            if (c) {
+                const int q = j / (Dw * 256), dl = (j >> 8) % Dw;
+                atomicAdd(&gh0[((size_t)dl * 2 + q) * 256 + (j & 255)], c);
+                lh[j] = 0u;                                                   // (clean for the next type)
+            }
         }
-        for (size_t e = nvec * VEC + threadIdx.x; e < total; e += SELECT_THREADS) tally(src[e], (unsigned int)(e % uDw));
-    } else {
-        // a window of a wide row: element (r, dl) at Y[(r0 + r) * D + dbeg + dl]
-        const unsigned int rows = it.r1 - it.r0;
-        unsigned int r = threadIdx.x / uDw, dl = threadIdx.x % uDw;
-        const unsigned int dr = (unsigned int)SELECT_THREADS / uDw, dd = (unsigned int)SELECT_THREADS % uDw;
-        while (r < rows) {
-            tally(Y[(size_t)(it.r0 + r) * D + dbeg + dl], dl);
-            r += dr; dl += dd;
-            if (dl >= uDw) { dl -= uDw; ++r; }
-        }
-    }
-    __syncthreads();
-    unsigned int *gh0 = hist + (((size_t)k * D + dbeg) * 2) * 256;          // [d][q][256] in global memory
-    for (int i = threadIdx.x; i < nbins; i += SELECT_THREADS) {
-        const unsigned int c = lh[i];
-        if (c) {
-            const int q = i / (Dw * 256), dl = (i >> 8) % Dw;
-            atomicAdd(&gh0[((size_t)dl * 2 + q) * 256 + (i & 255)], c);
-        }
+        __syncthreads();
     }
 }
 
