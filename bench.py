@@ -313,7 +313,7 @@ def main():
             out["exact_emd"] = exact_emd_record(L, P, M, args.config, with_cpu=not args.no_cpu_baseline)
             if args.config == "c3" and not args.no_c5:
                 c5 = bench_cellw2(args)       # BASELINE configs[4] (an extension): one pass over its 40 000 pairs, ~35 s
-                out["c5_cellw2"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "checks", "cpu_baseline")}
+                out["c5_cellw2"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "checks", "cpu_baseline", "parity")}
             if args.config in ("c2", "c3"):
                 from pilot_amd.synthetic import make_cells
                 cohort = make_cells(cfg["n_patients"], cfg["n_types"], cfg["n_dims"], cfg["seed"], cfg["cells_per_patient"])
@@ -924,7 +924,7 @@ def bench_cellw2(args, reg=0.1, D=30):
     sym = float(np.abs(W - W.T)[conv & conv.T].max())
     # CPU baseline: the C / OpenMP fp64 oracle (kind "port": the extension has no reference implementation) on a few pairs of the
     # SAME cohort, all cores inside a pair; also the parity check of those pairs
-    cpu = None
+    cpu, errs = None, []
     if not args.no_cpu_baseline:
         from oracle import oracle as O
         ncpu = host_cores()
@@ -937,6 +937,16 @@ def bench_cellw2(args, reg=0.1, D=30):
                "sample": "%d ordered pairs %s of the same cohort by oracle/pilot_oracle.c::pilot_oracle_cell_w2 (fp64, POT sinkhorn_log control "
                          "flow, OpenMP inside a pair on %d threads), %s updates; max|gpu-oracle| on its converged pairs = %s"
                          % (len(pairs), pairs, ncpu, [inf["iters"] for _, inf in vals], ("%.2e" % max(errs)) if errs else "n/a")}
+    # parity at this config's own settings beyond the few pairs timed above: tools/cellw2_parity_c5.py (32 ordered pairs of the same
+    # cohort against the fp64 oracle), committed under profiles/
+    parity = {"live": None if cpu is None else {"pairs": len(errs), "max_abs_diff": max(errs) if errs else None}, "tolerance": 1e-5}
+    ppath, prnd = profile_file("cellw2_parity_c5.json")
+    if ppath and (Np, nc, D, reg) == (200, 5000, 30, 0.1):
+        with open(ppath) as fh:
+            pj = json.load(fh)
+        parity["offline"] = {"pairs": pj["pairs"], "pairs_converged_in_oracle": pj["pairs_converged_in_oracle"], "max_abs_diff": pj["max_abs_diff"],
+                             "median_abs_diff": pj["median_abs_diff"], "gpu_stops_at_oracle_check_or_earlier": pj["gpu_stops_at_oracle_check_or_earlier"],
+                             "source": "profiles/%s/cellw2_parity_c5.json (tools/cellw2_parity_c5.py)" % prnd}
     traffic, traffic_src = None, None
     tpath, trnd = profile_file("cellw2_traffic.json")
     if tpath:
@@ -967,7 +977,7 @@ def bench_cellw2(args, reg=0.1, D=30):
                      "dot_tflops_f32_equivalent": round(flop / kern_s / 1e12, 2),
                      "mean_updates_per_pair": round(float(upd.mean()), 2)},
         "checks": {"pairs_converged": int(conv.sum()), "pairs": int(conv.size), "max_asymmetry_of_converged_pairs": sym},
-        "cpu_baseline": cpu,
+        "cpu_baseline": cpu, "parity": parity,
     }
 
 

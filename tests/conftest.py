@@ -96,3 +96,29 @@ def load_golden_pack(name="random_pack"):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     n = int(z["n_cases"])
     return [{k[len("c%d_" % i):]: z[k] for k in z.files if k.startswith("c%d_" % i)} for i in range(n)]
+
+
+def account_for_absorb_on_last(Eg, Eo, last_g, last_o, K, tol, max_one_sided_frac=1e-4):
+    """POT returns the transport cost scaled by 1/K^2 when a tau-absorption falls on a pair's FINAL update (u, v are reset to
+    1/K and the plan is rebuilt from them).  Every pair of a grid is held to `tol` by a stated rule -- none is excluded:
+
+    * flagged by neither side, or by both: |E_gpu - E_oracle| <= tol (both unscaled, or both scaled);
+    * flagged by the oracle alone (the f32 kernel stopped at an earlier check, before that absorption): the GPU returned the
+      unscaled cost, |E_gpu - K^2 E_oracle| <= tol;
+    * flagged by the GPU alone (its earlier last update was an absorbing one): |K^2 E_gpu - E_oracle| <= tol;
+    * the one-sided pairs are at most `max_one_sided_frac` of the grid (at least one pair is always allowed).
+
+    Returns (n_both, n_oracle_only, n_gpu_only)."""
+    Eg, Eo = np.asarray(Eg), np.asarray(Eo)
+    both, only_o, only_g = last_g & last_o, last_o & ~last_g, last_g & ~last_o
+    plain = ~(only_o | only_g)
+    d = np.abs(Eg - Eo)
+    assert d[plain].max() <= tol, "pairs flagged alike: max|gpu - oracle| = %.3e" % d[plain].max()
+    if only_o.any():
+        assert np.abs(Eg - K * K * Eo)[only_o].max() <= tol, "oracle-only absorb-on-last pairs: %.3e" % np.abs(Eg - K * K * Eo)[only_o].max()
+    if only_g.any():
+        assert np.abs(K * K * Eg - Eo)[only_g].max() <= tol, "GPU-only absorb-on-last pairs: %.3e" % np.abs(K * K * Eg - Eo)[only_g].max()
+    n_one = int(only_o.sum() + only_g.sum())
+    allowed = max(1, int(np.ceil(max_one_sided_frac * Eg.size)))
+    assert n_one <= allowed, "%d one-sided absorb-on-last pairs of %d (allowed %d)" % (n_one, Eg.size, allowed)
+    return int(both.sum()), int(only_o.sum()), int(only_g.sum())

@@ -11,6 +11,7 @@ Tolerances: f32 <= 1e-5, f64 <= 1e-12 (reg 0.01: <= 1e-9, values pass through ex
 import numpy as np
 import pytest
 
+from conftest import account_for_absorb_on_last
 from oracle import oracle as O
 from pilot_amd import _lib, engine
 from pilot_amd.synthetic import CONFIGS, make_cell_clouds, make_problem
@@ -57,7 +58,8 @@ def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle, monkeypatch):
     same = ig["iters"] == io["iters"]
     print("auto @ reg 0.01: %d of %d pairs in f64, max|gpu - oracle| %.3e (pairs with the oracle's update count: %d, %.3e)"
           % (f64.sum(), Eg.size, np.abs(Eg - Eo)[~last_o & ~last_g].max(), same.sum(), np.abs(Eg - Eo)[same & ~last_o].max()))
-    assert np.abs(Eg - Eo)[~last_o & ~last_g].max() <= TOL32
+    # every pair accounted for (conftest.account_for_absorb_on_last): one-sided flags are pairs where one side returned cost / K^2
+    account_for_absorb_on_last(Eg, Eo, last_g, last_o, P.shape[1], TOL32, max_one_sided_frac=1e-4)
     assert np.all(ig["iters"] <= io["iters"])                      # f32 stop-threshold floor: same or an earlier check
     np.testing.assert_array_equal(last_g[same], last_o[same])
     if f64.any():                                                  # pairs solved in f64 match update for update
@@ -138,7 +140,7 @@ def test_c5_converged_pairs_of_thousands_of_cells_against_the_c_oracle():
     floored at the f32 resolution of the marginal; at reg 0.1 the fp64 oracle needs several times as many updates to get from
     1e-8 to 1e-9), never later, and must agree within the f32 tolerance either way."""
     n_conv = 0
-    for cells, reg, pairs in ((2000, 0.2, ((0, 1), (1, 1), (2, 0))), (5000, 0.2, ((1, 0), (2, 2))), (2000, 0.1, ((0, 2),))):
+    for cells, reg, pairs in ((2000, 0.2, ((0, 1), (1, 1), (2, 0))), (5000, 0.2, ((1, 0), (2, 2))), (2000, 0.1, ((0, 2),)), (5000, 0.1, ((0, 1),))):
         X, offs, scale = make_cell_clouds(3, cells, 30, seed=cells + int(100 * reg))
         Wg, ig = engine.cell_w2_grid(X, offs, scale, reg, return_info=True)
         for i, j in pairs:
@@ -148,7 +150,7 @@ def test_c5_converged_pairs_of_thousands_of_cells_against_the_c_oracle():
             assert abs(Wg[i, j] - wo) <= C5_TOL, (cells, reg, i, j, Wg[i, j], wo, ig["iters"][i, j], info["iters"])
             print("cell-level W2, %d cells, reg %g, pair (%d, %d): oracle %d updates (err %.1e), gpu %d, |d| = %.2e"
                   % (cells, reg, i, j, info["iters"], info["err"], ig["iters"][i, j], abs(Wg[i, j] - wo)))
-    assert n_conv >= 4          # the reg 0.2 pairs converge under POT's own rule in fp64
+    assert n_conv >= 5          # the reg 0.2 pairs converge under POT's own rule in fp64, and so does config 5's own 5000-cell reg 0.1 pair
 
 
 def test_c5_full_size_cohort_properties():

@@ -4,7 +4,7 @@ Tolerances (BASELINE.json north star): |EMD_gpu - EMD_oracle|_inf <= 1e-5 in f32
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, account_for_absorb_on_last, load_golden
 from oracle import oracle as O
 from pilot_amd import _lib, engine
 from pilot_amd.synthetic import CONFIGS, make_problem
@@ -330,8 +330,9 @@ def test_single_digit_cell_type_counts_stay_on_the_mfma_kernels(K, monkeypatch):
     absorbed = (io["flags"] & O.FLAG_ABSORBED) > 0
     assert absorbed.sum() > 0                                   # the case this test is about occurs in the cohort
     assert (((info["flags"] & _lib.FLAG_ABSORBED) > 0) != absorbed).mean() < 0.01      # (a scaling within rounding of tau may differ)
-    edge = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((info["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
-    assert np.abs(E - Eo)[~edge].max() <= TOL32
+    last_o, last_g = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0, (info["flags"] & _lib.FLAG_ABSORB_LAST) > 0
+    edge = last_o | last_g
+    account_for_absorb_on_last(E, Eo, last_g, last_o, K, TOL32, max_one_sided_frac=1e-3)
     # duplicate patients (a == b, i != j: hundreds at this K) run in the tiles, the diagonal on waves of its own; both within tolerance
     dup = (np.abs(P[:, None, :] - P[None, :, :]).sum(-1) == 0) & ~np.eye(N, dtype=bool)
     assert dup.sum() > 0 or K > 3
@@ -350,9 +351,12 @@ def test_whole_grids_across_the_k_range_and_the_pairs_that_stop_later_than_pot(N
     P, M = make_problem(N, K, 8, seed=K, cells_per_patient=200)
     Eg, ig = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
     Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
-    last = ((io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0) | ((ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0)
+    last_o, last_g = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0, (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
+    last = last_o | last_g
     d = np.abs(Eg - Eo)
-    assert d[~last].max() <= TOL32
+    # (single-digit K: thousands of pairs absorb, and a pair that stops one check apart ends on the other side of an absorption
+    # more often than at c3's K -- bounded at 1e-3 of the grid there, 1e-4 from K = 17 on; each such pair checked against K^2)
+    account_for_absorb_on_last(Eg, Eo, last_g, last_o, K, TOL32, max_one_sided_frac=1e-4 if K >= 17 else 1e-3)
     later = ig["iters"] > io["iters"]
     allowed = 0 if K >= 17 or K == 2 else int(np.ceil(2e-4 * Eo.size))
     assert int(later.sum()) <= allowed, "%d pairs stop later than the oracle (allowed %d)" % (later.sum(), allowed)
@@ -371,14 +375,16 @@ def test_whole_grid_of_the_small_reg_sweep_at_test_size(reg):
     Eg, ig = engine.sinkhorn_grid(P, M, reg, return_info=True)
     Eo, io = O.sinkhorn_grid(P, M, reg, n_threads=16, return_info=True)
     last_o, last_g = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0, (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
-    d = np.abs(Eg - Eo)
-    assert d[~(last_o | last_g)].max() <= TOL32
+    # every pair accounted for: alike-flagged pairs within 1e-5; a one-sided flag means one side returned cost / K^2 and the
+    # other the cost, checked as such, and there are at most 1e-4 of the grid of them (VERDICT r05 weak #1a)
+    n_both, n_only_o, n_only_g = account_for_absorb_on_last(Eg, Eo, last_g, last_o, P.shape[1], TOL32, max_one_sided_frac=1e-4)
+    print("reg %g: absorb-on-last pairs: %d both, %d oracle only, %d GPU only of %d" % (reg, n_both, n_only_o, n_only_g, Eg.size))
     assert (ig["iters"] <= io["iters"]).all()
     same = ig["iters"] == io["iters"]
     assert int(((last_o ^ last_g) & same).sum()) <= 1          # (a scaling within an f32 rounding of tau on its last update: the knife edge)
     both = last_o & last_g
     if both.any():
-        assert d[both].max() <= 1e-12                           # both returned the 1/K^2-scaled cost
+        assert np.abs(Eg - Eo)[both].max() <= 1e-12             # both returned the 1/K^2-scaled cost
     if reg == 0.01:
         assert (io["iters"] >= 1000).mean() > 0.4 and ((io["flags"] & O.FLAG_ABSORBED) > 0).mean() > 0.9      # the regime this test is about
 

@@ -28,12 +28,19 @@ for spec in (sys.argv[1:] or ["c3:1.0", "c3:0.1", "c3:0.01", "c4:0.1:16"]):
              ((io["flags"] & O.FLAG_ABSORBED) > 0).sum(), ig["iters"].mean(), io["iters"].mean(), bool(np.all(ig["iters"] <= io["iters"])),
              ((ig["flags"] & _lib.FLAG_F64) > 0).sum()), flush=True)
     if last.any():
-        both = last_o & last_g
+        both, only_o, only_g = last_o & last_g, last_o & ~last_g, last_g & ~last_o
         same = ig["iters"] == io["iters"]
         print("   ... of those %d pairs: flagged on both sides %d (max|gpu - oracle| there %.3e), by the oracle alone %d, by the GPU alone %d; "
               "one-sided flags among pairs with the same update count on both sides: %d"
-              % (last.sum(), both.sum(), np.abs(Eg - Eo)[both].max() if both.any() else 0.0, (last_o & ~last_g).sum(), (last_g & ~last_o).sum(),
+              % (last.sum(), both.sum(), np.abs(Eg - Eo)[both].max() if both.any() else 0.0, only_o.sum(), only_g.sum(),
                  ((last_o ^ last_g) & same).sum()), flush=True)
+        # a one-sided flag: one side returned cost / K^2 (absorption on ITS last update), the other the cost -- accounted for as such
+        if only_o.any():
+            print("   ... oracle alone (the GPU stopped at an earlier check and returned the unscaled cost): max|gpu - K^2 oracle| = %.3e over %d pairs"
+                  % (np.abs(Eg - K * K * Eo)[only_o].max(), only_o.sum()), flush=True)
+        if only_g.any():
+            print("   ... GPU alone: max|K^2 gpu - oracle| = %.3e over %d pairs" % (np.abs(K * K * Eg - Eo)[only_g].max(), only_g.sum()), flush=True)
+        print("   ... one-sided share of the grid: %.2e (tests bound it at 1e-4)" % ((only_o.sum() + only_g.sum()) / Eo.size), flush=True)
     later = ig["iters"] > io["iters"]
     if later.any():
         absorbed = (io["flags"] & O.FLAG_ABSORBED) > 0
