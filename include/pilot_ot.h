@@ -111,6 +111,12 @@ int pilot_ot_get_device(int *device);             /* the calling thread's curren
 int pilot_ot_device_name(char *buf, int buflen);  /* gcnArchName of the current device                 */
 int pilot_ot_shutdown(void);                      /* free the calling thread's cached host-API workspace */
 
+/* TEST HOOK, not part of the drop-in surface: forces a kernel variant or an out-of-range configuration for the GPU tests and the
+ * A/B tools (names as the tests use them, e.g. "PILOT_OT_NO_SMALL_MEDIANS", "PILOT_OT_RAW_PRECISION"); some settings return results
+ * OUTSIDE the stated tolerance -- that is what they are for.  Process-wide; value NULL clears one switch, name NULL clears all.
+ * The library reads no environment variable that changes what it computes. */
+int pilot_ot_test_switch(const char *name, const char *value);
+
 /* thin device-memory helpers so a host language without a HIP binding can keep data resident */
 int pilot_ot_dev_alloc(void **dptr, unsigned long long bytes);
 int pilot_ot_dev_free(void *dptr);
@@ -197,8 +203,10 @@ int pilot_ot_sinkhorn_grid(const double *P, int N, int K, const double *M, doubl
                            double *emd, int *iters, double *err, int *flags);
 
 /* Device-resident form.  A plan owns the device workspace for one (N, K) shape so the call itself
- * allocates nothing (HIP-graph capturable) -- with one exception: the scratch of the POT-literal kernel (PREC_GENERIC,
- * 2 K^2 doubles per resident workgroup) is allocated by the first call that runs that kernel. */
+ * allocates nothing (HIP-graph capturable) -- with two exceptions, each ONE allocation made by the first call that needs it
+ * and kept until pilot_ot_plan_destroy (so make that first call outside a stream capture): the scratch of the POT-literal
+ * kernel (PREC_GENERIC, 2 K^2 doubles per resident workgroup), and the flow slab of the exact-OT kernels
+ * (pilot_ot_emd_grid_dev: K^2 doubles per resident pair, sized once for every kernel variant of the plan's K). */
 typedef struct pilot_ot_plan pilot_ot_plan;
 int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan);
 int pilot_ot_plan_destroy(pilot_ot_plan *plan);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "pilot_ot_sinkhorn_grid_dev", "pilot_ot_auto_precision", "pilot_ot_auto_precision_for", "pilot_ot_resolve_precision", "pilot_ot_emd_grid", "pilot_ot_emd_grid_dev",
     "pilot_ot_plan_enable_timing", "pilot_ot_plan_kernel_times", "pilot_ot_plan_enable_graph", "pilot_ot_shutdown",
     "pilot_ot_proportions", "pilot_ot_proportions_ex", "pilot_ot_centroid_medians", "pilot_ot_embedding_upload",
-    "pilot_ot_embedding_destroy", "pilot_ot_centroid_medians_dev", "pilot_ot_prepass_dev", "pilot_ot_prepass_device_ms", "pilot_ot_label_codes", "pilot_ot_cell_w2_grid",
+    "pilot_ot_embedding_destroy", "pilot_ot_centroid_medians_dev", "pilot_ot_prepass_dev", "pilot_ot_prepass_device_ms", "pilot_ot_label_codes", "pilot_ot_test_switch", "pilot_ot_cell_w2_grid",
     "pilot_ot_cell_cohort_create", "pilot_ot_cell_cohort_destroy", "pilot_ot_cell_cohort_pieces", "pilot_ot_cell_w2_grid_cohort", "pilot_ot_cell_w2_grid_multi",
     "pilot_ot_mirror_upper_dev",
     "pilot_ot_row_distances", "pilot_ot_row_distances_dev", "pilot_ot_silhouette", "pilot_ot_knn_kernel",
@@ -105,6 +105,7 @@ def load() -> ctypes.CDLL:
     L.pilot_ot_centroid_medians_dev.argtypes = [c_vp, ip, c_int, dp]
     L.pilot_ot_prepass_dev.argtypes = [c_vp, ip, ip, ctypes.c_longlong, c_int, c_int, c_dbl, c_int, dp, ctypes.POINTER(ctypes.c_longlong), dp]
     L.pilot_ot_prepass_device_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.pilot_ot_test_switch.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.pilot_ot_label_codes.argtypes = [c_vp, c_int, ctypes.c_longlong, c_int, c_int, ip, ctypes.POINTER(ctypes.c_longlong), ip]
     L.pilot_ot_cell_w2_grid.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl, c_int, c_int, c_int,
                                         dp, ip, dp]
@@ -164,6 +165,11 @@ def check(rc: int) -> None:
     if rc == ERCCL:
         raise PilotOTError("pilot_ot (RCCL): " + msg)
     raise PilotOTError("pilot_ot (HIP): " + msg)
+
+
+def test_switch(name=None, value=None) -> None:
+    """TEST HOOK (``pilot_ot_test_switch``): force a kernel variant; ``value=None`` clears the switch, ``name=None`` all of them."""
+    check(load().pilot_ot_test_switch(None if name is None else name.encode(), None if value is None else str(value).encode()))
 
 
 def device_count() -> int:

@@ -10,6 +10,9 @@ namespace pilot {
 
 // record the calling thread's error message (pilot_ot_last_error) and return `code`
 int abi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// value of a test switch (pilot_ot_test_switch), or nullptr: how the GPU tests and the A/B tools force a kernel variant.  The
+// library reads NO environment variable that changes what it computes.
+const char *test_switch(const char *name);
 // release every cached multi-GPU context of the host-buffer entry points (called by pilot_ot_shutdown)
 void abi_multi_release();
 // a buffer of the calling thread's pool of device temporaries (grown on demand, released by pilot_ot_shutdown); slots 0 .. 11

@@ -28,6 +28,16 @@
 
 namespace pilot {
 
+// Lanes of one wave hand data to each other through memory (the flow block, the arc scratch) without a workgroup barrier: DS
+// operations of a wave retire in order, but the COMPILER must not reorder or forward across the hand-over either.  Flows in LDS: a
+// wavefront-scope release fence + wave barrier (no instructions on the hardware); flows in the global slab: a workgroup-scope
+// release, as before.
+template <bool FLDS> __device__ inline void emd_wave_sync() {
+    if constexpr (FLDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    else EMD_FENCE();
+    __builtin_amdgcn_wave_barrier();
+}
+
 // the partner's x under a DPP control that gives every lane of a row a partner
 template <int CTRL> __device__ inline unsigned int dppx_u32(unsigned int x) {
     return (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, 0xf, 0xf, false);    // (old = the identity of min: the move folds into v_min_u32_dpp)
@@ -124,7 +134,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
     double *F = FLDS ? rowmin + K + 8 * waves + ((size_t)wave * NG + g) * K * K
                      : p.f_slab + (((size_t)blockIdx.x * waves + wave) * NG + g) * K * K;
     for (int t = c; t < K * K; t += G) F[t] = 0.0;
-    if constexpr (!FLDS) { EMD_FENCE(); __builtin_amdgcn_wave_barrier(); }
+    emd_wave_sync<FLDS>();
 
     auto gfield = [&](u64 b) -> unsigned int { return (unsigned int)(b >> gsh) & FM; };
     auto in_mask = [](u64 m) -> bool { return __builtin_amdgcn_inverse_ballot_w64(m); };
@@ -184,7 +194,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
                                 if (p.n_aug) p.n_aug[q] = tripped ? -(n_aug * 8 + trip_code) : n_aug;
 #endif
                             }
-                            if constexpr (!FLDS) { EMD_FENCE(); __builtin_amdgcn_wave_barrier(); }
+                            emd_wave_sync<FLDS>();
                             have_pair = false;
                         }
                         // next pair of the group (queue: see emd_grid_kernel)
@@ -227,7 +237,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
                             const double f = a_ < b_ ? a_ : b_;
                             if (f > 0.0) { F[c * K + c] = f; ship = 1u << c; a_ -= f; b_ -= f; }
                         }
-                        if constexpr (!FLDS) { EMD_FENCE(); __builtin_amdgcn_wave_barrier(); }
+                        emd_wave_sync<FLDS>();
                         ra = a_; rb = b_;
                         prev_src = 0u; n_aug = 0; n_search = 0; tripped = false; trip_code = 0; have_pair = true;
 #ifdef EMD_MSTAT
@@ -269,7 +279,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
             if (EMD_MSTAT == 2 && on && !rebuild) ++n_stat;
             if (EMD_MSTAT == 5 && on && rebuild) ++n_stat;
 #endif
-            const int i = __builtin_ctz(Rf | (1u << (G - 1)));     // (index 0 where the group has no row left: selected away)
+            const int i = on ? __builtin_ctz(Rf) : 0;              // (row 0 where the group has no row left: a valid address, selected away)
             Rf &= Rf - 1u;
             const double t_i = bperm_f64(puN, gsh + i);                  // pu_i - d_i
             const pm_t pm_i = bperm_pm(pmR, gsh + i);
@@ -313,6 +323,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
                 const bool onC = aug && ((pm_t_ >> c) & 1u), onR = aug && ((pm_t_ >> (G + c)) & 1u);
                 const bool is_t = aug && c == t;
                 if (onC) scr[gsh + parC] = (unsigned char)c;          // "your forward arc goes to me"
+                emd_wave_sync<true>();                                 // (other lanes of the wave read what this one stored)
                 const int fwd = scr[lane], bwd = parR;                 // (bwd < 0: the source row of the path)
                 double fb = INF;
                 if (onR && bwd >= 0) fb = F[c * K + bwd];
@@ -323,7 +334,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))
                     F[c * K + fwd] += delta;
                     if (bwd >= 0) F[c * K + bwd] = fb - delta;
                 }
-                if constexpr (!FLDS) { EMD_FENCE(); __builtin_amdgcn_wave_barrier(); }
+                emd_wave_sync<FLDS>();
                 const bool emp = onR && bwd >= 0 && fb == delta;      // a backward arc ran empty: it leaves the support
                 ship = onR ? ((ship | (1u << fwd)) & ~(emp ? 1u << bwd : 0u)) : ship;
                 const bool isrc = onR && bwd < 0;

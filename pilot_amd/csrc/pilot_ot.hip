@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <new>
 #include <vector>
 
@@ -207,7 +209,7 @@ static int emd_nk(int K) { return K <= 64 ? 1 : (K <= 128 ? 2 : (K <= 192 ? 3 : 
 // waves per SIMD still fit beside them; profiles/r05/emd_multi_probe.txt)
 constexpr int EMD_MULTI_MAX_K = 16;
 static int emd_multi_mode(int K) {
-    const char *e = getenv("PILOT_OT_EMD_MULTI");
+    const char *e = pilot::test_switch("PILOT_OT_EMD_MULTI");
     if (e && *e) return atoi(e);
     return K <= 15 ? 1 : 2;
 }
@@ -276,6 +278,31 @@ struct pilot_ot_plan {
 };
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// test switches: a process-wide table set through pilot_ot_test_switch (never from the environment)
+namespace {
+std::mutex g_switch_mutex;
+std::map<std::string, std::string> g_switches;
+}  // namespace
+namespace pilot {
+const char *test_switch(const char *name) {
+    static thread_local std::string value;                                 // (the caller's copy: another thread may set the switch meanwhile)
+    std::lock_guard<std::mutex> l(g_switch_mutex);
+    if (g_switches.empty()) return nullptr;
+    auto it = g_switches.find(name);
+    if (it == g_switches.end()) return nullptr;
+    value = it->second;
+    return value.c_str();
+}
+}  // namespace pilot
+
+PILOT_API int pilot_ot_test_switch(const char *name, const char *value) {
+    std::lock_guard<std::mutex> l(g_switch_mutex);
+    if (!name) { g_switches.clear(); return PILOT_OT_OK; }
+    if (value) g_switches[name] = value; else g_switches.erase(name);
+    return PILOT_OT_OK;
+}
+
 PILOT_API int pilot_ot_version(void) { return PILOT_OT_VERSION; }
 PILOT_API const char *pilot_ot_last_error(void) { return g_err; }
 
@@ -379,7 +406,7 @@ PILOT_API int pilot_ot_cost_matrix(const double *centroids, int K, int D, int me
 // ------------------------------------------------------------------------------------------------
 // range of the fp16-split configuration (PILOT_OT_H_MAX_COST_OVER_REG: experiment switch of tools/f16x2_range_probe.py)
 static double h_max_cost_over_reg() {
-    const char *e = getenv("PILOT_OT_H_MAX_COST_OVER_REG");
+    const char *e = pilot::test_switch("PILOT_OT_H_MAX_COST_OVER_REG");
     return e && *e ? atof(e) : pilot::H_MAX_COST_OVER_REG;
 }
 
@@ -413,7 +440,7 @@ PILOT_API int pilot_ot_resolve_precision(int precision, double max_cost_over_reg
     if (precision == PILOT_OT_PREC_GENERIC || max_cost_over_reg > PILOT_OT_MAX_COST_OVER_REG) return PILOT_OT_PREC_GENERIC;
     const bool f32_class = precision == PILOT_OT_PREC_F32 || precision == PILOT_OT_PREC_BF16X3 || precision == PILOT_OT_PREC_F16X2;
     // (PILOT_OT_RAW_PRECISION=1, tests only: run an explicit f32-class precision outside its range as asked)
-    const char *raw = getenv("PILOT_OT_RAW_PRECISION");
+    const char *raw = pilot::test_switch("PILOT_OT_RAW_PRECISION");
     const bool promote = f32_class && max_cost_over_reg > 60.0 && !(raw && *raw && *raw != '0');
     if (precision == PILOT_OT_PREC_AUTO || promote) {
         precision = pilot_ot_auto_precision_for(max_cost_over_reg, K, cost_is_symmetric);
@@ -572,7 +599,7 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
     g.list = list; g.list_len = list_len;
     int wgs = pl->generic_wgs < n_pairs ? pl->generic_wgs : n_pairs;
     if (list && wgs > 64) wgs = 64;          // a hand-over list is short (usually empty)
-    if (const char *e = getenv("PILOT_OT_GENERIC_WGS")) { const int w = atoi(e); if (w > 0 && w < wgs) wgs = w; }      // experiment switch
+    if (const char *e = pilot::test_switch("PILOT_OT_GENERIC_WGS")) { const int w = atoi(e); if (w > 0 && w < wgs) wgs = w; }      // experiment switch
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot::sinkhorn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pilot::sinkhorn_generic_kernel, dim3(wgs), dim3(pilot::GENERIC_WG), lds, s, g);
     HIP_TRY(hipGetLastError());
@@ -639,7 +666,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     const int N = pl->N, K = pl->K;
     const int RT = (K + TILE - 1) / TILE;
     const int KP = RT * TILE;
-    const char *dbg = getenv("PILOT_OT_DEBUG");
+    const char *dbg = pilot::test_switch("PILOT_OT_DEBUG");
     const int debug = dbg ? atoi(dbg) : 0;
     const size_t form = pilot::form_elems_rt(cfg, RT);
     // the per-wave hand-over buffers of the fast kernels
@@ -837,7 +864,7 @@ int run_wide(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     // the records are 2 KB per pair: a big grid is solved in row chunks of at most WIDE_CHUNK_PAIRS pairs (1 GB of records),
     // each a complete call of its own (same kernels, same pair -> same bits whatever the chunking)
     long WIDE_CHUNK_PAIRS = 512L * 1024;
-    if (const char *e = getenv("PILOT_OT_WIDE_CHUNK")) { const long v = atol(e); if (v > 0) WIDE_CHUNK_PAIRS = v; }     // (tests)
+    if (const char *e = pilot::test_switch("PILOT_OT_WIDE_CHUNK")) { const long v = atol(e); if (v > 0) WIDE_CHUNK_PAIRS = v; }     // (tests)
     if ((long)n_rows * N > WIDE_CHUNK_PAIRS && n_rows > 1) {
         const int rows_per = (int)(WIDE_CHUNK_PAIRS / N) > 0 ? (int)(WIDE_CHUNK_PAIRS / N) : 1;
         for (int r0 = 0; r0 < n_rows; r0 += rows_per) {
@@ -925,7 +952,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
         // call is inside the fp16-split range with a symmetric cost; an explicit f64 / POT-literal request, a non-symmetric cost
         // or a smaller reg keep the POT-literal kernel
         if (pl->K > MAX_K && pl->K <= WIDE_MAX_K && cost_is_symmetric && precision != PILOT_OT_PREC_GENERIC && precision != PILOT_OT_PREC_F64 &&
-            pl->max_cost / reg <= h_max_cost_over_reg() && tau <= pilot::H_MAX_TAU && !getenv("PILOT_OT_NO_WIDE")) {
+            pl->max_cost / reg <= h_max_cost_over_reg() && tau <= pilot::H_MAX_TAU && !pilot::test_switch("PILOT_OT_NO_WIDE")) {
             if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
             return run_wide(pl, d_P, d_M, reg, num_iter_max, stop_thr, tau, check_period, f32_floor_ulps, row_begin, n_rows_g, row_step, d_emd,
                             d_iters, d_err, d_flags, static_cast<hipStream_t>(stream));
@@ -943,7 +970,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
         mixed = true;
     }
     // beyond the f32 range AUTO still tries f32 first, pair by pair, where the split images fit and POT's defaults hold
-    mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && pl->max_cost / reg <= 140.0 && !getenv("PILOT_OT_NO_MIXED");
+    mixed = mixed && split_fits_lds(pl->K, cost_is_symmetric != 0, 2) && pl->max_cost / reg <= 140.0 && !pilot::test_switch("PILOT_OT_NO_MIXED");
     if (!(f32_floor_ulps > 0.0)) f32_floor_ulps = 8.0;
     const int n_rows = (row_end - row_begin + row_step - 1) / row_step;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -963,7 +990,7 @@ PILOT_API int pilot_ot_sinkhorn_grid_dev(pilot_ot_plan *pl, const double *d_P, c
     if (!pl->graph_mode || pl->timing || n_rows == 0) return run(s);
     // graph replay: the first call with a new argument set runs as usual (and grows the work buffers), the second one is
     // captured, later ones replay the instantiated graph
-    const char *dbg = getenv("PILOT_OT_DEBUG");
+    const char *dbg = pilot::test_switch("PILOT_OT_DEBUG");
     const pilot_ot_plan::GraphKey key = {d_P, d_M, d_emd, d_iters, d_err, d_flags, reg, stop_thr, tau, f32_floor_ulps, pl->max_cost, num_iter_max,
                                          check_period, cfg, mixed ? 1 : 0, cost_is_symmetric != 0 ? 1 : 0, row_begin, n_rows, row_step,
                                          dbg ? atoi(dbg) : 0};
@@ -1240,14 +1267,25 @@ PILOT_API int pilot_ot_emd_grid_dev(pilot_ot_plan *pl, const double *d_P, const 
     p.n_rows = n_rows; p.row_begin = row_begin; p.row_step = row_step;
     p.upper_only = mode != PILOT_OT_EMD_ALL;
     p.emd = d_emd; p.n_aug = d_n_aug; p.f_slab = nullptr; p.queue = pl->emd_counter;
-    // the flow slab of the wave-per-pair kernels: grown on demand (the first call of a plan in a mode that needs it)
+    // the flow slab of the wave-per-pair kernels: allocated ONCE, by the plan's first exact call that needs it, at the largest
+    // size any kernel variant of this K asks for (several pairs per wave with the flows in the slab; one pair per wave) -- never
+    // freed or regrown by a later call (a call made under stream capture after the first one allocates nothing)
     auto need_slab = [&](size_t bytes) -> int {
-        if (pl->f_slab_bytes < bytes) {
-            if (pl->f_slab) HIP_TRY(hipFree(pl->f_slab));
-            pl->f_slab = nullptr; pl->f_slab_bytes = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->f_slab), bytes));
-            pl->f_slab_bytes = bytes;
+        if (!pl->f_slab) {
+            size_t most = bytes;
+            if (K <= EMD_MAX_K) {
+                const size_t one = sizeof(double) * (size_t)K * K * emd_wgs_per_cu(K) * pl->n_cu * pilot::emd_waves(emd_nk(K));
+                most = one > most ? one : most;
+            }
+            if (K <= EMD_MULTI_MAX_K) {
+                const pilot::EmdMultiGeom g = pilot::emd_multi_geom(K, false);
+                const size_t multi = sizeof(double) * (size_t)K * K * 4 * g.waves * g.wgs_per_cu * pl->n_cu;
+                most = multi > most ? multi : most;
+            }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->f_slab), most));
+            pl->f_slab_bytes = most;
         }
+        if (pl->f_slab_bytes < bytes) return fail(PILOT_OT_EHIP, "exact OT: the plan's flow slab (%zu bytes) is smaller than this call needs (%zu)", pl->f_slab_bytes, bytes);
         p.f_slab = pl->f_slab;
         return PILOT_OT_OK;
     };
@@ -1514,7 +1552,7 @@ int launch_medians(const PrepassWs &ws, unsigned char *w, const T *dXp, const in
 // small cohorts: one launch, the selection in LDS (small_medians_kernel) -- when every type fits its key buffer and the
 // K x D workgroups reading all C codes is a small amount of traffic (PILOT_OT_NO_SMALL_MEDIANS=1: the general path, tests)
 bool small_medians_fit(long long C, int D, const int *cell_code, int K, unsigned int *n_max_out) {
-    if (!(C > 0 && (double)C * K * D <= 3.2e7) || getenv("PILOT_OT_NO_SMALL_MEDIANS")) return false;
+    if (!(C > 0 && (double)C * K * D <= 3.2e7) || pilot::test_switch("PILOT_OT_NO_SMALL_MEDIANS")) return false;
     std::vector<unsigned int> n_k((size_t)K, 0u);
     for (long long c = 0; c < C; ++c) { const int k = cell_code[c]; if (k >= 0 && k < K) ++n_k[(size_t)k]; }
     unsigned int n_max = 0;
@@ -1839,9 +1877,9 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
         p.dot_unscale = 1.f / p.two_alpha2;
         // two fp16 pieces (half the matrix work) while the scaled coordinates stay far inside fp16's range and above the
         // level where its subnormal spacing (2^-24) would cost accuracy; three bf16 pieces otherwise (PILOT_OT_CELL_BF16=1: always)
-        const char *force = getenv("PILOT_OT_CELL_BF16");
+        const char *force = pilot::test_switch("PILOT_OT_CELL_BF16");
         half = c->max_abs * op_scale < 3.0e4f && !(force && *force && *force != '0') ? 1 : 0;
-        const int one_slot = half && c->D <= 32 * c->KB - 2 && !getenv("PILOT_OT_CELL_NO_AUG") ? 1 : 0;
+        const int one_slot = half && c->D <= 32 * c->KB - 2 && !pilot::test_switch("PILOT_OT_CELL_NO_AUG") ? 1 : 0;
         if (c->xb_scale != op_scale || c->xb_half != half || c->xb_one_slot != one_slot) {
             if (c->xb_half != half) HIP_TRY(hipMemsetAsync(c->dXb, 0, (size_t)c->C * c->KB * 3 * 64 + pilot::CELL_PAD_BYTES, c->stream));   // (the piece count changes the planes)
             hipLaunchKernelGGL(pilot::cell_setup_kernel, dim3(grid_for(c->C * c->KB * 32, 256, c->n_cu)), dim3(256), 0, c->stream, c->dX,
@@ -1864,7 +1902,7 @@ int cell_w2_enqueue(pilot_ot_cell_cohort *c, double scale, double reg, int num_i
     if (wgs > c->n_cu * per_cu) wgs = c->n_cu * per_cu;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     hipError_t le = hipSuccess;
-    const bool aug = c->D <= 32 * c->KB - 2 && !getenv("PILOT_OT_CELL_NO_AUG");      // two spare k-slots carry h_col - m_row
+    const bool aug = c->D <= 32 * c->KB - 2 && !pilot::test_switch("PILOT_OT_CELL_NO_AUG");      // two spare k-slots carry h_col - m_row
     auto launch = [&](auto kern) {
         le = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (le == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(pilot::CELL_WG), lds, c->stream, p);

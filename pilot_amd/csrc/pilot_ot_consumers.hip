@@ -53,7 +53,7 @@ PILOT_API int pilot_ot_silhouette_dev(const double *d_D, const int *d_labels, in
     // the row and the labels are staged in LDS while they fit; beyond (N > ~12 700) the kernel reads them from global memory
     // in the same order (round 3 returned ENOTSUP there: ADVICE r03)
     size_t lds = sizeof(double) * ((size_t)N + n_clusters) + sizeof(int) * (size_t)N;
-    const char *force = getenv("PILOT_OT_SIL_UNSTAGED");       // (tests: the large-N form on a small matrix)
+    const char *force = pilot::test_switch("PILOT_OT_SIL_UNSTAGED");       // (tests: the large-N form on a small matrix)
     const int staged = (lds <= 150 * 1024 && !(force && *force && *force != '0')) ? 1 : 0;
     if (!staged) lds = sizeof(double) * (size_t)n_clusters;
     hipLaunchKernelGGL(pilot::label_sizes_kernel, dim3(1), dim3(256), 0, s, d_labels, N, n_clusters, d_sizes_scratch);

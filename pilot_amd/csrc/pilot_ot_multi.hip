@@ -375,7 +375,7 @@ PILOT_API int pilot_ot_multi_create(int N, int K, const int *devices, int n_shar
         if (e != hipSuccess) rc = fail(PILOT_OT_EHIP, "event: %s", hipGetErrorString(e));
     }
     if (rc == PILOT_OT_OK && n_shards > 1) {
-        const char *serial = getenv("PILOT_OT_MULTI_SERIAL");
+        const char *serial = pilot::test_switch("PILOT_OT_MULTI_SERIAL");
         if (!(serial && *serial && *serial != '0')) m->workers.reset(new (std::nothrow) ShardWorkers(n_shards));
     }
     if (rc != PILOT_OT_OK) { multi_free(m); return rc; }

@@ -450,7 +450,9 @@ def wasserstein_distance(adata, emb_matrix="X_PCA", clusters_col="cell_types", s
             t.join()
     if "error" in dev or chain.error is not None:
         raise dev.get("error") or chain.error
-    # (one private block, a row view per sample: 634 separate copies were a third of a millisecond)
+    # One private N x K block, a row view per sample (634 separate copies were a third of a millisecond).  Same values, keys and
+    # order as the reference's dict (Trajectory.py:432-436); unlike its independent arrays the rows share a base array: `arr.base`
+    # is the block and `arr.flags.owndata` is False, so a consumer that keeps one row keeps the block alive.
     proportions = dict(zip(samples, np.array(dev["P"], dtype=np.float64, order="C", copy=True)))
     first_rows = dev["first"]
     adata.uns["data"] = pd.DataFrame(own, columns=data.columns, copy=False)

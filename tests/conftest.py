@@ -98,6 +98,26 @@ def load_golden_pack(name="random_pack"):
     return [{k[len("c%d_" % i):]: z[k] for k in z.files if k.startswith("c%d_" % i)} for i in range(n)]
 
 
+class _Switches:
+    """Test switches of libpilot_ot.so (pilot_ot_test_switch): what the GPU tests use to force a kernel variant."""
+
+    def setenv(self, name, value):
+        from pilot_amd import _lib
+        _lib.test_switch(name, value)
+
+    def delenv(self, name, raising=True):
+        from pilot_amd import _lib
+        _lib.test_switch(name, None)
+
+
+@pytest.fixture
+def switches():
+    s = _Switches()
+    yield s
+    from pilot_amd import _lib
+    _lib.test_switch(None)                 # every switch cleared, whatever the test left set
+
+
 def account_for_absorb_on_last(Eg, Eo, last_g, last_o, K, tol, max_one_sided_frac=1e-4):
     """POT returns the transport cost scaled by 1/K^2 when a tau-absorption falls on a pair's FINAL update (u, v are reset to
     1/K and the plan is rebuilt from them).  Every pair of a grid is held to `tol` by a stated rule -- none is excluded:

@@ -42,7 +42,7 @@ def test_c3_reg001_twenty_rows_f64_follow_the_oracle_update_for_update(c3_small_
     assert ((io["flags"] & O.FLAG_ABSORBED) > 0).mean() > 0.9         # and nearly every pair tau-absorbs
 
 
-def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle, monkeypatch):
+def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle, switches):
     """precision='auto' at max(M)/reg = 100 (PILOT_OT_PREC_AUTO_MIXED): f32 values on the bf16-split tracking kernel with the
     Gibbs kernel in two exponent bands, f64 only for pairs that leave the f32 range.  A fifth of exp(-M/reg) lies below what
     one f32 band represents and most plans use those entries, so this is the test of the second band: every pair -- capped,
@@ -69,17 +69,17 @@ def test_c3_reg001_twenty_rows_auto_precision(c3_small_reg_oracle, monkeypatch):
     for prec in ("bf16x3", "fp32", "f16x2"):
         np.testing.assert_array_equal(engine.sinkhorn_grid(P, M, 0.01, precision=prec, **rows), Eg)
     # ... because one exponent band alone is NOT enough here (what the second band is for; PILOT_OT_RAW_PRECISION: tests only)
-    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
+    switches.setenv("PILOT_OT_RAW_PRECISION", "1")
     E1 = engine.sinkhorn_grid(P, M, 0.01, precision="bf16x3", **rows)
     assert np.abs(E1 - Eo)[~last_o].max() > 5 * TOL32
 
 
-def test_c3_reg001_twenty_rows_raw_f32_kernel(c3_small_reg_oracle, monkeypatch):
+def test_c3_reg001_twenty_rows_raw_f32_kernel(c3_small_reg_oracle, switches):
     """The f32-input MFMA kernel forced outside its range (PILOT_OT_RAW_PRECISION, tests only): what an explicit
     precision="fp32" would give at max(M)/reg = 100 if it were not promoted to AUTO_MIXED -- finite, the oracle's update counts
     or an earlier check, but up to 1e-4 off on the pairs that stop early.  Kept as the measurement behind the promotion rule
     (pilot_ot_resolve_precision); user-facing calls are held to 1e-5 by test_c3_reg001_twenty_rows_auto_precision."""
-    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
+    switches.setenv("PILOT_OT_RAW_PRECISION", "1")
     P, M, rows, Eo, io = c3_small_reg_oracle
     Eg, ig = engine.sinkhorn_grid(P, M, 0.01, precision="fp32", return_info=True, **rows)
     assert np.isfinite(Eg).all()

@@ -51,14 +51,14 @@ def test_sil_computing_matches_sklearn(emd_c2, metric):
         engine.silhouette_precomputed(D, np.zeros(100))                     # a single label, as sklearn refuses
 
 
-def test_silhouette_without_the_lds_row_gives_the_same_bits(emd_c2, monkeypatch):
+def test_silhouette_without_the_lds_row_gives_the_same_bits(emd_c2, switches):
     """Beyond ~12 700 samples a row no longer fits LDS and the kernel reads it from global memory in the same order (round 3
     refused such N): forced here on a small matrix, the per-sample scores must not move by a bit."""
     E = emd_c2 / emd_c2.max()
     labels = np.random.default_rng(3).integers(0, 4, 100)
     D = engine.row_distances(E, metric="cosine")
     _, staged = engine.silhouette_precomputed(D, labels, return_samples=True)
-    monkeypatch.setenv("PILOT_OT_SIL_UNSTAGED", "1")
+    switches.setenv("PILOT_OT_SIL_UNSTAGED", "1")
     _, unstaged = engine.silhouette_precomputed(D, labels, return_samples=True)
     np.testing.assert_array_equal(staged, unstaged)
 

@@ -35,7 +35,7 @@ def test_emd_full_size_grid_against_the_network_simplex(cfg, step):
 
 
 @pytest.mark.parametrize("K", [1, 2, 3, 5, 8, 11, 14, 15, 16])
-def test_emd_four_pairs_per_wave_kernel_against_the_one_pair_kernel(K, monkeypatch):
+def test_emd_four_pairs_per_wave_kernel_against_the_one_pair_kernel(K, switches):
     """K <= 16 (what real cohorts have: the reference test's own has 14 clusters): emd_multi_kernel solves four pairs per
     wavefront, one per 16-lane DPP row -- group minima by DPP butterflies, the node sets of a search as wave masks, augmentations
     through path masks instead of a walk.  Same algorithm and the same fp64 arithmetic per pair as the one-pair-per-wave
@@ -52,11 +52,11 @@ def test_emd_four_pairs_per_wave_kernel_against_the_one_pair_kernel(K, monkeypat
     P[7] = P[8]
     P[9] *= 0.5
     Eo = O.emd_grid(P, M, n_threads=16, fast="ns")
-    monkeypatch.setenv("PILOT_OT_EMD_MULTI", "0")
+    switches.setenv("PILOT_OT_EMD_MULTI", "0")
     E0, i0 = engine.emd_grid(P, M, mode="all", return_info=True)
     res = {}
     for mode in ("1", "2"):
-        monkeypatch.setenv("PILOT_OT_EMD_MULTI", mode)
+        switches.setenv("PILOT_OT_EMD_MULTI", mode)
         E1, i1 = engine.emd_grid(P, M, mode="all", return_info=True)
         np.testing.assert_array_equal(i1["n_aug"], i0["n_aug"])
         assert np.abs(E1 - E0).max() <= 1e-14 and np.abs(E1 - Eo).max() <= 1e-12
@@ -66,7 +66,7 @@ def test_emd_four_pairs_per_wave_kernel_against_the_one_pair_kernel(K, monkeypat
                                       np.where(np.arange(N)[None, :] >= rows[:, None], E1[rows], 0.0))
         res[mode] = E1
     np.testing.assert_array_equal(res["1"], res["2"])
-    monkeypatch.delenv("PILOT_OT_EMD_MULTI")
+    switches.delenv("PILOT_OT_EMD_MULTI")
     np.testing.assert_array_equal(engine.emd_grid(P, M, mode="all"), res["1"])          # the default is one of the two
 
 
@@ -85,7 +85,7 @@ def test_emd_whole_grids_at_small_k_against_the_network_simplex(K):
                                   np.where(np.arange(300)[None, :] >= rows[:, None], E[rows], 0.0))
 
 
-def test_emd_four_pairs_per_wave_kernel_on_the_reference_cohort(monkeypatch):
+def test_emd_four_pairs_per_wave_kernel_on_the_reference_cohort(switches):
     """Every pair of the reference test's own cohort (Kidney_IgAN_G: 634 patients x 14 clusters, up to 101 augmentations per
     pair) against the oracle's network simplex, and against the one-pair-per-wave kernel augmentation for augmentation."""
     g = load_golden(GOLDEN_REAL)
@@ -93,7 +93,7 @@ def test_emd_four_pairs_per_wave_kernel_on_the_reference_cohort(monkeypatch):
     E1, i1 = engine.emd_grid(P, M, return_info=True)
     assert np.abs(E1 - O.emd_grid(P, M, n_threads=16, fast="ns")).max() <= 1e-12
     assert np.array_equal(E1, E1.T) and np.abs(np.diag(E1)).max() == 0.0
-    monkeypatch.setenv("PILOT_OT_EMD_MULTI", "0")
+    switches.setenv("PILOT_OT_EMD_MULTI", "0")
     E0, i0 = engine.emd_grid(P, M, return_info=True)
     iu = np.triu_indices(P.shape[0])
     np.testing.assert_array_equal(i1["n_aug"][iu], i0["n_aug"][iu])
@@ -368,7 +368,7 @@ def test_centroid_medians_exact(dtype, C, D, K):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_small_cohort_medians_in_one_launch_give_the_general_path_s_bits(dtype, monkeypatch):
+def test_small_cohort_medians_in_one_launch_give_the_general_path_s_bits(dtype, switches):
     """Small cohorts (C x K x D <= 3.2e7 and no cell type beyond 8192 cells) select their medians in ONE launch, in LDS
     (small_medians_kernel); the general path (PILOT_OT_NO_SMALL_MEDIANS=1) is sixteen launches.  Same keys, ranks and final
     arithmetic: the same bits, with ties, signed zeros, infinities, an empty type, one-cell types, an even / odd split -- and a
@@ -382,9 +382,9 @@ def test_small_cohort_medians_in_one_launch_give_the_general_path_s_bits(dtype, 
         cc = rng.integers(0, K - 1, C).astype(np.int32)             # type K - 1 stays empty
         cc[:3] = [0, 1, 1]
         fast = engine.centroid_medians(X, cc, K)
-        monkeypatch.setenv("PILOT_OT_NO_SMALL_MEDIANS", "1")
+        switches.setenv("PILOT_OT_NO_SMALL_MEDIANS", "1")
         slow = engine.centroid_medians(X, cc, K)
-        monkeypatch.delenv("PILOT_OT_NO_SMALL_MEDIANS")
+        switches.delenv("PILOT_OT_NO_SMALL_MEDIANS")
         np.testing.assert_array_equal(fast, slow)
         assert np.isnan(fast[K - 1]).all()
         for k in range(K - 1):
@@ -570,3 +570,32 @@ def test_unsupported_metric_and_sil_ari_raise(tmp_path, monkeypatch):
     with pytest.raises(NotImplementedError):
         tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized="reg", return_sil_ari=True)
     assert ad.uns == {}
+
+
+def test_return_sil_ari_branch_end_to_end_with_a_stub_clustering(tmp_path, monkeypatch):
+    """return_sil_ari=True (Trajectory.py:108-113): the Leiden clustering is the reference's OWN function, looked up lazily; with a
+    stand-in for it (scanpy / leidenalg are not in this image) the whole branch runs -- Clustering gets EMD / EMD.max() and the
+    annotation frame, its labels replace uns['real_labels'], the silhouette comes from the device, and the ARI is stored
+    (only the lookup had a test)."""
+    import sys
+    import types
+    from sklearn.metrics import silhouette_score
+    monkeypatch.chdir(tmp_path)
+    ad = make_cells(20, 10, 10, seed=0, cells_per_patient=200)
+    seen = {}
+
+    def clustering(EMD, annot, metric="cosine", res=0.01, steper=0.01):
+        seen.update(EMD=EMD.copy(), annot=annot, metric=metric, res=res, steper=steper)
+        labels = ["case" if i % 2 else "ctrl" for i in range(EMD.shape[0])]
+        return [0] * EMD.shape[0], 0.75, labels
+
+    fake = types.ModuleType("pilotpy.tools.Trajectory")
+    fake.Clustering = clustering
+    for name, mod in (("pilotpy", types.ModuleType("pilotpy")), ("pilotpy.tools", types.ModuleType("pilotpy.tools")), ("pilotpy.tools.Trajectory", fake)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    tl.wasserstein_distance(ad, emb_matrix="X_pca", regularized="reg", reg=0.1, return_sil_ari=True, res=0.05, steper=0.02)
+    E = ad.uns["EMD"]
+    np.testing.assert_array_equal(seen["EMD"], E / E.max())
+    assert seen["annot"] is ad.uns["annot"] and (seen["metric"], seen["res"], seen["steper"]) == ("cosine", 0.05, 0.02)
+    assert ad.uns["ARI"] == 0.75 and ad.uns["real_labels"] == ["case" if i % 2 else "ctrl" for i in range(20)]
+    assert abs(ad.uns["Sil"] - silhouette_score(E / E.max(), ad.uns["real_labels"], metric="cosine")) <= 1e-12

@@ -193,7 +193,7 @@ def test_unnormalised_cost_takes_the_same_kernels_on_one_and_on_several_devices(
         mp.close()
 
 
-def test_shard_threads_serial_switch_and_back_to_back_calls(monkeypatch):
+def test_shard_threads_serial_switch_and_back_to_back_calls(switches):
     """Every shard is enqueued by its own host thread; PILOT_OT_MULTI_SERIAL=1 enqueues from the calling thread instead.
     Same bits either way, and back-to-back asynchronous calls with the peer-copy gather (the next call's kernels must wait
     for shard 0's copies of the previous rows) leave the right matrix after every call."""
@@ -201,7 +201,7 @@ def test_shard_threads_serial_switch_and_back_to_back_calls(monkeypatch):
     ref1 = engine.sinkhorn_grid(P, M, 0.1)
     ref2 = engine.sinkhorn_grid(P, M, 0.5)
     for serial in ("0", "1"):
-        monkeypatch.setenv("PILOT_OT_MULTI_SERIAL", serial)
+        switches.setenv("PILOT_OT_MULTI_SERIAL", serial)
         mp = multi.MultiPlan(P, M, devices=[0] * 5)
         for _ in range(6):
             mp.sinkhorn(0.5)

@@ -76,9 +76,9 @@ def test_small_reg_goes_through_absorption_tracking_f64():
     assert 0.2 < capped.mean() < 0.9
 
 
-def test_small_reg_f32_stays_within_tolerance_on_this_distribution(monkeypatch):
+def test_small_reg_f32_stays_within_tolerance_on_this_distribution(switches):
     """The raw f32-input MFMA kernel at max(M)/reg = 100 (outside its range; normal calls run AUTO_MIXED there)."""
-    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
+    switches.setenv("PILOT_OT_RAW_PRECISION", "1")
     P, M = make_problem(**CONFIGS["c3"])
     rows = dict(row_begin=100, row_end=102, row_step=1)
     Eo, io = O.sinkhorn_grid(P, M, 0.01, n_threads=16, return_info=True, **rows)
@@ -125,7 +125,7 @@ def test_k_above_128_runs_the_reference_semantics_kernel(K):
 
 
 @pytest.mark.parametrize("K", [129, 130, 160, 192, 250, 256])
-def test_k_129_to_256_runs_eight_waves_per_tile(K, monkeypatch):
+def test_k_129_to_256_runs_eight_waves_per_tile(K, switches):
     """128 < K <= 256, symmetric cost, max(M)/reg <= 16: sinkhorn_wide_kernel (wide_kernels.hpp) -- the fp16-split products with
     a tile's cell types spread over the eight waves of a workgroup -- instead of one workgroup per pair (round 3: 600x slower
     than K = 128).  f32-class tolerance against the fp64 oracle, the f32 stopping rule (same or an earlier check), shard /
@@ -147,9 +147,9 @@ def test_k_129_to_256_runs_eight_waves_per_tile(K, monkeypatch):
     assert np.abs(engine.sinkhorn_grid(P, M, 1.0) - O.sinkhorn_grid(P, M, 1.0, n_threads=16)).max() <= TOL32
     if K not in (130, 256):
         return
-    monkeypatch.setenv("PILOT_OT_WIDE_CHUNK", "300")                     # row chunks of 7 rows (the 1 GB cap of the records, forced)
+    switches.setenv("PILOT_OT_WIDE_CHUNK", "300")                     # row chunks of 7 rows (the 1 GB cap of the records, forced)
     np.testing.assert_array_equal(engine.sinkhorn_grid(P, M, 0.1), Eg)
-    monkeypatch.delenv("PILOT_OT_WIDE_CHUNK")
+    switches.delenv("PILOT_OT_WIDE_CHUNK")
     for tau in (2.0, 1.2):
         Et, it_ = engine.sinkhorn_grid(P, M, 0.1, tau=tau, return_info=True)
         Eot, iot = O.sinkhorn_grid(P, M, 0.1, tau=tau, n_threads=16, return_info=True)
@@ -197,7 +197,7 @@ def test_small_reg_two_exponent_bands_other_shapes(K, sym):
     assert f64.all() if K == 100 else f64.mean() < 0.2
 
 
-def test_pairs_that_go_nan_are_resolved_like_pot(monkeypatch):
+def test_pairs_that_go_nan_are_resolved_like_pot(switches):
     """POT breaks out of a pair whose scalings become NaN and returns the cost of the last good iterate.  The
     fast kernels hand such pairs to the POT-literal kernel instead of writing NaN: forcing the f32 kernel far outside its
     range (max(M)/reg = 400: exp(-M/reg) underflows in f32) must leave no NaN behind, and every pair that was handed over
@@ -205,7 +205,7 @@ def test_pairs_that_go_nan_are_resolved_like_pot(monkeypatch):
     P, M = make_problem(**CONFIGS["c1"])
     Eo, io = O.sinkhorn_grid(P, M, 0.0025, n_threads=16, return_info=True)
     # (an explicit f32-class precision beyond max(M)/reg = 60 normally runs AUTO_MIXED: the raw kernels are forced here)
-    monkeypatch.setenv("PILOT_OT_RAW_PRECISION", "1")
+    switches.setenv("PILOT_OT_RAW_PRECISION", "1")
     for prec in ("fp32", "bf16x3", "f16x2"):
         Eg, ig = engine.sinkhorn_grid(P, M, 0.0025, precision=prec, return_info=True)
         assert not np.isnan(Eg).any()
@@ -283,7 +283,7 @@ def test_nonsymmetric_cost_with_tail_rows(K, prec, tol):
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", TOL32), ("bf16x3", TOL32), ("f16x2", TOL32), ("fp64", TOL64)])
-def test_duplicate_patients_take_the_solo_path(prec, tol, monkeypatch):
+def test_duplicate_patients_take_the_solo_path(prec, tol, switches):
     """The diagonal pairs (i, i) are solved one per wavefront; duplicate PATIENTS (a == b bit for bit, i != j) stay in the
     tiles since round 4 (a cohort with a handful of cell types has thousands of them).  Row shards must reproduce the full
     matrix, and switching the one-wave path off must agree within the tolerance (different summation order, same
@@ -299,16 +299,16 @@ def test_duplicate_patients_take_the_solo_path(prec, tol, monkeypatch):
     for r in (0, 5, 29):                                       # one-row shards: 4 (resp. 2) duplicates on one solo workgroup
         part = engine.sinkhorn_grid(P, M, 0.1, precision=prec, row_begin=r, row_end=r + 1)
         np.testing.assert_array_equal(part[0], Eg[r])
-    monkeypatch.setenv("PILOT_OT_DEBUG", "512")
+    switches.setenv("PILOT_OT_DEBUG", "512")
     Eoff = engine.sinkhorn_grid(P, M, 0.1, precision=prec)
-    monkeypatch.delenv("PILOT_OT_DEBUG")
+    switches.delenv("PILOT_OT_DEBUG")
     dup = np.eye(30, dtype=bool)
     np.testing.assert_array_equal(Eoff[~dup], Eg[~dup])        # everything off the diagonal is the same code path, bit for bit
     assert np.abs(Eoff - Eg).max() <= tol
 
 
 @pytest.mark.parametrize("K", [2, 3, 4, 5, 8])
-def test_single_digit_cell_type_counts_stay_on_the_mfma_kernels(K, monkeypatch):
+def test_single_digit_cell_type_counts_stay_on_the_mfma_kernels(K, switches):
     """Pathomics cohorts have single-digit K.  Their scalings can jump from below tau past the fp16 range within one update
     (531 -> 2071 at K = 2): such a pair must be handed to the f32 tracking kernel, not end as "numerical errors" and take the
     POT-literal kernel (round 3: 20 580 of 360 000 pairs at K = 2, 65 of the call's 67 ms).  With the hand-over launch
@@ -317,7 +317,7 @@ def test_single_digit_cell_type_counts_stay_on_the_mfma_kernels(K, monkeypatch):
     P, M = make_problem(160, K, 8, seed=K, cells_per_patient=200)
     N = P.shape[0]
     Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
-    monkeypatch.setenv("PILOT_OT_DEBUG", "1024")
+    switches.setenv("PILOT_OT_DEBUG", "1024")
     plan = engine.DevicePlan(P, M)
     sent = np.full(N * N, -7, dtype=np.int32)
     _lib.check(plan.L.pilot_ot_memcpy_h2d(plan.dFl, sent.ctypes.data, sent.nbytes))
@@ -629,18 +629,18 @@ def test_c4_shape_sampled_rows():
     assert np.abs(Eg - Eo).max() <= TOL64
 
 
-def test_results_do_not_depend_on_work_order_or_occupancy(monkeypatch):
+def test_results_do_not_depend_on_work_order_or_occupancy(switches):
     """A pair's arithmetic is independent of which wave / column / launch order it lands in: disabling the
     longest-first ordering or changing the number of resident workgroups must reproduce the same bits."""
     P, M = make_problem(**CONFIGS["c2"])
     for prec in ("fp32", "bf16x3", "f16x2"):
         ref, iref = engine.sinkhorn_grid(P, M, 0.1, precision=prec, return_info=True)
         for dbg in ("2", "16", "34"):          # no ordering; 1 workgroup per CU; both
-            monkeypatch.setenv("PILOT_OT_DEBUG", dbg)
+            switches.setenv("PILOT_OT_DEBUG", dbg)
             got, ig = engine.sinkhorn_grid(P, M, 0.1, precision=prec, return_info=True)
             np.testing.assert_array_equal(got, ref)
             np.testing.assert_array_equal(ig["iters"], iref["iters"])
-        monkeypatch.delenv("PILOT_OT_DEBUG")
+        switches.delenv("PILOT_OT_DEBUG")
 
 
 def test_host_workspace_cache_across_shapes_and_shutdown():

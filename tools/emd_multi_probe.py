@@ -3,6 +3,8 @@
 one-pair-per-wave kernel (=0) and the oracle's network simplex, whole grids.  usage: emd_multi_probe.py [K ...] (default: a sweep + the
 Kidney_IgAN_G cohort of tests/golden)"""
 import os, sys, time
+__import__("sys").path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))   # tools/switches.py
+import switches
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
@@ -18,7 +20,7 @@ def cohort(k):
     return make_problem(600, int(k), 8, seed=int(k), cells_per_patient=200)
 
 def run(P, M, mode, reps=5):
-    os.environ["PILOT_OT_EMD_MULTI"] = str(mode)
+    switches.set("PILOT_OT_EMD_MULTI", mode)
     N, K = P.shape
     plan = engine.DevicePlan(P, M)
     def emd(): _lib.check(plan.L.pilot_ot_emd_grid_dev(plan.plan, plan.dP, plan.dM, 2, 0, N, 1, plan.dE, plan.dIt, None))

@@ -6,6 +6,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 from pilot_amd import engine, _lib
+sys.path.insert(0, os.path.join(R, "tools"))
+import switches
+switches.apply_from_env()                      # TOOL_SWITCHES="PILOT_OT_EMD_MULTI=0" (tools/emd_multi_pmc.sh)
 if sys.argv[1] == "real":
     from conftest import GOLDEN_REAL, load_golden
     g = load_golden(GOLDEN_REAL)

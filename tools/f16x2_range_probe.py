@@ -3,7 +3,7 @@ at smaller reg on c3 / c4 row samples and compares with the oracle and with bf16
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
-os.environ["PILOT_OT_H_MAX_COST_OVER_REG"] = "40"
+__import__("sys").path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__))); import switches; switches.set("PILOT_OT_H_MAX_COST_OVER_REG", "40")
 from oracle import oracle as O
 from pilot_amd import engine
 from pilot_amd.synthetic import CONFIGS, make_problem

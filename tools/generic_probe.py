@@ -7,11 +7,16 @@ if len(sys.argv) > 1:
     from pilot_amd import engine
     from pilot_amd.synthetic import make_problem
     K = int(sys.argv[1]); N = 200
+    wgs = sys.argv[2] if len(sys.argv) > 2 else None
+    if wgs:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import switches
+        switches.set("PILOT_OT_GENERIC_WGS", wgs)
     P, M = make_problem(N, K, 8, seed=K, cells_per_patient=800)
     E = engine.sinkhorn_grid(P, M, 0.1)
     t = time.perf_counter(); E = engine.sinkhorn_grid(P, M, 0.1); dt = time.perf_counter() - t
-    print("K=%d workgroups %s: %.1f ms" % (K, os.environ.get("PILOT_OT_GENERIC_WGS", "512"), dt * 1e3), flush=True)
+    print("K=%d workgroups %s: %.1f ms" % (K, wgs or "512", dt * 1e3), flush=True)
 else:
     for K in (130, 192, 256):
         for w in (16, 32, 64, 96, 128, 256, 512):
-            subprocess.run([sys.executable, __file__, str(K)], env=dict(os.environ, PILOT_OT_GENERIC_WGS=str(w)))
+            subprocess.run([sys.executable, __file__, str(K), str(w)])

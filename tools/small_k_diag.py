@@ -3,7 +3,7 @@ hand-over launch, so the pairs it would have solved keep the sentinel this scrip
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
-os.environ["PILOT_OT_DEBUG"] = "1024"
+__import__("sys").path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__))); import switches; switches.set("PILOT_OT_DEBUG", "1024")
 from pilot_amd import engine, _lib
 from pilot_amd.synthetic import make_problem
 from oracle import oracle as O

@@ -2,12 +2,14 @@
 (1000 updates) is ONE tile (PILOT_OT_DEBUG=512: no one-wave path) or, with N = 1, one wave on the diagonal path; the kernel time
 divided by 1000 is the latency of one update.  Then the 600-patient grid with the one-wave path on / off and in natural order."""
 import os, sys, subprocess
+__import__("sys").path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))   # tools/switches.py
+import switches
 sys.path.insert(0, ".")
 import numpy as np
 
 
 def run(K, N, debug, full=False):
-    os.environ["PILOT_OT_DEBUG"] = str(debug)
+    switches.set("PILOT_OT_DEBUG", debug)
     from pilot_amd import engine
     from pilot_amd.synthetic import make_problem
     P, M = make_problem(600, K, 8, seed=K, cells_per_patient=200)

@@ -1,9 +1,11 @@
 """Is the small-K Sinkhorn grid bound by throughput (time ~ N^2) or by a serial tail (time ~ const)?"""
 import os, sys, subprocess
+__import__("sys").path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))   # tools/switches.py
+import switches
 sys.path.insert(0, ".")
 import numpy as np
 def run(K, N, debug):
-    os.environ["PILOT_OT_DEBUG"] = str(debug)
+    switches.set("PILOT_OT_DEBUG", debug)
     from pilot_amd import engine
     from pilot_amd.synthetic import make_problem
     P, M = make_problem(N, K, 8, seed=K, cells_per_patient=200)
