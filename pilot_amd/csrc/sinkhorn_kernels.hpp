@@ -607,6 +607,9 @@ template <int RT, int NP> struct SplitImage { u32x4_t a[NP][split_kblocks(RT)][R
 #ifndef PILOT_DEFER_HANDOVER
 #define PILOT_DEFER_HANDOVER 1
 #endif
+#ifndef PILOT_E2_PACKED
+#define PILOT_E2_PACKED 1     // (round 6: the lane's squared error two slots per v_pk_fma_f32; instructions -12 per error test, time unchanged)
+#endif
 template <class C, int RT>
 __device__ inline void panel_product_pieces_regs(const SplitImage<RT, C::NP> &A, const SplitPanel<RT, C::NP> &B,
                                                  typename C::acc_t (&OUT)[RT], const typename C::acc_t &last_init) {
@@ -1214,7 +1217,8 @@ sinkhorn_stream_kernel(GridParams p) {
     };
 
     const int K = p.K, N = p.N;
-    const T *Pt = static_cast<const T *>(p.P);
+    // (fp16-split configuration: the copy of the proportions in its scaled domain, written by the prep kernel behind the plain one)
+    const T *Pt = static_cast<const T *>(p.P) + (C::HALF ? (size_t)p.N * (RT * M::TILE) + p.N : 0);
     const T uinit = PANEL_SCALE / T(K);
     // (fp16-split configuration: the test reads the leading fp16 piece, which is within 2^-11 of the scaling -- the
     // threshold is lowered by 2^-10 so that no scaling beyond tau is missed; the few pairs this sends over early are
@@ -1311,6 +1315,9 @@ sinkhorn_stream_kernel(GridParams p) {
     const bool hand_all_over = C::HALF && p.unequal && *p.unequal != 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
+        // (round 6, tried and dropped: refills -- and with them the error checks, which follow a refill by 1 + 20 n updates -- only on
+        // every 2nd / 4th update of the wave, so that the refill and error blocks run in a quarter of the updates instead of 40 % /
+        // 56 %: c3 kernel 0.609 -> 0.626 / 0.651 ms, the idle column-updates cost more than the skipped blocks; profiles/r06/ab_experiments.md)
         const unsigned long long wmask = ballot_b(want) & colmask;
         if (wmask) {
             if (res_next >= res_end && !exhausted) {
@@ -1375,13 +1382,12 @@ sinkhorn_stream_kernel(GridParams p) {
                     load_regs<C>(pa + t * NGRP * NREG, A[t]);          // 16-byte loads: a lane's slots are contiguous
                     load_regs<C>(pb + t * NGRP * NREG, B[t]);
                 }
-                thr = Pt[(size_t)N * KP + j] * IN_SCALE;      // stop threshold of column patient j (prep: f32 floor folded in)
+                thr = Pt[(size_t)N * KP + j];                 // stop threshold of column patient j (prep: f32 floor folded in; HALF: scaled copy)
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     load_regs<C>(acc0 + (t * NGRP + grp) * NREG, ACC[t]);
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
-                        if constexpr (C::HALF) { A[t][r] *= IN_SCALE; B[t][r] *= IN_SCALE; }
                         U[t][r] = (t == RT - 1) ? uinit - uinit * PADC[r] : uinit;   // 0 in padded slots; v follows from ACC
                         if constexpr (TRACK) { RU[t][r] = T(1); RV[t][r] = T(1); }
                     }
@@ -1548,6 +1554,29 @@ sinkhorn_stream_kernel(GridParams p) {
         // squared marginal error of this lane's slots, per-tile partial sums added in tile order
         auto lane_e2 = [&](T sc) {
             T e2 = T(0);
+            if constexpr (PILOT_E2_PACKED && sizeof(T) == 4 && !TRACK && NREG == 4) {
+                // two slots per instruction (v_pk_fma_f32 on adjacent registers): d = v acc - b, e += d d -- 14 instead of 26 vector
+                // instructions in a block that more than half the updates run; the two running sums are added at the end
+                using P2 = pair_of<float>;
+                P2 acc2 = {0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int r0 = 2 * h, r1 = 2 * h + 1;
+                        if (dead(t, r0) && dead(t, r1)) continue;
+                        if (dead(t, r0) || dead(t, r1)) {            // half a pair: the live slot alone
+                            const int r = dead(t, r0) ? r1 : r0;
+                            const float d = V[t][r] * ACC[t][r] - B[t][r];
+                            acc2[0] = __builtin_fmaf(d, d, acc2[0]);
+                            continue;
+                        }
+                        const P2 v2 = {V[t][r0], V[t][r1]}, a2 = {ACC[t][r0], ACC[t][r1]}, b2 = {B[t][r0], B[t][r1]};
+                        const P2 d2 = __builtin_elementwise_fma(v2, a2, -b2);
+                        acc2 = __builtin_elementwise_fma(d2, d2, acc2);
+                    }
+                return acc2[0] + acc2[1];
+            }
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 T et = T(0);
@@ -1627,10 +1656,6 @@ sinkhorn_stream_kernel(GridParams p) {
                                 if (active) {
                                     load_regs<C>(pa + t * NGRP * NREG, A[t]);
                                     load_regs<C>(pb + t * NGRP * NREG, B[t]);
-#pragma unroll
-                                    for (int r = 0; r < NREG; ++r) {
-                                        if constexpr (C::HALF) { A[t][r] *= IN_SCALE; B[t][r] *= IN_SCALE; }
-                                    }
                                 }
                             }
                             if constexpr (C::HALF) product_h(a_gt.img, PU, ACC);
@@ -1856,6 +1881,7 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
         double thr = stop_thr;
         if (sizeof(T) == 4) { const double fl = floor_ulps * 1.1920928955078125e-07 * sqrt(n2); thr = thr > fl ? thr : fl; }
         Pdst[n_p + row] = T(thr);
+        if constexpr (C::HALF) Pdst[(n_p + n_p / KP) + n_p + row] = T(thr) * T(H_IN_SCALE);
     }
     // proportions: N rows of KP values in slot order, zero in padding (n_p = N * KP)
     for (long idx = tid; idx < n_p; idx += nthr) {
@@ -1864,6 +1890,10 @@ __device__ inline void setup_body(const double *__restrict__ Msrc, int K, int RT
         const int r = sidx % M::NREG, g = (sidx / M::NREG) % M::NGRP, t = sidx / (M::NGRP * M::NREG);
         const int l = M::lidx(t, r, g);
         Pdst[idx] = l < K ? T(Psrc[row * K + l]) : T(0);
+        // fp16-split configuration: a second copy in the scaled domain of its tile kernel (a 2^25, b 2^25, thresholds 2^25 -- powers of
+        // two: the same bits the kernel used to form at every refill, 32 multiplies per lane in a block that 40 % of the updates
+        // run) behind the first one (the buffer is sized for f64); the one-wave path and the tracking pass read the plain copy
+        if constexpr (C::HALF) Pdst[(n_p + n_p / KP) + idx] = l < K ? T(Psrc[row * K + l]) * T(H_IN_SCALE) : T(0);
     }
 }
 
