@@ -487,7 +487,14 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
     } else if (K <= WIDE_MAX_K) {       // the 8-waves-per-tile kernel: the fp16-split operand block at 16 row-tiles
         if (e == hipSuccess) e = hipMalloc(&pl->img, pilot::img_elems(pilot::CFG_H32, 16) * sizeof(float));
     }
-    if (e == hipSuccess) e = hipMalloc(&pl->p_slot, sizeof(double) * ((size_t)N * kp + N));   // + one stop threshold per patient
+    {
+        // proportions in slot order + one stop threshold per patient: sized for f64 at the padded K; the fp16-split configuration keeps
+        // TWO f32 copies there (plain, and in its scaled domain) -- the same bytes up to K = 128, more with the 16 row-tiles of the
+        // eight-waves-per-tile kernel
+        size_t p_bytes = sizeof(double) * ((size_t)N * kp + N);
+        if (K > MAX_K && K <= WIDE_MAX_K) { const size_t two = 2 * sizeof(float) * ((size_t)N * 256 + N); p_bytes = two > p_bytes ? two : p_bytes; }
+        if (e == hipSuccess) e = hipMalloc(&pl->p_slot, p_bytes);
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);

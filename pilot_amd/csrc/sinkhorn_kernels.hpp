@@ -496,9 +496,45 @@ template <int NP> __host__ __device__ constexpr int term_b(int i) {
     if (NP == 3) return i == 1 ? 2 : (i == 2 || i == 4 ? 1 : 0);
     return i == 1 ? 1 : 0;
 }
-template <class C> __device__ inline typename C::acc_t mfma_pieces(u32x4_t a, u32x4_t b, typename C::acc_t c) {
+// TAIL16: the last k-block of an ODD row-tile count holds one row-tile, i.e. 16 k-slots: the lane's first four of eight (k-slot e of
+// group g <-> cell type lidx(2 kb + e / 4, e % 4, g), so e < 4 is row-tile 2 kb and the 16x16x16 instruction's own slot 4 g + e) -- the
+// same operand registers, their low 8 bytes, on v_mfma_f32_16x16x16_{f16,bf16}: half the matrix-pipe time of a k-block that was half
+// padding (K = 100: 7 row-tiles, 4 k-blocks -> 3.5: c4 25.06 -> 23.2 ms, K = 100 at N = 600 1.69 -> 1.60 ms; tools/ubench/mfma_tail16.hip
+// checks the instruction pair against each other).
+// HAZARD (found the hard way, profiles/r06/ab_experiments.md section 4): a 16x16x16 MFMA that reads as SrcC the result of a 16x16x32 MFMA
+// issued a few instructions earlier gets a stale accumulator -- the hardware forwards accumulators only between MFMAs of one shape,
+// and hipcc (ROCm 7.2) inserts no wait states for the mixed pair (it does for a bare back-to-back pair, which is why a two-instruction
+// test passes).  So: either the tail MFMAs of a tile are issued many MFMAs after its full ones (tails last: the register-image order 2,
+// PILOT_TAIL16_ORDER 1), or tail16_gap() stands between them.
+#ifndef PILOT_TAIL16
+#define PILOT_TAIL16 7      // bit 0: register image, bit 1: LDS image, bit 2: cost flush / band-1 products
+#endif
+template <int RT, int BIT = 7> __host__ __device__ constexpr bool tail16_kb(int kb) { return (PILOT_TAIL16 & BIT) && (RT & 1) && kb == (RT + 1) / 2 - 1; }
+using u32x2_t = unsigned int __attribute__((ext_vector_type(2)));
+using f16x4_t = _Float16 __attribute__((ext_vector_type(4)));
+using s16x4_t = short __attribute__((ext_vector_type(4)));
+#ifndef PILOT_TAIL16_GAP
+#define PILOT_TAIL16_GAP 12     // (measured on c4-shaped and K = 33 .. 112 grids: 4 wait states still give wrong sums, 8 / 12 / 16 are right)
+#endif
+#ifndef PILOT_TAIL16_ORDER
+#define PILOT_TAIL16_ORDER 1    // LDS-image products: 1 = tails last (no gap needed), 0 = tile after tile with the gap (c4 23.21 vs 23.13 ms, K = 80 0.968 vs 0.997)
+#endif
+// wait states between a 16x16x32 MFMA and a 16x16x16 MFMA that reads its result as SrcC (ROCm 7.2 inserts none, the
+// hardware forwards an accumulator only between MFMAs of the same shape)
+__device__ inline void tail16_gap() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop %0" ::"n"(PILOT_TAIL16_GAP - 1) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class C, bool TAIL16 = false> __device__ inline typename C::acc_t mfma_pieces(u32x4_t a, u32x4_t b, typename C::acc_t c) {
+    if constexpr (TAIL16) {
+        const u32x2_t a2 = {a[0], a[1]}, b2 = {b[0], b[1]};
+        if constexpr (C::HALF) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a2), __builtin_bit_cast(f16x4_t, b2), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a2), __builtin_bit_cast(s16x4_t, b2), c, 0, 0, 0);
+    } else {
     if constexpr (C::HALF) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
 }
 
 // the scaling panel as packed B operands: p[part][k-block] = the lane's 8 k-slots (accumulator registers of row-tiles 2 kb, 2 kb + 1)
@@ -534,8 +570,14 @@ __device__ inline typename C::acc_t split_tile_product(const typename C::T *form
         u32x4_t a[TP];
 #pragma unroll
         for (int part = 0; part < TP; ++part) a[part] = img[((part * KB + kb) * RT + t) * WAVE + lane];
+        if (tail16_kb<RT, 4>(kb)) {         // (a compile-time condition after unrolling)
+            if (kb > 0) tail16_gap();
+#pragma unroll
+            for (int i = 0; i < n_terms<TP>(); ++i) acc = mfma_pieces<C, true>(a[term_a<TP>(i)], B.p[term_b<TP>(i)][kb], acc);
+        } else {
 #pragma unroll
         for (int i = 0; i < n_terms<TP>(); ++i) acc = mfma_pieces<C>(a[term_a<TP>(i)], B.p[term_b<TP>(i)][kb], acc);
+        }
     }
     return acc;
 }
@@ -557,29 +599,41 @@ __device__ inline void panel_product_pieces(const typename C::T *form, const typ
     u32x4_t a[NP];
 #pragma unroll
     for (int part = 0; part < NP; ++part) a[part] = img[((part * KB + 0) * RT + 0) * WAVE];
+    // the steps (tile, k-block) in issue order.  TAILS_LAST (odd row-tile counts with the 16-wide tail k-block, >= 3 row-tiles): the full
+    // k-blocks of every tile first, then the tails tile after tile -- a tile's 16x16x16 MFMAs then read an accumulator that was
+    // written many MFMAs earlier (the hardware forwards an accumulator only between MFMAs of one shape, and ROCm 7.2 puts no wait
+    // states between a 16x16x32 and a 16x16x16 that reads its result: see tail16_gap)
+    constexpr bool TAILS_LAST = PILOT_TAIL16_ORDER == 1 && tail16_kb<RT, 2>(KB - 1) && KB > 1;
+    constexpr int STEPS = RT * KB, FULL = RT * (KB - 1);
+    auto step_t = [](int s) { return TAILS_LAST ? (s < FULL ? s / (KB - 1) : s - FULL) : s / KB; };
+    auto step_kb = [](int s) { return TAILS_LAST ? (s < FULL ? s % (KB - 1) : KB - 1) : s % KB; };
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        typename C::acc_t acc;
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (t == RT - 1) ? last_init[r] : 0.f;
+        for (int r = 0; r < 4; ++r) OUT[t][r] = (t == RT - 1) ? last_init[r] : 0.f;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int nt = kb + 1 < KB ? t : t + 1, nkb = kb + 1 < KB ? kb + 1 : 0;      // the step after this one
-            u32x4_t n[NP];
+    for (int s = 0; s < STEPS; ++s) {
+        const int t = step_t(s), kb = step_kb(s);
+        u32x4_t n[NP];
 #pragma unroll
-            for (int part = 0; part < NP; ++part) n[part] = a[part];
-            if (nt < RT) {
+        for (int part = 0; part < NP; ++part) n[part] = a[part];
+        if (s + 1 < STEPS) {
+            const int nt = step_t(s + 1), nkb = step_kb(s + 1);                       // the step after this one
 #pragma unroll
-                for (int part = 0; part < NP; ++part) n[part] = img[((part * KB + nkb) * RT + nt) * WAVE];
-            }
-            __builtin_amdgcn_sched_barrier(0x6);        // (VALU / SALU may move across; the LDS reads stay ahead of the MFMAs)
-#pragma unroll
-            for (int i = 0; i < n_terms<NP>(); ++i) acc = mfma_pieces<C>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], acc);
-            __builtin_amdgcn_sched_barrier(0x6);
-#pragma unroll
-            for (int part = 0; part < NP; ++part) a[part] = n[part];
+            for (int part = 0; part < NP; ++part) n[part] = img[((part * KB + nkb) * RT + nt) * WAVE];
         }
-        OUT[t] = acc;
+        __builtin_amdgcn_sched_barrier(0x6);        // (VALU / SALU may move across; the LDS reads stay ahead of the MFMAs)
+        if (tail16_kb<RT, 2>(kb)) {
+            if (kb > 0 && !TAILS_LAST) tail16_gap();
+#pragma unroll
+            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C, true>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], OUT[t]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], OUT[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+        for (int part = 0; part < NP; ++part) a[part] = n[part];
     }
     if (form1) {        // wave-uniform; a compile-time nullptr in the single-band kernels
 #pragma unroll
@@ -638,7 +692,7 @@ __device__ inline void panel_product_pieces_regs(const SplitImage<RT, C::NP> &A,
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(A.a[term_a<NP>(i)][KB - 1][t], B.p[term_b<NP>(i)][KB - 1], OUT[t]);
+        for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C, tail16_kb<RT, 1>(KB - 1)>(A.a[term_a<NP>(i)][KB - 1][t], B.p[term_b<NP>(i)][KB - 1], OUT[t]);
 #elif PILOT_AREG_ORDER == 3
     // every k-block tile after tile
 #pragma unroll
