@@ -598,6 +598,28 @@ def precision_ladder(P, M, reg, config, steps=10, row_step=60):
             "oracle_mean_updates_per_pair": round(float(io["iters"].mean()), 2), "rungs": rungs}
 
 
+def sweep_roofline(key, ms):
+    """Matrix-pipe roofline of a sweep row: the dominant kernel of the workload from the committed rocprofv3 PMC passes
+    (profiles/rNN/sweep_rooflines.json, tools/sweep_pmc.sh) -- MFMA instructions per launch, the share of the launch's SIMD cycles
+    the matrix pipe / the vector unit were busy, and `frac` = matrix-pipe busy share x the kernel's share of the step."""
+    path, rnd = profile_file("sweep_rooflines.json")
+    if not path:
+        return None
+    try:
+        with open(path) as fh:
+            e = json.load(fh).get(key)
+    except (OSError, ValueError):
+        return None
+    if not e:
+        return None
+    return {"bound": "mfma", "kernel": e["kernel"], "pipe": "16-bit matrix pipe (v_mfma_f32_16x16x32 / 16x16x16, f16 or bf16 pieces)",
+            "mfma_per_launch": e["sq_insts_mfma"], "valu_per_launch": e["sq_insts_valu"], "mfma_busy": e["mfma_busy"], "valu_busy": e["valu_busy"],
+            "coexec": e["coexec"], "kernel_ms_rocprofv3": round(e["kernel_us_profiled"] / 1e3, 4), "frac": e["mfma_busy"],
+            "frac_is": "share of the launch's SIMD cycles with the matrix pipe busy (SQ_VALU_MFMA_BUSY_CYCLES): issue utilisation of the pipe that "
+                       "bounds the kernel, padding and piece products included",
+            "source": "profiles/%s/sweep_rooflines.json (rocprofv3 --pmc, git %s)" % (rnd, e.get("git", "?"))}
+
+
 def reg_sweep(P, M, K, regs=(0.01, 0.1, 1.0), row_step=60):
     """BASELINE config 3 names the sweep reg 0.01 / 0.1 / 1.0: per reg the step time with precision='auto', what AUTO
     picked, and parity against the oracle on rows 0, 60, 120, ... (10 rows x 600 columns)."""
@@ -643,6 +665,7 @@ def reg_sweep(P, M, K, regs=(0.01, 0.1, 1.0), row_step=60):
             "cpu_pairs_per_s": round(Eo.size / dt_cpu, 1), "cpu_cores": host_cores(),
             "cpu_pairs_per_s_one_thread": round(N / dt_cpu1, 1),
             "cpu_what": "the fp64 oracle (POT's rule, kind \"port\") on the same sample, OpenMP over pairs on cpu_cores; one thread: row 0 (%d pairs)" % N,
+            "roofline": sweep_roofline("c3|%g" % reg, 1e3 * dt),
         })
     plan.close()
     return {"precision": "auto", "sample": "rows 0,%d,.. x all columns" % row_step, "rows": rows}
@@ -831,6 +854,7 @@ def bench_c4(L, rank, world, comm, args, single_process_multi, steps=3):
         _, info = plan.fetch(n_rows=N)
         fl = algorithmic_flops(info["iters"], P.shape[1])
         res["roofline_frac_f32_mfma"] = round(fl / (float(np.mean(main_ms)) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        res["roofline"] = sweep_roofline("c4|0.1", 1e3 * dt)
     if comm:
         res["max_kernel_ms_over_ranks"] = round(comm.all_reduce_max(float(np.mean(main_ms))), 3)
         fence()
