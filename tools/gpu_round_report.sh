@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything the round commits under profiles/: usage tools/gpu_round_report.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/report_$TAG
 mkdir -p $O
@@ -20,6 +20,7 @@ python bench.py --gpus 2 --logical-shards --no-cpu-baseline > $O/bench_two_logic
 python bench.py --gpus 8 --logical-shards --no-cpu-baseline > $O/bench_eight_logical_shards_one_gpu.json 2>> $O/bench.err
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29544 python bench.py --gpus 1 --force-comm --no-cpu-baseline > $O/bench_one_rank_rccl_comm.json 2>> $O/bench.err
 python tools/e2e_profile.py c3 > $O/e2e_tl_wasserstein_distance_c3.txt 2>&1
+python tools/cellw2_parity_c5.py 4 8 $O/cellw2_parity_c5.json > $O/cellw2_parity_c5.txt 2>&1
 python tools/shard_floor.py $O/shard_floor.json > $O/shard_floor_one_gpu.txt 2>&1
 python tools/host_enqueue_time.py > $O/host_enqueue_time.txt 2>&1
 python tools/k_sweep.py > $O/k_sweep.txt 2>&1
@@ -54,6 +55,9 @@ cp $O/stats_k80/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_k80.csv 2>/dev/nu
 cp $O/stats_k96/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_k96.csv 2>/dev/null
 bash tools/profile_pmc.sh gpurun_out/report_$TAG/pmc --no-extras > /dev/null 2>&1
 cp $O/pmc/summary.txt $O/rocprofv3_pmc_summary_bench_c3.txt
+# the pre-pass (kernel stats, FETCH / WRITE per kernel, prepass_traffic.json) and the sweep rows (reg 0.01 / 1.0, c4: sweep_rooflines.json)
+bash tools/prepass_pmc.sh gpurun_out/report_$TAG > /dev/null 2>&1
+bash tools/sweep_pmc.sh gpurun_out/report_$TAG > /dev/null 2>&1
 # exact-OT kernels (c3, the reference test's cohort, the K = 64/65 and 128/129 steps) and the cell-level kernel's traffic:
 # rocprofv3_pmc_summary_emd_*.txt, emd_instr.json, cellw2_traffic.json
 bash tools/emd_round_profiles.sh gpurun_out/report_$TAG > /dev/null 2>&1
