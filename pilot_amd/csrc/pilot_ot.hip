@@ -769,16 +769,23 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     }
     hipEvent_t *ev = (pl->timing > 0 && (pl->n_calls++ % pl->timing) == 0) ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
+    // (fp16-split configuration, 96 < K <= 128, symmetric cost: four waves per tile, one tile per workgroup, three workgroups per CU)
+    const bool quad = half && pilot::quad_covers(K, sym) && !pilot::test_switch("PILOT_OT_NO_QUAD");
     auto launch = [&](int tvv, bool track, int wgs, const StreamLds &L) -> hipError_t {
         p.ring = L.ring;
         if (tvv) return pilot::launch_stream_tv(cfg, tvv, RT, sym, track, dim3(wgs), L.bytes, s, p);
+        if (half && !track && quad) return pilot::launch_quad(dim3(wgs), s, p);
         if (half && !track) return pilot::launch_stream_h32(RT, sym, live1, dim3(wgs), L.bytes, s, p);
         if (split) return pilot::launch_stream_s32(RT, sym, track, live1, dim3(wgs), L.bytes, s, p);
         return f64 ? pilot::launch_stream_f64(RT, sym, track, dim3(wgs), L.bytes, s, p)
                    : pilot::launch_stream_f32(RT, sym, track, dim3(wgs), L.bytes, s, p);
     };
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
-    if (!track_all) {
+    if (!track_all && quad) {
+        int wgs = 3 * pl->n_cu;
+        if (wgs > tiles) wgs = tiles;
+        HIP_TRY(launch(tv, false, wgs, StreamLds{}));
+    } else if (!track_all) {
         int want = stream_min_waves(w, RT, sym, false, tv, split, half);
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
         // split configurations up to 4 row-tiles flush their ring inline and park U in LDS meanwhile (pilot::parked_flush):
