@@ -583,7 +583,7 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
     if (lds > LDS_BYTES) return fail(PILOT_OT_ENOTSUP, "K=%d does not fit the generic kernel's LDS vectors", K);
     if (!pl->kws) {
         // two workgroups per CU, fewer when K' and its transpose would take more than 8 GB in all
-        int wgs = 2 * pl->n_cu;
+        int wgs = 3 * pl->n_cu;
         const size_t per = sizeof(double) * 2 * (size_t)K * K;
         while (wgs > 1 && per * wgs > ((size_t)8 << 30)) wgs /= 2;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->kws), per * wgs));
@@ -769,7 +769,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     }
     hipEvent_t *ev = (pl->timing > 0 && (pl->n_calls++ % pl->timing) == 0) ? pl->ev[pl->n_timed % TIMING_RING] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    // (fp16-split configuration, 96 < K <= 128, symmetric cost: four waves per tile, one tile per workgroup, three workgroups per CU)
+    // (fp16-split configuration, 112 < K <= 128, symmetric cost: four waves per tile, one tile per workgroup, two workgroups per CU)
     const bool quad = half && pilot::quad_covers(K, sym) && !pilot::test_switch("PILOT_OT_NO_QUAD");
     auto launch = [&](int tvv, bool track, int wgs, const StreamLds &L) -> hipError_t {
         p.ring = L.ring;
@@ -782,7 +782,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     };
     // first pass: throughput kernel (pairs that would tau-absorb are handed to the second pass)
     if (!track_all && quad) {
-        int wgs = 3 * pl->n_cu;
+        int wgs = 2 * pl->n_cu;
         if (wgs > tiles) wgs = tiles;
         HIP_TRY(launch(tv, false, wgs, StreamLds{}));
     } else if (!track_all) {

@@ -1,118 +1,44 @@
-// Sinkhorn pair-grid kernel for 96 < K <= 128 cell types (symmetric cost, fp16-split range): FOUR waves per 16-pair tile.
+// Sinkhorn pair-grid kernel for 112 < K <= 128 cell types (8 row-tiles; symmetric cost, fp16-split range): FOUR waves per 16-pair tile.
 //
-// Why.  From 7 row-tiles on the one-wave-per-tile kernel (sinkhorn_stream_kernel) reads its operand image from LDS for every
-// pair of MFMAs, keeps 5 panels of 7 x 4 registers and spills (400 B per lane at K = 100): c4 (2000 x 100, the shape BASELINE gives
-// to 8 GPUs) ran 23.2 ms with the matrix pipe half busy.  Here, like in sinkhorn_wide_kernel (128 < K <= 256, eight waves), the cell
-// types of a tile are spread over the waves of a 256-thread workgroup -- wave w owns the output row-tiles 2 w and 2 w + 1:
-//   * its rows of the image live in REGISTERS (2 pieces x 4 k-blocks x 2 tiles x 16 B = 64 VGPRs), loaded once per wave;
-//     G^T = G serves both products, nothing but panels moves in the update loop;
+// Why.  At 8 row-tiles the one-wave-per-tile kernel (sinkhorn_stream_kernel) needs 347 registers, runs one wave per SIMD and reads
+// its operand image from LDS for every pair of MFMAs: K = 128 at N = 600 took 1.85 ms against 1.0 ms at K = 96.  Here, like in
+// sinkhorn_wide_kernel (128 < K <= 256, eight waves), the cell types of a tile are spread over the waves of a 256-thread workgroup --
+// wave w owns the output row-tiles 2 w and 2 w + 1:
+//   * its rows of the image AND of G o M live in REGISTERS (2 x 2 pieces x 4 k-blocks x 2 tiles x 16 B = 128 VGPRs), loaded once
+//     per wave; G^T = G serves both products, nothing but panels moves in the update loop; two workgroups per CU;
 //   * the accumulator registers of tiles 2 w, 2 w + 1 are exactly k-block w of the next product's B operand, so after the
 //     element-wise step a wave publishes ONE k-block of packed pieces (2 KB) in LDS and reads all four: two workgroup
-//     barriers per update;
+//     barriers per update (LDS-only barriers: lds_barrier);
 //   * control state is replicated in every wave and moves only on values every wave reads identically from LDS (the tau
 //     flags of the columns, the four partial squared errors added in wave order), so the waves never diverge and a pair's bits
 //     do not depend on its slot, its workgroup or the row subset of the call;
 //   * the operand block, the slot-ordered proportions, the longest-first work list, the hand-over list of pairs in which POT
 //     would tau-absorb (solved by the bf16 tracking kernel) and the NaN list are those of the stream kernel's fast pass: this
 //     kernel takes its place in the same call sequence;
-//   * THE COSTS ARE FORMED INSIDE THE KERNEL (round 5's four-wave experiment left records for a second kernel and lost its
-//     18 - 26 % again in that round trip): a finished pair parks its (u, v) pieces -- every wave its own k-block -- in a ring
-//     of 16 slots in LDS; when the ring is full the four waves form <Gamma, M> = u^T (G o M) v for all 16 pairs with ONE more
-//     panel product (each wave its rows of G o M, read from L2), the per-wave partial sums meet in LDS in wave order.
-// The last k-block of an odd row-tile count (K <= 112) holds one row-tile and runs on v_mfma_f32_16x16x16_f16 (see
-// mfma_pieces<C, true> and tail16_gap).
+//   * the costs are formed inside the kernel: a finished pair parks its (u, v) pieces -- every wave its own k-block -- in a ring
+//     of 32 slots in LDS; when the ring is full the four waves form <Gamma, M> = u^T (G o M) v with one more panel product per 16
+//     pairs and the per-wave partial sums meet in LDS in wave order.
+// Why not from 7 row-tiles (K = 97 .. 112, BASELINE's c4 among them), where the update loop alone (140 VGPRs, three workgroups per CU)
+// runs K = 100 at N = 600 in 1.32 ms against the stream kernel's 1.60: every way of giving the cost flush its rows of G o M costs more
+// than that -- a second register image means two workgroups per CU (1.69 ms); a call that fetches the rows pays its register saves
+// (1.61 ms); streaming them through spare registers, or swapping the register image for the flush, spills the update loop (1.77 /
+// 2.15 ms); records for a second kernel are round 5's 2.3 ms at c4.  The table is in profiles/r06/ab_experiments.md section 5.
 // Same scaled domain, stopping rule (f32 floor of the threshold) and tolerance as the fp16-split stream kernel.
 #pragma once
 #include "sinkhorn_kernels.hpp"
 
 namespace pilot {
 
-constexpr int QUAD_WAVES = 4, QUAD_KB = 4, QUAD_RING = 16, QUAD_MIN_K = 97, QUAD_MAX_K = 128;
+constexpr int QUAD_WAVES = 4, QUAD_KB = 4, QUAD_RING = 32, QUAD_MIN_K = 113, QUAD_MAX_K = 128;
 
-// The costs of the cnt pairs in the ring: one more panel product by all four waves (cnt is the same in every wave).  Deliberately
-// NOT inlined: it runs once per 16 finished pairs, and as a call its registers (an accumulator pair, eight operand registers of
-// G o M in flight) are paid at the call site instead of in the update loop, which must fit 168 VGPRs for three workgroups per CU.
-template <int RT>
-__device__ __attribute__((noinline)) void quad_flush(const GridParams &p, int cnt, const u32x4_t (*ring_pu)[QUAD_KB][2][CfgH32x16::NGRP],
-                                                     const u32x4_t (*ring_pv)[QUAD_KB][2][CfgH32x16::NGRP], const int (*ring_meta)[2],
-                                                     float (*red_val)[CfgH32x16::TILE]) {
-    using C = CfgH32x16;
-    using acc_t = C::acc_t;
-    constexpr int TILE = C::TILE, NREG = C::NREG, KB = QUAD_KB;
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE, col = lane % TILE, grp = lane / TILE;
-    constexpr int KBL = (RT + 1) / 2;
-    constexpr bool tail16 = PILOT_TAIL16 && (RT & 1);
-    constexpr int FORM = form_elems<C>(RT);
-    const float *img = static_cast<const float *>(p.img);
-    __syncthreads();                                                    // every wave's ring stores are visible
-    const int s = col < cnt ? col : cnt - 1;                            // columns beyond the fill level redo the last slot, unused
-    acc_t W[2];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) W[tl][r] = 0.f;
-    {
-        // my rows of G o M (form 2) from L2, one tile at a time
-        const u32x4_t *gm = reinterpret_cast<const u32x4_t *>(img + 2 * FORM);
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            if (2 * wave + tl >= RT) continue;                          // (wave-uniform: tile 7 is dead up to K = 112)
-            u32x4_t G[2][KB];
-#pragma unroll
-            for (int part = 0; part < 2; ++part)
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    G[part][kb] = u32x4_t{0u, 0u, 0u, 0u};
-                    if (kb < KBL) G[part][kb] = gm[((part * KBL + kb) * RT + (2 * wave + tl)) * WAVE + lane];
-                }
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                if (kb >= KBL) continue;
-                const u32x4_t b0 = ring_pv[s][kb][0][grp], b1 = ring_pv[s][kb][1][grp];
-                if (tail16 && kb == KBL - 1) {
-                    tail16_gap();                                       // (the tile's full MFMAs are right in front)
-                    W[tl] = mfma_pieces<C, true>(G[1][kb], b0, W[tl]);
-                    W[tl] = mfma_pieces<C, true>(G[0][kb], b1, W[tl]);
-                    W[tl] = mfma_pieces<C, true>(G[0][kb], b0, W[tl]);
-                } else {
-                    W[tl] = mfma_pieces<C>(G[1][kb], b0, W[tl]);
-                    W[tl] = mfma_pieces<C>(G[0][kb], b1, W[tl]);
-                    W[tl] = mfma_pieces<C>(G[0][kb], b0, W[tl]);
-                }
-            }
-        }
-    }
-    // u of my rows = hi + lo of my k-block of the slot's u pieces
-    const u32x4_t uh = ring_pu[s][wave][0][grp], ul = ring_pu[s][wave][1][grp];
-    float val = 0.f;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        val += pieces_sum_lo(uh[h], ul[h]) * W[h / 2][2 * (h & 1)];
-        val += pieces_sum_hi(uh[h], ul[h]) * W[h / 2][2 * (h & 1) + 1];
-    }
-    val = group_sum<C>(val);
-    if (grp == 0) red_val[wave][col] = val;
-    __syncthreads();
-    if (wave == 0 && grp == 0 && col < cnt) {
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < QUAD_WAVES; ++w) tot += red_val[w][col];             // wave order: one sum, whatever the timing
-        tot *= 1.f / H_IN_SCALE;                                        // u~^T (2^15 G o M) v~ = 2^25 u^T (G o M) v
-        const int qq = ring_meta[col][0];
-        int fl = ring_meta[col][1];
-        if (p.nan_list && (!(tot - tot == 0.f) || (fl & FLAG_NAN))) {               // NaN or inf: the POT-literal kernel solves the pair again
-            p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
-        } else {
-            if (tot != tot) fl |= FLAG_NAN;
-            p.emd[qq] = double(tot);
-            p.flags[qq] = fl;
-        }
-    }
-    __syncthreads();                                                    // the slots are reused only after every lane has read them
-}
+// Workgroup barrier for data that travels through LDS only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
+// (s_waitcnt vmcnt(0): the outputs of finished pairs, a microsecond or two until L2 acknowledges them) -- in a kernel that meets at
+// two barriers per update and writes outputs now and then that wait was 6 us per cost flush (K = 128 at N = 600: 1.58 ms with
+// __syncthreads, see profiles/r06/ab_experiments.md).  Nothing the waves of a workgroup tell each other here goes through global memory.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int RT>
-__global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(GridParams p) {
+__global__ void __launch_bounds__(WAVE * QUAD_WAVES, 2) sinkhorn_quad_kernel(GridParams p) {
     static_assert(RT == 7 || RT == 8, "four waves own two row-tiles each");
     using C = CfgH32x16;
     using acc_t = C::acc_t;
@@ -141,18 +67,8 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) tile_live[tl] = 2 * wave + tl < RT;  // (wave-uniform; tile 7 is dead up to K = 112)
 
-    // my rows of the operand image: [piece][k-block][local tile]
+    // my rows of the operand image: [piece][k-block][local tile] (loaded below, and again after every cost flush)
     u32x4_t AR[2][KB][2];
-#pragma unroll
-    for (int part = 0; part < 2; ++part)
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                AR[part][kb][tl] = u32x4_t{0u, 0u, 0u, 0u};
-                if (tile_live[tl] && kb < KBL)                       // (a dead tile keeps a zero image)
-                    AR[part][kb][tl] = reinterpret_cast<const u32x4_t *>(img)[((part * KBL + kb) * RT + (2 * wave + tl)) * WAVE + lane];
-            }
     // padded slots (cell types beyond K; every slot of a dead tile) as a bit mask: their accumulators start at 1, which keeps 0 / OUT finite
     unsigned int padmask = 0u;
 #pragma unroll
@@ -162,14 +78,10 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
 
     // OUT (my two tiles) = image rows x the panel in PB[panel]; piece products smallest first: a2 b1, a1 b2, a1 b1.  Straight-line code:
     // a dead tile (tile 7 up to K = 112, wave 3 only) multiplies a zero image -- the other three waves set the pace anyway.
-    auto product = [&](int panel, acc_t (&OUT)[2]) {
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r) OUT[tl][r] = (padmask >> (tl * NREG + r)) & 1u ? 1.f : 0.f;
+    auto product_of = [&](const u32x4_t (&IMG)[2][KB][2], auto bget, acc_t (&OUT)[2]) {
 #pragma unroll
         for (int kb = 0; kb < KBL; ++kb) {
-            const u32x4_t b0 = PB[panel][kb][0][lane], b1 = PB[panel][kb][1][lane];
+            const u32x4_t b0 = bget(kb, 0), b1 = bget(kb, 1);
             if constexpr (tail16) {
                 if (kb == KBL - 1) {                                     // one row-tile of k-slots: the 16-deep instruction
                     // (a tile's tail MFMAs follow its last full MFMA behind three other MFMAs; the gap keeps the 16x16x32 -> 16x16x16
@@ -177,20 +89,27 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
                     tail16_gap();
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) {
-                        OUT[tl] = mfma_pieces<C, true>(AR[1][kb][tl], b0, OUT[tl]);
-                        OUT[tl] = mfma_pieces<C, true>(AR[0][kb][tl], b1, OUT[tl]);
-                        OUT[tl] = mfma_pieces<C, true>(AR[0][kb][tl], b0, OUT[tl]);
+                        OUT[tl] = mfma_pieces<C, true>(IMG[1][kb][tl], b0, OUT[tl]);
+                        OUT[tl] = mfma_pieces<C, true>(IMG[0][kb][tl], b1, OUT[tl]);
+                        OUT[tl] = mfma_pieces<C, true>(IMG[0][kb][tl], b0, OUT[tl]);
                     }
                     continue;
                 }
             }
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
-                OUT[tl] = mfma_pieces<C>(AR[1][kb][tl], b0, OUT[tl]);
-                OUT[tl] = mfma_pieces<C>(AR[0][kb][tl], b1, OUT[tl]);
-                OUT[tl] = mfma_pieces<C>(AR[0][kb][tl], b0, OUT[tl]);
+                OUT[tl] = mfma_pieces<C>(IMG[1][kb][tl], b0, OUT[tl]);
+                OUT[tl] = mfma_pieces<C>(IMG[0][kb][tl], b1, OUT[tl]);
+                OUT[tl] = mfma_pieces<C>(IMG[0][kb][tl], b0, OUT[tl]);
             }
         }
+    };
+    auto product = [&](int panel, acc_t (&OUT)[2]) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) OUT[tl][r] = (padmask >> (tl * NREG + r)) & 1u ? 1.f : 0.f;
+        product_of(AR, [&](int kb, int part) { return PB[panel][kb][part][lane]; }, OUT);
     };
     // X (my two tiles) -> the packed pieces of my k-block
     auto pieces_of = [&](const acc_t (&X)[2], u32x4_t &hi, u32x4_t &lo) {
@@ -202,8 +121,71 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
         }
     };
 
-    auto flush = [&](int cnt) { quad_flush<RT>(p, cnt, ring_pu, ring_pv, ring_meta, red_val); };
+    // my rows of G (form 0, the update loop's) and of G o M (form 2, the cost flush's): both stay in registers
+    // (branch-free loads: a dead tile -- tile 7 at 7 row-tiles, wave 3 only -- reads its neighbour's rows and masks them to zero)
+    u32x4_t AGM[2][KB][2];
+    auto load_image = [&](int form, u32x4_t (&IMG)[2][KB][2]) {
+        const u32x4_t *src = reinterpret_cast<const u32x4_t *>(img + form * FORM) + lane;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int kb = 0; kb < KBL; ++kb)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int t = 2 * wave + tl < RT ? 2 * wave + tl : RT - 1;
+                    u32x4_t x = src[((part * KBL + kb) * RT + t) * WAVE];
+                    if constexpr (RT & 1) {
+                        const unsigned int m = tile_live[tl] ? 0xffffffffu : 0u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] &= m;
+                    }
+                    IMG[part][kb][tl] = x;
+                }
+    };
+    // ---- the costs of the cnt pairs in the ring: one more panel product per 16 pairs, all four waves (cnt is the same in every wave) ----
+    auto flush = [&](int cnt) {
+        lds_barrier();                                                  // every wave's ring stores are visible
+        for (int base = 0; base < cnt; base += TILE) {                  // (wave-uniform)
+            const int n = cnt - base < TILE ? cnt - base : TILE;
+            const int s = base + (col < n ? col : n - 1);               // columns beyond the fill level redo the last slot, unused
+            acc_t W[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) W[tl][r] = 0.f;
+            product_of(AGM, [&](int kb, int part) { return ring_pv[s][kb][part][grp]; }, W);      // W = my rows of (G o M) v
+            // u of my rows = hi + lo of my k-block of the slot's u pieces
+            const u32x4_t uh = ring_pu[s][wave][0][grp], ul = ring_pu[s][wave][1][grp];
+            float val = 0.f;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                val += pieces_sum_lo(uh[h], ul[h]) * W[h / 2][2 * (h & 1)];
+                val += pieces_sum_hi(uh[h], ul[h]) * W[h / 2][2 * (h & 1) + 1];
+            }
+            val = group_sum<C>(val);
+            if (grp == 0) red_val[wave][col] = val;
+            lds_barrier();
+            if (wave == 0 && grp == 0 && col < n) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < QUAD_WAVES; ++w) tot += red_val[w][col];     // wave order: one sum, whatever the timing
+                tot *= 1.f / H_IN_SCALE;                                // u~^T (2^15 G o M) v~ = 2^25 u^T (G o M) v
+                const int qq = ring_meta[s][0];
+                int fl = ring_meta[s][1];
+                if (p.nan_list && (!(tot - tot == 0.f) || (fl & FLAG_NAN))) {       // NaN or inf: the POT-literal kernel solves the pair again
+                    p.nan_list[__hip_atomic_fetch_add(p.nan_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = qq;
+                } else {
+                    if (tot != tot) fl |= FLAG_NAN;
+                    p.emd[qq] = double(tot);
+                    p.flags[qq] = fl;
+                }
+            }
+            lds_barrier();                                              // red_val and the slots are reused only after every lane has read them
+        }
+    };
 
+    load_image(0, AR);
+    load_image(2, AGM);
     bool active = false, want = true, exhausted = false;
     int q = 0, ii = 0, chk = 1, flags = 0, ring_cnt = 0;
     float errv = 1.f, thr = 0.f;
@@ -215,7 +197,7 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
     int res_next = 0, res_end = 0, res_base = 0, qbatch = 0, ibatch = 0, jbatch = 0, draws = 0;
     const bool all_over = p.unequal && *p.unequal != 0;                  // histograms of unequal mass: see the stream kernel
     if (threadIdx.x < 2 * TILE) (&ovc[0][0])[threadIdx.x] = 0;
-    __syncthreads();
+    lds_barrier();
     if ((int)blockIdx.x * TILE >= n_items) return;                       // more workgroups than work
 
     for (int it = 0;; ++it) {
@@ -230,7 +212,7 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
                 } else {
                     if (threadIdx.x == 0)
                         sh_base[draws & 1] = (int)gridDim.x * TILE + __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __syncthreads();
+                    lds_barrier();
                     base = __builtin_amdgcn_readfirstlane(sh_base[draws & 1]);
                 }
                 ++draws;
@@ -297,7 +279,7 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
             PB[0][wave][0][lane] = hi; PB[0][wave][1][lane] = lo;
         }
         if (active && !(mx <= tau)) ovc[par][col] = 1;                   // (NaN counts as over: the tracking kernel restarts the pair)
-        __syncthreads();
+        lds_barrier();
         // ---- u = a / (G v) ------------------------------------------------------------------------------------------------
         product(0, ACC);
         mx = 0.f;
@@ -313,7 +295,7 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
         }
         if (active && !(mx <= tau)) ovc[par][col] = 1;
         if (threadIdx.x < TILE) ovc[par ^ 1][threadIdx.x] = 0;           // next iteration's flags (nobody reads them before barrier 2 of it)
-        __syncthreads();
+        lds_barrier();
         // POT: max|u| > tau or max|v| > tau -> absorb: the pair leaves the scaled domain; the tracking kernel restarts it
         const bool over = active && ovc[par][col] != 0;
         if (over) {
@@ -337,7 +319,7 @@ __global__ void __launch_bounds__(WAVE * QUAD_WAVES, 3) sinkhorn_quad_kernel(Gri
             }
             e2 = group_sum<C>(e2);
             if (grp == 0) red_e2[par][wave][col] = e2;
-            __syncthreads();
+            lds_barrier();
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < QUAD_WAVES; ++w) tot += red_e2[par][w][col];     // wave order: the same sum in every wave

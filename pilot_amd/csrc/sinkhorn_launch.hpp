@@ -30,7 +30,7 @@ hipError_t launch_prep(int cfg, const double *M, int K, int RT, double reg, void
 hipError_t launch_wide(dim3 grid, hipStream_t s, const GridParams &p, float *rec);
 hipError_t launch_wide_value(dim3 grid, hipStream_t s, const GridParams &p, const float *rec);
 size_t wide_rec_elems();
-// 96 < K <= 128, symmetric cost: the fast pass of the fp16-split configuration with four waves per 16-pair tile (quad_kernels.hpp);
+// 112 < K <= 128, symmetric cost: the fast pass of the fp16-split configuration with four waves per 16-pair tile (quad_kernels.hpp);
 // same GridParams, work list, hand-over and NaN lists as launch_stream_h32, one tile per 256-thread workgroup, costs formed in the kernel
 hipError_t launch_quad(dim3 grid, hipStream_t s, const GridParams &p);
 bool quad_covers(int K, bool sym);

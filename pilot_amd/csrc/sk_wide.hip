@@ -1,4 +1,4 @@
-// The 8-waves-per-tile Sinkhorn kernels for 128 < K <= 256 (wide_kernels.hpp), the 4-waves-per-tile kernel for 96 < K <= 128
+// The 8-waves-per-tile Sinkhorn kernels for 128 < K <= 256 (wide_kernels.hpp), the 4-waves-per-tile kernel for 112 < K <= 128
 // (quad_kernels.hpp) and their launch entry points.
 #include "sinkhorn_launch.hpp"
 #include "wide_kernels.hpp"
@@ -16,8 +16,7 @@ hipError_t launch_wide_value(dim3 grid, hipStream_t s, const GridParams &p, cons
 }
 size_t wide_rec_elems() { return (size_t)WIDE_REC; }
 hipError_t launch_quad(dim3 grid, hipStream_t s, const GridParams &p) {
-    if ((p.K + 15) / 16 == 7) hipLaunchKernelGGL(sinkhorn_quad_kernel<7>, grid, dim3(WAVE * QUAD_WAVES), 0, s, p);
-    else hipLaunchKernelGGL(sinkhorn_quad_kernel<8>, grid, dim3(WAVE * QUAD_WAVES), 0, s, p);
+    hipLaunchKernelGGL(sinkhorn_quad_kernel<8>, grid, dim3(WAVE * QUAD_WAVES), 0, s, p);
     return hipGetLastError();
 }
 bool quad_covers(int K, bool sym) { return sym && K >= QUAD_MIN_K && K <= QUAD_MAX_K; }

@@ -124,9 +124,9 @@ def test_k_above_128_runs_the_reference_semantics_kernel(K):
     assert np.abs(engine.emd_grid(P, M) - O.emd_grid(P, M, n_threads=16)).max() <= 1e-12
 
 
-@pytest.mark.parametrize("K", [97, 100, 112, 113, 128])
-def test_k_97_to_128_runs_four_waves_per_tile(K, switches):
-    """96 < K <= 128, symmetric cost, fp16-split range: sinkhorn_quad_kernel (quad_kernels.hpp) -- a tile's cell types spread over
+@pytest.mark.parametrize("K", [113, 120, 128])
+def test_k_113_to_128_runs_four_waves_per_tile(K, switches):
+    """112 < K <= 128 (8 row-tiles), symmetric cost, fp16-split range: sinkhorn_quad_kernel (quad_kernels.hpp) -- a tile's cell types spread over
     four waves, the operand image in registers, the costs formed inside the kernel -- takes the place of the one-wave-per-tile
     stream kernel's fast pass (PILOT_OT_NO_QUAD: that kernel).  f32-class tolerance against the fp64 oracle, the f32 stopping rule
     (the oracle's check or an earlier one), the two kernels agree (same update counts but for pairs at the stop floor), shard / full
@@ -149,16 +149,16 @@ def test_k_97_to_128_runs_four_waves_per_tile(K, switches):
         np.testing.assert_array_equal(part, Eq[rb:re_:rs])
     np.testing.assert_array_equal(engine.sinkhorn_grid(P, M, 0.1), Eq)   # deterministic
     assert np.abs(engine.sinkhorn_grid(P, M, 1.0) - O.sinkhorn_grid(P, M, 1.0, n_threads=16)).max() <= TOL32
-    if K not in (100, 128):
+    if K not in (113, 128):
         return
-    for tau in (150.0, 40.0):
+    for tau in (40.0, 6.0):
         Et, it_ = engine.sinkhorn_grid(P, M, 0.1, tau=tau, return_info=True)
         Eot, iot = O.sinkhorn_grid(P, M, 0.1, tau=tau, n_threads=16, return_info=True)
         last_o, last_g = (iot["flags"] & O.FLAG_ABSORB_ON_LAST) > 0, (it_["flags"] & _lib.FLAG_ABSORB_LAST) > 0
         account_for_absorb_on_last(Et, Eot, last_g, last_o, K, TOL32, max_one_sided_frac=2e-3)
         absorbed_o = (iot["flags"] & O.FLAG_ABSORBED) > 0
         assert (((it_["flags"] & _lib.FLAG_ABSORBED) > 0) != absorbed_o).mean() < 0.01
-    assert absorbed_o.sum() > 0                                          # (at tau = 40 some pair does absorb)
+    assert absorbed_o.sum() > 0                                          # (at tau = 6 some pair does absorb)
 
 
 @pytest.mark.parametrize("K", [129, 130, 160, 192, 250, 256])
