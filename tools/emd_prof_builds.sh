@@ -8,6 +8,6 @@ cp ../libpilot_ot.so "$KEEP"
 trap 'cp "$KEEP" "$R/pilot_amd/libpilot_ot.so"; rm -f "$KEEP"' EXIT
 for st in 1 2 3 4 5 6 7 8 9; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -DEMD_PROF=$st $EXTRA -c -o /tmp/pilot_ot_prof.o pilot_ot.hip 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_prof.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_wide.o build/sk_inst_*.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_prof.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/pilot_ot_labels.o build/sk_wide.o build/sk_inst_*.o -ldl -lpthread
   (cd $R; python3 tools/emd_stats.py ${1:-c3} | sed "s/^/EMD_PROF=$st (ticks\/16): /" | head -2 | tr '\n' ' '; echo)
 done

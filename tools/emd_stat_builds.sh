@@ -10,6 +10,6 @@ trap 'cp "$KEEP" "$R/pilot_amd/libpilot_ot.so"; rm -f "$KEEP"' EXIT
 python3 $R/tools/emd_stats.py ${1:-c3} | sed 's/^/augmentations: /' | head -1
 for st in 1 2 3 4 5; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -DEMD_STAT=$st -c -o /tmp/pilot_ot_stat.o pilot_ot.hip 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_stat.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/sk_wide.o build/sk_inst_*.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpilot_ot.so /tmp/pilot_ot_stat.o build/pilot_ot_multi.o build/pilot_ot_consumers.o build/pilot_ot_labels.o build/sk_wide.o build/sk_inst_*.o -ldl -lpthread
   python3 $R/tools/emd_stats.py ${1:-c3} | sed "s/^/EMD_STAT=$st: /" | head -1
 done
