@@ -581,8 +581,8 @@ __device__ inline typename C::acc_t split_tile_product(const typename C::T *form
     }
     return acc;
 }
-// OUT = X_form * IN for the whole panel.  The operand pieces of step (t, kb + 1) are requested from LDS before the
-// MFMAs of step (t, kb) are issued, so a wave never sits on an LDS round trip between MFMA groups.
+// OUT = X_form * IN for the whole panel.  The operand pieces of a later step are requested from LDS before the MFMAs of step
+// (t, kb) are issued (lds_ahead), so a wave does not sit on an LDS round trip between MFMA groups.
 // form1 (nullable, wave-uniform): the band-1 image of the same operand; OUT = X0 * IN + 2^-128 (X1 * IN).
 // Band 1 holds the Gibbs entries below 2^-110: what they contribute to a product is a small part of it (the plans of the
 // 600 x 50 benchmark at reg 0.01 put 1e-8 .. 1e-2 of their mass there), so the band-1 partial product is taken from the
@@ -590,15 +590,24 @@ __device__ inline typename C::acc_t split_tile_product(const typename C::T *form
 // piece of the stationary operand is a fixed relative perturbation <= 2^-16 of those entries -- a cost change of
 // reg * 2^-16 on entries that carry <= 1e-2 of the mass -- and the panel's is rounding noise of the same size on that part
 // (c3 at reg 0.01: 37.8 -> 32.0 ms per matrix, max distance to the fp64 oracle on 12 000 pairs 1.5e-7 -> 4.4e-7).
+// How many steps ahead of its MFMAs a step's operand pieces are requested from LDS (PILOT_LDS_AHEAD = n forces it for A/B builds).
+// One step ahead (rounds 3 - 5) leaves a wave waiting on the LDS round trip at every other step; further ahead costs 8 registers
+// per step.  fp16-split configuration, same box (tools/ahead_variants.sh, profiles/r06/ahead_variants.txt): 1 / 2 / 3 steps ahead
+// K = 72 0.963 / 0.916 / 0.939 ms, K = 80 0.936 / 0.895 / 0.901, K = 96 0.958 / 0.951 / 0.934, K = 100 1.477 / 1.441 / 1.460,
+// c4 21.75 / 21.67 / 21.54 ms per launch; the three-piece bf16 images (12 registers per step) stay at one.
+template <class C, int RT> __host__ __device__ constexpr int lds_ahead() {
+#ifdef PILOT_LDS_AHEAD
+    return PILOT_LDS_AHEAD;
+#else
+    return !C::HALF ? 1 : (RT <= 5 ? 2 : 3);
+#endif
+}
 template <class C, int RT>
 __device__ inline void panel_product_pieces(const typename C::T *form, const typename C::T *form1, int lane,
                                             const SplitPanel<RT, C::NP> &B, typename C::acc_t (&OUT)[RT],
                                             const typename C::acc_t &last_init) {
     constexpr int KB = split_kblocks(RT), NP = C::NP;
     const u32x4_t *img = reinterpret_cast<const u32x4_t *>(form) + lane;
-    u32x4_t a[NP];
-#pragma unroll
-    for (int part = 0; part < NP; ++part) a[part] = img[((part * KB + 0) * RT + 0) * WAVE];
     // the steps (tile, k-block) in issue order.  TAILS_LAST (odd row-tile counts with the 16-wide tail k-block, >= 3 row-tiles): the full
     // k-blocks of every tile first, then the tails tile after tile -- a tile's 16x16x16 MFMAs then read an accumulator that was
     // written many MFMAs earlier (the hardware forwards an accumulator only between MFMAs of one shape, and ROCm 7.2 puts no wait
@@ -607,6 +616,16 @@ __device__ inline void panel_product_pieces(const typename C::T *form, const typ
     constexpr int STEPS = RT * KB, FULL = RT * (KB - 1);
     auto step_t = [](int s) { return TAILS_LAST ? (s < FULL ? s / (KB - 1) : s - FULL) : s / KB; };
     auto step_kb = [](int s) { return TAILS_LAST ? (s < FULL ? s % (KB - 1) : KB - 1) : s % KB; };
+    // the operand pieces of step s + AHEAD are requested from LDS before the MFMAs of step s are issued (a rotating set of AHEAD + 1
+    // register groups; the indices are compile-time after unrolling)
+    constexpr int AHEAD = lds_ahead<C, RT>();
+    u32x4_t a[AHEAD + 1][NP];
+#pragma unroll
+    for (int d = 0; d < AHEAD; ++d)
+        if (d < STEPS) {
+#pragma unroll
+            for (int part = 0; part < NP; ++part) a[d][part] = img[((part * KB + step_kb(d)) * RT + step_t(d)) * WAVE];
+        }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -614,26 +633,22 @@ __device__ inline void panel_product_pieces(const typename C::T *form, const typ
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const int t = step_t(s), kb = step_kb(s);
-        u32x4_t n[NP];
+        if (s + AHEAD < STEPS) {
+            const int nt = step_t(s + AHEAD), nkb = step_kb(s + AHEAD);
 #pragma unroll
-        for (int part = 0; part < NP; ++part) n[part] = a[part];
-        if (s + 1 < STEPS) {
-            const int nt = step_t(s + 1), nkb = step_kb(s + 1);                       // the step after this one
-#pragma unroll
-            for (int part = 0; part < NP; ++part) n[part] = img[((part * KB + nkb) * RT + nt) * WAVE];
+            for (int part = 0; part < NP; ++part) a[(s + AHEAD) % (AHEAD + 1)][part] = img[((part * KB + nkb) * RT + nt) * WAVE];
         }
         __builtin_amdgcn_sched_barrier(0x6);        // (VALU / SALU may move across; the LDS reads stay ahead of the MFMAs)
+        const u32x4_t (&ac)[NP] = a[s % (AHEAD + 1)];
         if (tail16_kb<RT, 2>(kb)) {
             if (kb > 0 && !TAILS_LAST) tail16_gap();
 #pragma unroll
-            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C, true>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], OUT[t]);
+            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C, true>(ac[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], OUT[t]);
         } else {
 #pragma unroll
-            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(a[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], OUT[t]);
+            for (int i = 0; i < n_terms<NP>(); ++i) OUT[t] = mfma_pieces<C>(ac[term_a<NP>(i)], B.p[term_b<NP>(i)][kb], OUT[t]);
         }
         __builtin_amdgcn_sched_barrier(0x6);
-#pragma unroll
-        for (int part = 0; part < NP; ++part) a[part] = n[part];
     }
     if (form1) {        // wave-uniform; a compile-time nullptr in the single-band kernels
 #pragma unroll
@@ -978,7 +993,9 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_solo_track_kerne
 //
 // Small reg in f32 (bf16-split configuration): with p.bands == 2 the cost product uses both exponent bands of G o M; with
 // p.fb_list set, a pair whose cost is not finite is not written out but appended to fb_list for the f64 kernel.
-template <class C, int RT>
+// V_PIECES (fp16-split configuration): the v half of a slot holds packed pieces (the records of the eight-wave kernel, whose waves
+// never hold a whole f32 panel) instead of f32 values (the ring of the one-wave kernel)
+template <class C, int RT, bool V_PIECES = false>
 __device__ inline __attribute__((always_inline)) void ring_flush_body(const typename C::T *ring, const GridParams &p, int cnt) {
     using M = C;
     using T = typename C::T;
@@ -999,14 +1016,32 @@ __device__ inline __attribute__((always_inline)) void ring_flush_body(const type
     // one output row-tile at a time: only the v panel (or its bf16 pieces) is live
     T val = T(0), val1 = T(0);
     if constexpr (C::HALF) {
-        // the ring holds packed pieces: v's are the B operand as they lie, u = hi + lo
+        // the ring holds u as packed pieces (u = hi + lo) and v as f32 values: v's pieces -- the B operand of the cost product -- are
+        // formed again here, once per 16 finished pairs, with the update loop's own instruction sequence (same bits).  In the
+        // update loop v's pieces are then dead once the product G v is issued and share their registers with u's (7 row-tiles:
+        // 32 registers, which the loop used to spill; profiles/r06/ab_experiments.md)
         constexpr int KB = split_kblocks(RT);
         SplitPanel<RT, 2> Bv;
+        if constexpr (V_PIECES) {
 #pragma unroll
-        for (int part = 0; part < 2; ++part)
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    Bv.p[part][kb] = *reinterpret_cast<const u32x4_t *>(rec + PE + ((part * KB + kb) * NGRP + grp) * 4);
+        } else {
+            acc_t Vr[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) load_regs<C>(rec + PE + (t * NGRP + grp) * NREG, Vr[t]);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
-                Bv.p[part][kb] = *reinterpret_cast<const u32x4_t *>(rec + PE + ((part * KB + kb) * NGRP + grp) * 4);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int t = 2 * kb + h / 2, e = 2 * (h & 1);
+                    unsigned int hi = 0u, lo = 0u;
+                    if (t < RT) quot_pieces(float(Vr[t][e]), float(Vr[t][e + 1]), hi, lo);      // (padded and dead slots hold 0: pieces 0)
+                    Bv.p[0][kb][h] = hi; Bv.p[1][kb][h] = lo;
+                }
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             acc_t zero;
@@ -1489,6 +1524,21 @@ sinkhorn_stream_kernel(GridParams p) {
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) V[t][r] = dead(t, r) ? T(0) : B[t][r] * M::rcp(ACC[t][r]);
             quot_panel(V, PV);
+            // max(v) over the leading pieces, two elements per instruction; PV is dead once the product below is issued
+            unsigned int m2 = 0u;
+            {
+                unsigned int pend = 0u;
+                bool have = false;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        if (pieces_live(kb, h)) {
+                            if (have) { m2 = pk_max3_f16(m2, pend, PV.p[0][kb][h]); have = false; }
+                            else { pend = PV.p[0][kb][h]; have = true; }
+                        }
+                if (have) m2 = pk_max3_f16(m2, pend, pend);
+            }
             product_h(a_g.img, PV, ACC);
             {
                 acc_t X[RT];
@@ -1498,14 +1548,21 @@ sinkhorn_stream_kernel(GridParams p) {
                     for (int r = 0; r < NREG; ++r) X[t][r] = dead(t, r) ? T(0) : A[t][r] * M::rcp(ACC[t][r]);
                 quot_panel(X, PU);
             }
-            // max(u, v) over the leading pieces, two elements per instruction (a NaN piece makes the maximum NaN and the
-            // comparison below false: the pair is caught by the error test instead, as in POT)
-            unsigned int m2 = 0u;
+            // ... joined by max(u) (a NaN piece makes the maximum NaN and the comparison below false: the pair is caught by the
+            // error test instead, as in POT)
+            {
+                unsigned int pend = 0u;
+                bool have = false;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+                for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int h = 0; h < 4; ++h)
-                    if (pieces_live(kb, h)) m2 = pk_max3_f16(m2, PU.p[0][kb][h], PV.p[0][kb][h]);
+                    for (int h = 0; h < 4; ++h)
+                        if (pieces_live(kb, h)) {
+                            if (have) { m2 = pk_max3_f16(m2, pend, PU.p[0][kb][h]); have = false; }
+                            else { pend = PU.p[0][kb][h]; have = true; }
+                        }
+                if (have) m2 = pk_max3_f16(m2, pend, pend);
+            }
             const f16x2_t mh = __builtin_bit_cast(f16x2_t, m2);
             const float m0 = float(mh[0]), m1 = float(mh[1]);
             mx = (m0 <= tau && m1 <= tau) ? fmax(m0, m1) : __builtin_inff();      // a NaN half counts as over (see below)
@@ -1726,10 +1783,11 @@ sinkhorn_stream_kernel(GridParams p) {
 #pragma unroll
                             for (int part = 0; part < 2; ++part)
 #pragma unroll
-                                for (int kb = 0; kb < KB; ++kb) {
+                                for (int kb = 0; kb < KB; ++kb)
                                     *reinterpret_cast<u32x4_t *>(rec + ((part * KB + kb) * NGRP + grp) * 4) = PU.p[part][kb];
-                                    *reinterpret_cast<u32x4_t *>(rec + PE + ((part * KB + kb) * NGRP + grp) * 4) = PV.p[part][kb];
-                                }
+                            static_assert(!C::HALF || PE >= RT * C::TILE, "the v half of a ring slot holds f32 values");
+#pragma unroll
+                            for (int t = 0; t < RT; ++t) store_regs<C>(rec + PE + (t * NGRP + grp) * NREG, V[t]);   // (f32: see ring_flush_body)
                         } else {
 #pragma unroll
                         for (int t = 0; t < RT; ++t) {

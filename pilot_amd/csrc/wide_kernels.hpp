@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(WAVE * WAVES_PER_WG) sinkhorn_wide_value_kerne
     const int n_waves = (int)gridDim.x * WAVES_PER_WG;
     for (int tile = (int)blockIdx.x * WAVES_PER_WG + (int)threadIdx.x / WAVE; tile < n_tiles; tile += n_waves) {
         const int cnt = p.n_pairs - tile * 16 < 16 ? p.n_pairs - tile * 16 : 16;
-        ring_flush_body<CfgH32x16, WIDE_RT>(rec_base + (size_t)tile * 16 * WIDE_REC, p, cnt);
+        ring_flush_body<CfgH32x16, WIDE_RT, true>(rec_base + (size_t)tile * 16 * WIDE_REC, p, cnt);
     }
 }
 
