@@ -23,6 +23,8 @@ python tools/e2e_profile.py c3 > $O/e2e_tl_wasserstein_distance_c3.txt 2>&1
 python tools/cellw2_parity_c5.py 4 8 $O/cellw2_parity_c5.json > $O/cellw2_parity_c5.txt 2>&1
 python tools/shard_floor.py $O/shard_floor.json > $O/shard_floor_one_gpu.txt 2>&1
 python tools/host_enqueue_time.py > $O/host_enqueue_time.txt 2>&1
+python tools/host_to_host_probe.py > $O/host_to_host_probe.txt 2>&1
+python tools/k2_occupancy_probe.py c3 c4 > $O/k2_occupancy_probe.txt 2>&1
 python tools/k_sweep.py > $O/k_sweep.txt 2>&1
 python tools/consumer_rate.py > $O/consumer_rate.txt 2>&1
 python tools/small_reg_probe.py > $O/small_reg_c3_reg0.01.txt 2>&1
