@@ -85,3 +85,33 @@ def test_wasserstein_distance_from_concurrent_threads_and_short_lived_callers():
     assert m0 - m1 <= 160 * 2 ** 20, "%.1f MB stayed reserved across the first caller after a shutdown" % ((m0 - m1) / 2 ** 20)
     assert m0 - m2 <= 192 * 2 ** 20
     assert np.array_equal(engine.sinkhorn_grid(P, M, 0.1), Es)         # and the library works after a shutdown
+
+
+def test_large_results_from_concurrent_callers_leave_the_pinned_block_intact(switches):
+    """Results of 1 MB and more leave the pinned staging block in pieces that the library's helper threads copy out while the next
+    piece is in flight (host_fetch, pilot_ot.hip): four concurrent callers -- each with its own staging block, all sharing the
+    helper threads -- get the bits of a lone caller with one copying thread, for the matrix and for the info arrays."""
+    P, M = make_problem(420, 20, 6, seed=11, cells_per_patient=500)            # 420 x 420 doubles = 1.4 MB
+    switches.setenv("PILOT_OT_FETCH_THREADS", "1")
+    E1, i1 = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+    X1 = engine.emd_grid(P, M)
+    switches.delenv("PILOT_OT_FETCH_THREADS")
+    E3, i3 = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+    assert np.array_equal(E1, E3) and all(np.array_equal(i1[k], i3[k]) for k in i1)
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(5):
+                if (tid + it) % 2:
+                    E, info = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+                    if not (np.array_equal(E, E1) and all(np.array_equal(info[k], i1[k]) for k in i1)):
+                        errors.append((tid, it, "sinkhorn differs"))
+                elif not np.array_equal(engine.emd_grid(P, M), X1):
+                    errors.append((tid, it, "exact differs"))
+        except Exception as e:                              # noqa: BLE001 -- reported below
+            errors.append((tid, repr(e)))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:3]

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU-box pass that produces everything the round commits under profiles/: usage tools/gpu_round_report.sh <tag>
 TAG=${1:-r06}
+# (before sending this to the GPU box: git rev-parse --short HEAD > tools/.git_sha -- the box has no .git, the PMC summaries are stamped from that file)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/report_$TAG
 mkdir -p $O
