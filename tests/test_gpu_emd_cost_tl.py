@@ -451,6 +451,27 @@ def test_pdist_kernel_vs_scipy_the_remaining_names(metric, K, D):
     assert np.all(np.diag(got) == 0)
 
 
+@pytest.mark.parametrize("D", [1, 2, 5, 30])
+def test_jensenshannon_of_proportional_rows_is_scipy_s_own_rounding(D):
+    """Proportional rows: the Jensen-Shannon distance is 0 up to rounding, and scipy returns the root of whatever the rounding left
+    -- 0, 1e-8, or NaN where the sum came out below zero.  scipy's build multiplies by the reciprocal of a row's sum; the kernel does
+    the same and lands on scipy's values and on scipy's NaNs (found by tools/fuzz_prepass.py: rows [0.4f] and [0.9f], D = 1)."""
+    import warnings
+    rng = np.random.default_rng(D)
+    base = np.abs(rng.standard_normal((40, D))).astype(np.float32).astype(np.float64)
+    X = np.concatenate([base, base * float(np.float32(0.9)), base * float(np.float32(2.25)), base[:5] * 0.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ssd.squareform(ssd.pdist(X, metric="jensenshannon"))
+    got = engine.pdist_square(X, metric="jensenshannon")
+    off = ~np.eye(len(X), dtype=bool)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    if D <= 2:
+        assert np.isnan(ref[off]).any()                       # (the case exists at the small dimensions)
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_cost_matrix_golden(name):
     g = load_golden(name)
