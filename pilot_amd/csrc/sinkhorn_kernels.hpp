@@ -1406,7 +1406,9 @@ sinkhorn_stream_kernel(GridParams p) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
         // (round 6, tried and dropped: refills -- and with them the error checks, which follow a refill by 1 + 20 n updates -- only on
         // every 2nd / 4th update of the wave, so that the refill and error blocks run in a quarter of the updates instead of 40 % /
-        // 56 %: c3 kernel 0.609 -> 0.626 / 0.651 ms, the idle column-updates cost more than the skipped blocks; profiles/r06/ab_experiments.md)
+        // 56 %: c3 kernel 0.609 -> 0.626 / 0.651 ms, the idle column-updates cost more than the skipped blocks; at one row-tile, where the
+        // update itself is a few dozen instructions, the gate changes nothing either (the 634 x 14 cohort 0.350 / 0.351 / 0.347 ms at gates
+        // 1 / 2 / 4, K = 20 .. 32 +2 .. +7 %): profiles/r06/ab_experiments.md sections 3 and 8)
         const unsigned long long wmask = ballot_b(want) & colmask;
         if (wmask) {
             if (res_next >= res_end && !exhausted) {
