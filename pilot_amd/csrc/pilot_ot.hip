@@ -210,6 +210,9 @@ constexpr int WIDE_MAX_K = 256;      // sinkhorn_wide_kernel: 128 < K <= 256, ei
 // (Round 4 had an experiment switch that ran the eight-waves-per-tile kernel below K = 128; it under-sized p_slot / img for the
 // wide layout and the experiment is done -- profiles/r04/ab_experiments.md #7 -- so the switch is gone.)
 constexpr int CTRL_INTS = pilot::CTRL_INTS;      // control block of a call: see pilot_ot_plan::track_count
+// ... followed by the two order histograms and, from a 128-byte boundary, the ticket counters of the fast launch's work queue
+constexpr int CTRL_SHARDS_AT = (CTRL_INTS + 2 * pilot::ORDER_NB + 31) / 32 * 32;
+constexpr int CTRL_BLOCK_INTS = CTRL_SHARDS_AT + pilot::QUEUE_SHARDS * pilot::QUEUE_SHARD_STRIDE;
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
@@ -507,7 +510,7 @@ PILOT_API int pilot_ot_plan_create(int N, int K, pilot_ot_plan **plan) {
         if (e == hipSuccess) e = hipMalloc(&pl->p_slot, p_bytes);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_list), sizeof(int) * (size_t)N * N);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->track_count), CTRL_BLOCK_INTS * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_list), sizeof(int) * (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->order_bucket), (size_t)N * N);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl->emd_counter), sizeof(int) * pilot::EMD_NQ * pilot::EMD_Q_STRIDE);
@@ -626,6 +629,7 @@ int run_generic(pilot_ot_plan *pl, const double *d_P, const double *d_M, double 
 
 // resident workgroups per CU of the single-tile stream kernel (mirrors pilot::min_waves_per_simd)
 int stream_min_waves(int w /* sizeof(T)/4 */, int RT, bool sym, bool track, int tv, bool split, bool half = false) {
+    if (half && !track && RT <= pilot::HALF_OCC4_MAX_RT) return 4;
     if (split) return RT <= (track ? pilot::SPLIT_OCC2_MAX_RT_TRACK : (half ? pilot::HALF_OCC2_MAX_RT : pilot::SPLIT_OCC2_MAX_RT)) ? 2 : 1;
     const int na = RT * 4 * RT * w;
     const bool greg = !split && sym && na <= pilot::GREG_MAX;
@@ -708,7 +712,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         return fail(PILOT_OT_ENOTSUP, "K=%d with a %ssymmetric cost needs %zu B of LDS (> %zu) in this precision", K, sym ? "" : "non-",
                     fixed + pilot::WAVES_PER_WG * slot_bytes, LDS_BYTES);
     pl->order_hist = pl->track_count + CTRL_INTS;     // one control block, one memset per call
-    HIP_TRY(hipMemsetAsync(pl->track_count, 0, (CTRL_INTS + 2 * pilot::ORDER_NB) * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(pl->track_count, 0, CTRL_BLOCK_INTS * sizeof(int), s));
     void *img = pl->img;
     void *Pt = pl->p_slot;
     if (n_rows == 0) return PILOT_OT_OK;
@@ -734,6 +738,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
     p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
+    p.queue_shards = pl->track_count + CTRL_SHARDS_AT;       // (the fast launch up to two row-tiles; the list launches below draw from one counter)
     p.ring = 0;
     p.fb_list = nullptr; p.fb_count = nullptr; p.bands = 1;
     // pairs that end in NaN ("Numerical errors" in POT) are collected and re-solved by the POT-literal kernel, which
@@ -798,6 +803,9 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         HIP_TRY(launch(tv, false, wgs, StreamLds{}));
     } else if (!track_all) {
         int want = stream_min_waves(w, RT, sym, false, tv, split, half);
+        // (K <= 4: a third of the pairs tau-absorb and are handed over, and the hand-over's atomics and list stores are what more resident
+        // waves contend for -- K = 3 / 4 at N = 600: 0.60 / 0.64 ms at two workgroups per CU, 0.69 / 0.72 at four; from K = 5 on four win)
+        if (half && K <= 4 && want > 2) want = 2;
         if ((p.debug >> 4) & 7) want = (p.debug >> 4) & 7;           // experiment: resident workgroups per CU
         // split configurations up to 4 row-tiles flush their ring inline and park U in LDS meanwhile (pilot::parked_flush):
         // one 16-byte line per lane and row-tile
@@ -818,7 +826,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
-    p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
+    p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2; p.queue_shards = nullptr;
     p.solo_blocks = 0;
     size_t fixed_t = fixed;
     if (half) {     // tracking pass of the fp16-split configuration: the bf16-split kernel on its own operand block
@@ -939,7 +947,7 @@ int run_wide(pilot_ot_plan *pl, const double *d_P, const double *d_M, double reg
     p.max_iter = num_iter_max; p.period = check_period;
     p.stop_thr = stop_thr; p.tau = tau; p.floor_ulps = floor_ulps;
     p.emd = d_emd; p.iters = d_iters; p.err = d_err; p.flags = d_flags;
-    p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1;
+    p.track_list = pl->track_list; p.track_count = pl->track_count; p.queue_head = pl->track_count + 1; p.queue_shards = nullptr;
     p.ring = 0; p.bands = 1;
     p.fb_list = nullptr; p.fb_count = nullptr;
     p.nan_list = pl->nan_list; p.nan_count = pl->track_count + 10;

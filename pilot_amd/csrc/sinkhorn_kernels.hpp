@@ -749,6 +749,16 @@ __device__ inline void panel_product_split(const typename C::T *form, const type
     panel_product_pieces<C, RT>(form, form1, lane, B, OUT, last_init);
 }
 
+// Work queue of the fast launch at one / two row-tiles (K <= 32): 16-item batches are handed out by QUEUE_SHARDS ticket counters on
+// cache lines of their own (counter c hands out the batches c, c + QUEUE_SHARDS, ...).  One counter for all serialises: 11.4 ns of one
+// L2 atomic unit per draw whatever the batch costs -- the reference test's cohort (634 x 14, 25 000 draws: 0.29 of the main kernel's
+// 0.35 ms) and every grid of a few cell types ran at 1.4e9 pairs/s at most, and every wave's last, empty draw queued on the same
+// address (6 144 waves: 70 us).  From three row-tiles on a batch costs more than its draw and the single counter stays: with the
+// shards c3 / c4 measured +1 % / +4 % (a wave gives up after four empty counters: the long batches of the last counters are left to
+// fewer waves), and a variant that flags empty counters and steals from any live one cost the small kernels a wave per SIMD in
+// registers (profiles/r06/ab_experiments.md section 9).
+constexpr int QUEUE_SHARD_MAX_RT = 2;
+constexpr int QUEUE_SHARDS = 32, QUEUE_SHARD_STRIDE = 32;
 struct GridParams {
     const void *P;        // N x KP, element type T, every row in accumulator-slot order [tile][group][reg], 0 in padding;
                           // then N stop thresholds (one per column patient)
@@ -767,6 +777,8 @@ struct GridParams {
     int *track_list;      // fast kernel appends pairs that need POT absorption tracking
     int *track_count;
     int *queue_head;      // dynamic work queue of this launch (zeroed by the host before the launch)
+    int *queue_shards;    // nullable (the fast launch): QUEUE_SHARDS ticket counters, QUEUE_SHARD_STRIDE ints apart, zeroed by the host --
+                          //   used instead of queue_head, see the draw in sinkhorn_stream_kernel
     const int *solo_len;  // fast launch: device-side number of leading list items (exact duplicates a == b) for solo_pairs
     int *solo_head;       //   their queue head
     int solo_blocks;      //   leading workgroups of the launch that run solo_pairs (they start first); 0: none
@@ -1162,6 +1174,7 @@ constexpr int GREG_MAX = 64;
 #define PILOT_HALF_SOLO_MIN_RT 1         // (3: duplicates of the fp16-split configuration stay in tiles up to K = 32)
 #endif
 constexpr int HALF_SOLO_MIN_RT = PILOT_HALF_SOLO_MIN_RT;
+constexpr int HALF_OCC4_MAX_RT = 2;
 constexpr int SPLIT_OCC2_MAX_RT = PILOT_SPLIT_OCC2_MAX_RT, SPLIT_OCC2_MAX_RT_TRACK = PILOT_SPLIT_OCC2_MAX_RT_TRACK, HALF_OCC2_MAX_RT = PILOT_HALF_OCC2_MAX_RT;
 // live panel registers per lane: A, B, U, V, ACC (+ RU, RV when tracking)
 // the operand image is kept in registers when it needs <= 64 VGPRs per lane and the cost is symmetric
@@ -1177,6 +1190,9 @@ template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int panel
 template <class C, int RT, bool SYM, bool TRACK, int TV = 0> constexpr int min_waves_per_simd() {
     // split variants: two waves per SIMD up to SPLIT_OCC2_MAX_RT row tiles (tracking variants: SPLIT_OCC2_MAX_RT_TRACK), one wave
     // with the whole register file beyond (3 waves per SIMD at RT <= 4: slower)
+    // (fp16-split fast kernel at one / two row-tiles: four -- 82 / 116 registers; with the sharded work queue the 634 x 14 cohort runs
+    // 0.242 / 0.195 / 0.185 / 0.193 ms at 2 / 3 / 4 / 6 workgroups per CU, K = 16 .. 32 -12 .. -22 %: tools/small_k_occupancy_probe.py)
+    if (C::HALF && !TRACK && RT <= HALF_OCC4_MAX_RT) return 4;
     if (C::SPLIT) return RT <= (TRACK ? SPLIT_OCC2_MAX_RT_TRACK : (C::HALF ? HALF_OCC2_MAX_RT : SPLIT_OCC2_MAX_RT)) ? 2 : 1;
     return panel_regs<C, RT, SYM, TRACK, TV>() <= 128 ? 4 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 168 ? 3 : (panel_regs<C, RT, SYM, TRACK, TV>() <= 256 ? 2 : 1));
 }
@@ -1401,6 +1417,9 @@ sinkhorn_stream_kernel(GridParams p) {
     const int n_tile_waves = ((int)gridDim.x - (solo_in_stream<C, RT, SYM, TRACK, TV>() ? p.solo_blocks : 0)) * WAVES_PER_WG;
     const int queue_start = (solo_in_stream<C, RT, SYM, TRACK, TV>() && p.solo_len && p.solo_blocks > 0) ? *p.solo_len : 0;
     bool want = true;  // column asks for a (new) pair
+    constexpr bool SHARDED_QUEUE = RT <= QUEUE_SHARD_MAX_RT && !TRACK;
+    int qc = wave_id % QUEUE_SHARDS, q_tries = 0;                       // (sharded queue: the counter this wave draws from)
+    const int q_max_tries = n_tile_waves >= QUEUE_SHARDS ? 4 : QUEUE_SHARDS;
     const bool hand_all_over = C::HALF && p.unequal && *p.unequal != 0;
     for (;;) {
         // ---- (re)fill columns: a new pair starts with u = v = 1/K and ACC = G^T u0 (table) ----------
@@ -1420,6 +1439,21 @@ sinkhorn_stream_kernel(GridParams p) {
                 if (first_draw) {
                     base = queue_start + wave_id * TILE;
                     first_draw = false;
+                } else if (SHARDED_QUEUE && p.queue_shards) {
+                    // ticket t of counter c is batch c + QUEUE_SHARDS t behind the statically dealt ones.  A wave starts on the counter
+                    // of its own number and moves on when a counter has run out; every counter has waves that start on it and drain it
+                    // (a launch with fewer waves than counters makes the full round), the batches of all counters interleave, so they run
+                    // out within a round of each other and a wave gives up after a few empty ones
+                    base = n_items;
+                    while (q_tries < q_max_tries) {
+                        int t = 0;
+                        if (lane == 0) t = __hip_atomic_fetch_add(p.queue_shards + qc * QUEUE_SHARD_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t = __builtin_amdgcn_readfirstlane(t);
+                        const long b = (long)queue_start + ((long)n_tile_waves + qc + (long)QUEUE_SHARDS * t) * TILE;
+                        if (b < n_items) { base = (int)b; q_tries = 0; break; }
+                        ++q_tries;
+                        qc = qc + 1 == QUEUE_SHARDS ? 0 : qc + 1;
+                    }
                 } else {
                     if (lane == 0) base = __hip_atomic_fetch_add(p.queue_head, TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     base = __builtin_amdgcn_readfirstlane(base) + n_tile_waves * TILE;
