@@ -766,7 +766,15 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     p.debug = debug;
     const int tiles = (n_pairs + TILE - 1) / TILE;
     // exact duplicates (a == b): one wave per pair in the leading workgroups of the fast launch (symmetric cost, K <= 64)
-    const bool solo = stream_has_solo(w, RT, sym, tv, split, half) && !(p.debug & 512) && !track_all;
+    // ... while the grid is small.  A wave that iterates ONE pair has the shorter update (K = 50: 0.57 us against 0.77 us for a lone
+    // 16-pair wave), which is what a launch with fewer tiles than wave slots waits for (c2; the row shards of a multi-device call);
+    // on a full device the 600 diagonal pairs of c3 (165 updates on average, up to 301) on 600 waves of their own are a tail instead:
+    // main kernel 0.617 -> 0.584 ms with the duplicates in the tiles (tools/solo_probe.py; crossover between 5 600 and 7 500 tiles at 2 048
+    // wave slots).  The rule reads the FULL grid (N x N), not the rows of this call: a row shard and the full grid send the same pair
+    // down the same path, so their bits agree.
+    const long full_tiles = ((long)N * N + TILE - 1) / TILE;
+    const long wave_slots = (long)pl->n_cu * stream_min_waves(w, RT, sym, false, tv, split, half) * pilot::WAVES_PER_WG;
+    const bool solo = stream_has_solo(w, RT, sym, tv, split, half) && !(p.debug & 512) && !track_all && full_tiles < 3 * wave_slots;
     int solo_blocks = 0;
     {
         // longest-first work order (see order_bucket_kernel)
