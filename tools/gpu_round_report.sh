@@ -26,6 +26,10 @@ python tools/shard_floor.py $O/shard_floor.json > $O/shard_floor_one_gpu.txt 2>&
 python tools/host_enqueue_time.py > $O/host_enqueue_time.txt 2>&1
 python tools/host_to_host_probe.py > $O/host_to_host_probe.txt 2>&1
 python tools/k2_occupancy_probe.py c3 c4 > $O/k2_occupancy_probe.txt 2>&1
+python tools/small_k_occupancy_probe.py > $O/small_k_occupancy_probe.txt 2>&1
+python tools/tail_probe.py c3 c4 > $O/tail_probe.txt 2>&1
+python tools/solo_probe.py > $O/solo_probe.txt 2>&1
+python tools/update_latency_probe.py > $O/update_latency_probe.txt 2>&1
 python tools/k_sweep.py > $O/k_sweep.txt 2>&1
 python tools/consumer_rate.py > $O/consumer_rate.txt 2>&1
 python tools/small_reg_probe.py > $O/small_reg_c3_reg0.01.txt 2>&1
