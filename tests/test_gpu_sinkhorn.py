@@ -697,3 +697,25 @@ def test_host_workspace_cache_across_shapes_and_shutdown():
     part = engine.sinkhorn_grid(*make_problem(40, 20, 6, seed=60, cells_per_patient=300), 0.2, precision="fp64",
                                 row_begin=3, row_end=9)
     np.testing.assert_array_equal(part, outs[(40, 20)][0][3:9])
+
+
+@pytest.mark.parametrize("N,K", [(460, 8), (330, 40)])
+def test_diagonal_of_a_large_grid_stays_in_the_tiles_and_row_shards_agree_bit_for_bit(N, K, switches):
+    """Exact duplicates (the diagonal, a == b) run one pair per wave only while the FULL grid is small (N^2 / 16 below three times the
+    launch's wave slots: N < 443 at K <= 32, N < 314 at 33 <= K <= 64 on 256 CUs); above that they stay in the 16-pair tiles, because 600
+    one-pair waves were the tail of the c3 launch.  The rule reads N, not the rows of the call: a row shard of such a grid keeps its
+    diagonal in the tiles too and returns the full grid's bits; both paths are within the f32-class tolerance of the oracle."""
+    P, M = make_problem(N, K, 6, seed=N + K, cells_per_patient=400)
+    Eo, io = O.sinkhorn_grid(P, M, 0.1, n_threads=16, return_info=True)
+    Eg, ig = engine.sinkhorn_grid(P, M, 0.1, return_info=True)
+    assert np.abs(Eg - Eo).max() <= TOL32
+    d = np.arange(N)
+    itd = ig["iters"][d, d]
+    assert np.all(itd <= io["iters"][d, d]) and np.all((itd % 20 == 1) | (itd == 1000))      # (POT's checks, or its cap)
+    for rb, re_, rs in ((0, N, 8), (3, N, 5), (N // 2, N // 2 + 1, 1)):
+        part = engine.sinkhorn_grid(P, M, 0.1, row_begin=rb, row_end=re_, row_step=rs)
+        np.testing.assert_array_equal(part, Eg[rb:re_:rs])
+    # the one-wave path for the same diagonal (forced off / the small-grid rule cannot be forced on: compare the two paths' values)
+    switches.setenv("PILOT_OT_DEBUG", "512")
+    Et = engine.sinkhorn_grid(P, M, 0.1)
+    np.testing.assert_array_equal(Et, Eg)                    # (already in the tiles: the switch changes nothing at this size)
