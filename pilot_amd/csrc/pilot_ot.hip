@@ -212,7 +212,8 @@ constexpr int WIDE_MAX_K = 256;      // sinkhorn_wide_kernel: 128 < K <= 256, ei
 constexpr int CTRL_INTS = pilot::CTRL_INTS;      // control block of a call: see pilot_ot_plan::track_count
 // ... followed by the two order histograms and, from a 128-byte boundary, the ticket counters of the fast launch's work queue
 constexpr int CTRL_SHARDS_AT = (CTRL_INTS + 2 * pilot::ORDER_NB + 31) / 32 * 32;
-constexpr int CTRL_BLOCK_INTS = CTRL_SHARDS_AT + pilot::QUEUE_SHARDS * pilot::QUEUE_SHARD_STRIDE;
+constexpr int CTRL_SHARDS_TRACK_AT = CTRL_SHARDS_AT + pilot::QUEUE_SHARDS * pilot::QUEUE_SHARD_STRIDE;      // (the tracking launch's)
+constexpr int CTRL_BLOCK_INTS = CTRL_SHARDS_TRACK_AT + pilot::QUEUE_SHARDS * pilot::QUEUE_SHARD_STRIDE;
 constexpr int TIMING_RING = 64;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
@@ -834,7 +835,8 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], s)); HIP_TRY(hipEventRecord(ev[2], s)); }
     // second pass: pairs in which POT would tau-absorb, with the absorption iterations tracked
-    p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2; p.queue_shards = nullptr;
+    p.list = pl->track_list; p.list_len = pl->track_count; p.queue_head = pl->track_count + 2;
+    p.queue_shards = pl->track_count + CTRL_SHARDS_TRACK_AT;     // (used by the tracking kernels up to two row-tiles)
     p.solo_blocks = 0;
     size_t fixed_t = fixed;
     if (half) {     // tracking pass of the fp16-split configuration: the bf16-split kernel on its own operand block
@@ -870,7 +872,7 @@ int run_grid(int cfg, pilot_ot_plan *pl, const double *d_P, const double *d_M, d
         HIP_TRY(pilot::launch_prep(pilot::CFG_F64, d_M, K, RT64, reg, img, d_P, Pt, N, 2, stop_thr, floor_ulps, 0, row_begin, row_step,
                                    pl->order_bucket, pl->order_hist, pl->order_list, pl->track_count + 4, pl->track_count + 1, 0, 1, s));
         pilot::GridParams q = p;
-        q.list = mixed ? pl->track_list : fb_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9;
+        q.list = mixed ? pl->track_list : fb_list; q.list_len = pl->track_count + 8; q.queue_head = pl->track_count + 9; q.queue_shards = nullptr;
         q.img = img;                        // (the fp16-split configuration's tracking pass had moved it to its own block)
         q.fb_list = nullptr; q.fb_count = nullptr; q.bands = 1;
         q.nan_list = pl->nan_list; q.nan_count = pl->track_count + 10;

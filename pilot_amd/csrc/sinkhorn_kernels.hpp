@@ -1417,7 +1417,7 @@ sinkhorn_stream_kernel(GridParams p) {
     const int n_tile_waves = ((int)gridDim.x - (solo_in_stream<C, RT, SYM, TRACK, TV>() ? p.solo_blocks : 0)) * WAVES_PER_WG;
     const int queue_start = (solo_in_stream<C, RT, SYM, TRACK, TV>() && p.solo_len && p.solo_blocks > 0) ? *p.solo_len : 0;
     bool want = true;  // column asks for a (new) pair
-    constexpr bool SHARDED_QUEUE = RT <= QUEUE_SHARD_MAX_RT && !TRACK;
+    constexpr bool SHARDED_QUEUE = RT <= QUEUE_SHARD_MAX_RT;
     int qc = wave_id % QUEUE_SHARDS, q_tries = 0;                       // (sharded queue: the counter this wave draws from)
     const int q_max_tries = n_tile_waves >= QUEUE_SHARDS ? 4 : QUEUE_SHARDS;
     const bool hand_all_over = C::HALF && p.unequal && *p.unequal != 0;
