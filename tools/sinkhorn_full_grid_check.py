@@ -16,7 +16,7 @@ for spec in (sys.argv[1:] or ["c3:1.0", "c3:0.1", "c3:0.01", "c4:0.1:16"]):
     N, K = P.shape
     Eg, ig = engine.sinkhorn_grid(P, M, reg, row_step=step, return_info=True)
     t = time.perf_counter()
-    Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=16, return_info=True)
+    Eo, io = O.sinkhorn_grid(P, M, reg, row_step=step, n_threads=(16 if Eg.size <= 400000 else min(64, __import__('os').cpu_count() or 16)), return_info=True)
     dt = time.perf_counter() - t
     last_o, last_g = (io["flags"] & O.FLAG_ABSORB_ON_LAST) > 0, (ig["flags"] & _lib.FLAG_ABSORB_LAST) > 0
     last = last_o | last_g
