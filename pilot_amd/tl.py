@@ -256,8 +256,11 @@ def _values_at(series, rows):
     if isinstance(series.dtype, pd.CategoricalDtype):
         values = series.array
         codes = values.codes[np.asarray(rows, dtype=np.int64)]
-        cats = values.categories
-        return [cats[c] if c >= 0 else np.nan for c in codes]
+        cats = values.categories.to_numpy()             # (one array lookup: `categories[c]` per element is 0.4 us of pandas each)
+        out = list(cats[np.where(codes >= 0, codes, 0)]) if len(cats) else [np.nan] * len(codes)
+        for i in np.flatnonzero(codes < 0):
+            out[i] = np.nan
+        return out
     values = series.to_numpy()
     return [values[int(r)] for r in rows]
 
